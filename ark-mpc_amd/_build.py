@@ -1,0 +1,82 @@
+"""Build recipe for the engine's native libraries (hipcc, gfx950 only; no GPU needed to build).
+
+    python ark-mpc_amd/_build.py [--force]      (also driven by __graft_entry__.build())
+
+Outputs (git-ignored, but they travel to the GPU box with the tree):
+    ark-mpc_amd/lib/libarkmpc_hip.so    the C-ABI engine (include/arkmpc.h)
+    ark-mpc_amd/lib/libarkmpc_host.so   the C++ host-side mirror of the reference's fabric API
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "lib", "obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "sha3_host.hip"]
+ENGINE_DEPS = ["fp.cuh", "field_consts.inc", "arkmpc_internal.hpp", os.path.join("..", "..", "include", "arkmpc.h")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_engine(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    deps = [os.path.join(CSRC, d) for d in ENGINE_DEPS]
+    objs, jobs = [], []
+    for src in ENGINE_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + deps):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for out in ex.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    so = os.path.join(LIB, "libarkmpc_hip.so")
+    if force or jobs or _newer(so, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs)
+    return so
+
+
+def build_host(force=False, verbose=False):
+    """C++ host-side mirror (MpcFabric / AuthenticatedScalar batch API) linked against the engine."""
+    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")] if os.path.isdir(HOST) else []
+    if not srcs:
+        return None
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp") or f.endswith(".h")]
+    so = os.path.join(LIB, "libarkmpc_host.so")
+    if force or _newer(so, srcs + hdrs + [os.path.join(LIB, "libarkmpc_hip.so")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-I", os.path.join(HERE, "..", "include"),
+              "-o", so] + srcs + ["-L", LIB, "-larkmpc_hip", "-Wl,-rpath,$ORIGIN"])
+    return so
+
+
+def build_all(force=False, verbose=False):
+    a = build_engine(force, verbose)
+    b = build_host(force, verbose)
+    return a, b
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,361 @@
+// arkmpc_curve.hip -- HIP kernels + C ABI for the curve side of the hot path (SURVEY.md section 8a
+// rows a15-a19): BN254 G1 point add / sub / neg / scalar-mul (K7, K8) and the PointShare batch ops
+// behind AuthenticatedPointResult (online-phase/src/algebra/curve/{curve,share,authenticated_curve}.rs).
+//
+// Points cross the ABI as ark-ec short-Weierstrass `Projective{x,y,z}` = Jacobian coordinates over
+// Fq in Montgomery form, identity = (1,1,0).  The group law is representation-free, so results are
+// compared with the reference on AFFINE coordinates (what arkworks' PartialEq and the wire format
+// `serialize_compressed` see, curve.rs:103-108); the Jacobian triple itself depends on the addition
+// chain.  Formulas: add-2007-bl and dbl-2009-l for a = 0 (y^2 = x^3 + 3).
+//
+// These kernels are integer-ALU bound (a scalar-mul is ~6k Fq multiplications against 128 B of
+// traffic), one thread per point.
+#include "arkmpc_internal.hpp"
+
+#define TPB_EC 128
+constexpr int FQ = F_BN254_FQ;
+constexpr int FR = F_BN254_FR;
+
+struct G1 {
+    Fe x, y, z;
+};
+
+__device__ __forceinline__ G1 g1_load(const u64* p) {
+    G1 r;
+    r.x = fe_load(p); r.y = fe_load(p + 4); r.z = fe_load(p + 8);
+    return r;
+}
+// stores the canonical identity (1,1,0) for any z == 0 value
+__device__ __forceinline__ void g1_store(u64* p, const G1& a) {
+    const bool inf = fe_is_zero(a.z);
+    const Fe one = fe_one<FQ>();
+    fe_store(p, fe_select(inf, one, a.x));
+    fe_store(p + 4, fe_select(inf, one, a.y));
+    fe_store(p + 8, a.z);
+}
+__device__ __forceinline__ G1 g1_identity() {
+    G1 r;
+    r.x = fe_one<FQ>(); r.y = fe_one<FQ>(); r.z = fe_zero<FQ>();
+    return r;
+}
+__device__ __forceinline__ G1 g1_generator() {  // (1, 2, 1)
+    G1 r;
+    r.x = fe_one<FQ>(); r.y = fe_dbl<FQ>(fe_one<FQ>()); r.z = fe_one<FQ>();
+    return r;
+}
+__device__ __forceinline__ G1 g1_select(bool c, const G1& a, const G1& b) {
+    G1 r;
+    r.x = fe_select(c, a.x, b.x); r.y = fe_select(c, a.y, b.y); r.z = fe_select(c, a.z, b.z);
+    return r;
+}
+__device__ __forceinline__ G1 g1_neg(const G1& a) {
+    G1 r = a;
+    r.y = fe_neg<FQ>(a.y);
+    return r;
+}
+// dbl-2009-l (a = 0).  z = 0 in -> z = 0 out, so the identity needs no branch.
+__device__ __noinline__ G1 g1_double(const G1& p) {
+    Fe A = fe_sqr<FQ>(p.x), B = fe_sqr<FQ>(p.y), C = fe_sqr<FQ>(B);
+    Fe t = fe_sqr<FQ>(fe_add<FQ>(p.x, B));
+    Fe D = fe_dbl<FQ>(fe_sub<FQ>(fe_sub<FQ>(t, A), C));
+    Fe E = fe_add<FQ>(fe_dbl<FQ>(A), A);
+    Fe Fq_ = fe_sqr<FQ>(E);
+    G1 r;
+    r.x = fe_sub<FQ>(Fq_, fe_dbl<FQ>(D));
+    Fe C8 = fe_dbl<FQ>(fe_dbl<FQ>(fe_dbl<FQ>(C)));
+    r.y = fe_sub<FQ>(fe_mul<FQ>(E, fe_sub<FQ>(D, r.x)), C8);
+    r.z = fe_dbl<FQ>(fe_mul<FQ>(p.y, p.z));
+    return r;
+}
+// add-2007-bl with the exceptional cases of the group law handled explicitly
+// (identity operands, P + P, P + (-P)), as ark-ec's `Projective += Projective` does.
+__device__ __noinline__ G1 g1_add(const G1& p, const G1& q) {
+    const bool pinf = fe_is_zero(p.z), qinf = fe_is_zero(q.z);
+    Fe Z1Z1 = fe_sqr<FQ>(p.z), Z2Z2 = fe_sqr<FQ>(q.z);
+    Fe U1 = fe_mul<FQ>(p.x, Z2Z2), U2 = fe_mul<FQ>(q.x, Z1Z1);
+    Fe S1 = fe_mul<FQ>(fe_mul<FQ>(p.y, q.z), Z2Z2), S2 = fe_mul<FQ>(fe_mul<FQ>(q.y, p.z), Z1Z1);
+    Fe H = fe_sub<FQ>(U2, U1);
+    Fe rr = fe_dbl<FQ>(fe_sub<FQ>(S2, S1));
+    G1 out;
+    if (!pinf && !qinf && fe_is_zero(H)) {  // same x: doubling or inverse points (rare, divergent)
+        if (fe_is_zero(rr)) return g1_double(p);
+        return g1_identity();
+    }
+    Fe I = fe_sqr<FQ>(fe_dbl<FQ>(H));
+    Fe J = fe_mul<FQ>(H, I);
+    Fe V = fe_mul<FQ>(U1, I);
+    out.x = fe_sub<FQ>(fe_sub<FQ>(fe_sqr<FQ>(rr), J), fe_dbl<FQ>(V));
+    out.y = fe_sub<FQ>(fe_mul<FQ>(rr, fe_sub<FQ>(V, out.x)), fe_dbl<FQ>(fe_mul<FQ>(S1, J)));
+    Fe zz = fe_sub<FQ>(fe_sub<FQ>(fe_sqr<FQ>(fe_add<FQ>(p.z, q.z)), Z1Z1), Z2Z2);
+    out.z = fe_mul<FQ>(zz, H);
+    out = g1_select(qinf, p, out);
+    out = g1_select(pinf, q, out);
+    return out;
+}
+// [s]P, s given in Montgomery form over Fr (curve.rs:403-409).  MSB-first double-and-add with
+// wave-uniform control flow: every lane doubles; the add is computed when any lane needs it and
+// merged per lane with a select.
+__device__ __forceinline__ G1 g1_scalar_mul(const G1& p, const Fe& s_mont) {
+    const Fe s = fe_to_canonical<FR>(s_mont);
+    G1 acc = g1_identity();
+    for (int limb = 7; limb >= 0; --limb) {
+        const u32 w = s.v[limb];
+        for (int bit = 31; bit >= 0; --bit) {
+            acc = g1_double(acc);
+            const bool take = (w >> bit) & 1u;
+            if (__any(take)) {
+                G1 sum = g1_add(acc, p);
+                acc = g1_select(take, sum, acc);
+            }
+        }
+    }
+    return acc;
+}
+// Fq inversion by Fermat (a^(p-2)); only used by the affine / byte conversions
+__device__ __noinline__ Fe fq_inv(const Fe& a) {
+    using P = FieldParams<FQ>;
+    Fe acc = fe_one<FQ>();
+    for (int limb = 7; limb >= 0; --limb) {
+        u32 w = P::P(limb);
+        if (limb == 0) w -= 2u;  // p - 2 (p is odd and its low limb is > 2, so no borrow)
+        for (int bit = 31; bit >= 0; --bit) {
+            acc = fe_sqr<FQ>(acc);
+            if ((w >> bit) & 1u) acc = fe_mul<FQ>(acc, a);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& inf) {
+    inf = fe_is_zero(a.z);
+    Fe zi = fq_inv(a.z);  // 0 -> 0
+    Fe zi2 = fe_sqr<FQ>(zi);
+    x = fe_mul<FQ>(a.x, zi2);
+    y = fe_mul<FQ>(a.y, fe_mul<FQ>(zi2, zi));
+    if (inf) { x = fe_zero<FQ>(); y = fe_zero<FQ>(); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// K7: curve.rs:203-209 (+), :282-288 (-); NEGB selects subtraction (a + (-b)), as curve/share.rs:95-101
+template <bool NEGB>
+__global__ void __launch_bounds__(TPB_EC) k_g1_add(size_t n, const u64* a, const u64* b, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    G1 p = g1_load(a + 12 * i), q = g1_load(b + 12 * i);
+    if (NEGB) q = g1_neg(q);
+    g1_store(out + 12 * i, g1_add(p, q));
+}
+__global__ void __launch_bounds__(TPB_EC) k_g1_neg(size_t n, const u64* a, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    g1_store(out + 12 * i, g1_neg(g1_load(a + 12 * i)));
+}
+// K8: out_i = scalars[i * s_stride .. ] * points[i * p_stride ..]  (strides in u64 units; p_stride = 0 with
+// points == nullptr means the generator).  Covers CurvePoint*Scalar (curve.rs:403-409, :459-479),
+// PointShare*Scalar (curve/share.rs:108-114: two launches' worth, index i -> element i/2, scalar i/2),
+// ScalarShare*CurvePoint (scalar/share.rs:135-141) and ScalarShare*generator (authenticated_curve.rs:754-780).
+__global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* points, u32 p_stride, u32 p_div,
+                                                           const u64* scalars, u32 s_stride, u32 s_div, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    G1 p = points ? g1_load(points + (size_t)p_stride * (i / p_div)) : g1_generator();
+    Fe s = fe_load(scalars + (size_t)s_stride * (i / s_div));
+    g1_store(out + 12 * i, g1_scalar_mul(p, s));
+}
+// PointShare::add_public (curve/share.rs:57-60): share += rhs iff PARTY0 ; mac += mac_key * rhs
+__global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public(size_t n, int party, Fe key, const u64* shares, const u64* pub, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    G1 rhs = g1_load(pub + 12 * i);
+    G1 sh = g1_load(shares + 24 * i), mac = g1_load(shares + 24 * i + 12);
+    if (party == 0) sh = g1_add(sh, rhs);
+    mac = g1_add(mac, g1_scalar_mul(rhs, key));
+    g1_store(out + 24 * i, sh);
+    g1_store(out + 24 * i + 12, mac);
+}
+// value * mac_key - share.mac()  (authenticated_curve.rs:215-220)
+__global__ void __launch_bounds__(TPB_EC) k_point_mac_check(size_t n, Fe key, const u64* opened, const u64* shares, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    G1 v = g1_load(opened + 12 * i), mac = g1_load(shares + 24 * i + 12);
+    g1_store(out + 12 * i, g1_add(g1_scalar_mul(v, key), g1_neg(mac)));
+}
+// my + peer == identity  (authenticated_curve.rs:127-131), per element
+__global__ void __launch_bounds__(TPB_EC) k_point_mac_verify(size_t n, const u64* mine, const u64* peer, unsigned char* ok) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    G1 s = g1_add(g1_load(mine + 12 * i), g1_load(peer + 12 * i));
+    ok[i] = fe_is_zero(s.z) ? 1 : 0;
+}
+__global__ void __launch_bounds__(TPB_EC) k_pointshare_extract(size_t n, const u64* shares, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    g1_store(out + 12 * i, g1_load(shares + 24 * i));
+}
+__global__ void __launch_bounds__(TPB_EC) k_g1_to_affine(size_t n, const u64* pts, u64* out_xy, unsigned char* out_inf) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    Fe x, y; bool inf;
+    g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
+    fe_store(out_xy + 8 * i, x);
+    fe_store(out_xy + 8 * i + 4, y);
+    out_inf[i] = inf ? 1 : 0;
+}
+// CurvePoint::to_bytes (curve.rs:103-108) = ark-serialize compressed SW encoding: x little-endian,
+// bit 7 of the last byte set iff y > -y (as integers), bit 6 set (and x = 0) for the identity.
+__global__ void __launch_bounds__(TPB_EC) k_g1_to_bytes(size_t n, const u64* pts, unsigned char* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    Fe x, y; bool inf;
+    g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
+    Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(fe_neg<FQ>(y));
+    // y > -y  <=>  (-y) - y borrows
+    u32 br = 0, bo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nyc.v[k], yc.v[k], br, &bo); br = bo; }
+    u32 top = xc.v[7];
+    if (inf) top |= 0x40000000u;
+    else if (br) top |= 0x80000000u;
+    uint4* q = reinterpret_cast<uint4*>(out + 32 * i);
+    q[0] = make_uint4(xc.v[0], xc.v[1], xc.v[2], xc.v[3]);
+    q[1] = make_uint4(xc.v[4], xc.v[5], xc.v[6], top);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+#define ENTER_EC(ctx)                                                                           \
+    if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
+    CtxGuard guard__(ctx);                                                                      \
+    if (guard__.rc) return guard__.rc;                                                          \
+    if ((ctx)->field_id != ARKMPC_BN254_FR) { (ctx)->err = "point ops need a BN254_FR context"; return ARKMPC_ERR_UNSUPPORTED; }
+
+static inline bool party_ok(int p) { return p == 0 || p == 1; }
+
+extern "C" {
+
+static int g1_addsub(arkmpc_ctx* ctx, bool sub, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t mult) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    const size_t m = n * mult;  // mult = 2 treats n PointShares as 2n points
+    int ia = st.declare_in(a, m * 96), ib = st.declare_in(b, m * 96), io = st.declare_out(out, m * 96);
+    if (st.commit()) return st.rc;
+    if (m) {
+        dim3 g(blocks_for(m, TPB_EC)), t(TPB_EC);
+        if (sub) hipLaunchKernelGGL((k_g1_add<true>), g, t, 0, ctx->stream, m, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+        else hipLaunchKernelGGL((k_g1_add<false>), g, t, 0, ctx->stream, m, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+    }
+    return st.finish();
+}
+int arkmpc_g1_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return g1_addsub(ctx, false, n, a, b, out, 1); }
+int arkmpc_g1_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return g1_addsub(ctx, true, n, a, b, out, 1); }
+int arkmpc_pointshare_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return g1_addsub(ctx, false, n, a, b, out, 2); }
+int arkmpc_pointshare_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return g1_addsub(ctx, true, n, a, b, out, 2); }
+
+static int g1_neg_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* a, uint64_t* out) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, m * 96), io = st.declare_out(out, m * 96);
+    if (st.commit()) return st.rc;
+    if (m) hipLaunchKernelGGL(k_g1_neg, dim3(blocks_for(m, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, m, st.in<u64>(ia), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_g1_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return g1_neg_impl(ctx, n, a, out); }
+int arkmpc_pointshare_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return g1_neg_impl(ctx, 2 * n, a, out); }
+
+// generic scalar-mul launcher: m output points; point index = i / p_div, scalar index = i / s_div
+static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n_points, u32 p_stride, u32 p_div,
+                     const uint64_t* scalars, size_t scalar_bytes, u32 s_stride, u32 s_div, uint64_t* out) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int ip = points ? st.declare_in(points, n_points * 96) : -1;
+    int is = st.declare_in(scalars, scalar_bytes), io = st.declare_out(out, m * 96);
+    if (st.commit()) return st.rc;
+    if (m) {
+        hipLaunchKernelGGL(k_g1_scalar_mul, dim3(blocks_for(m, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, m,
+                           points ? st.in<u64>(ip) : (const u64*)nullptr, p_stride, p_div, st.in<u64>(is), s_stride, s_div, st.out<u64>(io));
+    }
+    return st.finish();
+}
+int arkmpc_g1_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out) {
+    if (n && !points) return ctx ? ark_bad(ctx, "null points") : ARKMPC_ERR_BAD_ARG;
+    return smul_impl(ctx, n, points, n, 12, 1, scalars, n * 32, 4, 1, out);
+}
+int arkmpc_g1_generator_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* scalars, uint64_t* out) {
+    return smul_impl(ctx, n, nullptr, 0, 0, 1, scalars, n * 32, 4, 1, out);
+}
+// PointShare * Scalar: output point j (0..2n) = shares_as_points[j] * scalars[j / 2]
+int arkmpc_pointshare_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, const uint64_t* scalars, uint64_t* out) {
+    if (n && !shares) return ctx ? ark_bad(ctx, "null shares") : ARKMPC_ERR_BAD_ARG;
+    return smul_impl(ctx, 2 * n, shares, 2 * n, 12, 1, scalars, n * 32, 4, 2, out);
+}
+// ScalarShare * generator: output point j = G * scalar_shares_as_scalars[j]
+int arkmpc_scalarshare_mul_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out) {
+    return smul_impl(ctx, 2 * n, nullptr, 0, 0, 1, scalar_shares, n * 64, 4, 1, out);
+}
+// ScalarShare * CurvePoint: output point j = points[j / 2] * scalar_shares_as_scalars[j]
+int arkmpc_scalarshare_mul_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, const uint64_t* points, uint64_t* out) {
+    if (n && !points) return ctx ? ark_bad(ctx, "null points") : ARKMPC_ERR_BAD_ARG;
+    return smul_impl(ctx, 2 * n, points, n, 12, 2, scalar_shares, n * 64, 4, 1, out);
+}
+
+int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                                 const uint64_t* pub_points, uint64_t* out) {
+    ENTER_EC(ctx);
+    if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int is = st.declare_in(shares, n * 192), ip = st.declare_in(pub_points, n * 96), io = st.declare_out(out, n * 192);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_pointshare_add_public, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, party_id,
+                              fe_from_host(mac_key), st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_pointshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int is = st.declare_in(shares, n * 192), io = st.declare_out(out_points, n * 96);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_pointshare_extract, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(is), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_point_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* opened_points,
+                                  const uint64_t* shares, uint64_t* out_chk_points) {
+    ENTER_EC(ctx);
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int iv = st.declare_in(opened_points, n * 96), is = st.declare_in(shares, n * 192), io = st.declare_out(out_chk_points, n * 96);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_point_mac_check, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, fe_from_host(mac_key),
+                              st.in<u64>(iv), st.in<u64>(is), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_point_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int im = st.declare_in(mine, n * 96), ip = st.declare_in(peer, n * 96), io = st.declare_out(out_ok, n);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_point_mac_verify, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(im), st.in<u64>(ip),
+                              st.out<unsigned char>(io));
+    return st.finish();
+}
+int arkmpc_g1_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy, uint8_t* out_inf) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(points, n * 96), io = st.declare_out(out_xy, n * 64), ii = st.declare_out(out_inf, n);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_g1_to_affine, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.out<u64>(io),
+                              st.out<unsigned char>(ii));
+    return st.finish();
+}
+int arkmpc_g1_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(points, n * 96), io = st.declare_out(out_bytes, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_g1_to_bytes, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.out<unsigned char>(io));
+    return st.finish();
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// arkmpc_internal.hpp -- context, error plumbing and host-buffer staging shared by the C-ABI TUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+#include "../../include/arkmpc.h"
+#include "fp.cuh"
+
+struct arkmpc_ctx {
+    int field_id = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool host_buffers = false;
+    std::mutex mu;
+    std::string err;
+    // device scratch arena for host-buffer staging and internal temporaries
+    char* arena = nullptr;
+    size_t arena_cap = 0;
+    size_t arena_used = 0;
+    // small device word for reductions (mac_verify) + pinned mirror
+    int* d_flag = nullptr;
+    int* h_flag = nullptr;
+    // pinned double buffer for the commitment pipeline
+    unsigned char* h_pin[2] = {nullptr, nullptr};
+    size_t h_pin_cap = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+#define ARK_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return ARKMPC_ERR_HIP;                                                              \
+        }                                                                                       \
+    } while (0)
+
+static inline int ark_bad(arkmpc_ctx* ctx, const char* what) {
+    if (ctx) ctx->err = what;
+    return ARKMPC_ERR_BAD_ARG;
+}
+
+// RAII: serialise calls on the context and make its device current
+struct CtxGuard {
+    arkmpc_ctx* c;
+    std::unique_lock<std::mutex> lk;
+    int rc = ARKMPC_OK;
+    explicit CtxGuard(arkmpc_ctx* ctx) : c(ctx), lk(ctx->mu) {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) { ctx->err = std::string("hipSetDevice: ") + hipGetErrorString(e); rc = ARKMPC_ERR_HIP; }
+    }
+};
+
+// Arena: bump allocator over one device allocation, reset at the end of each staged call.
+static inline int arena_reserve(arkmpc_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->arena_cap) return ARKMPC_OK;
+    ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) ARK_HIP(ctx, hipFree(ctx->arena));
+    ctx->arena = nullptr; ctx->arena_cap = 0;
+    size_t cap = bytes + (bytes >> 2) + (1 << 20);
+    ARK_HIP(ctx, hipMalloc((void**)&ctx->arena, cap));
+    ctx->arena_cap = cap;
+    return ARKMPC_OK;
+}
+
+// Staging of one API call.  In device mode `in`/`out` are pass-through (with an alignment check);
+// in host mode they carve device buffers out of the arena, upload inputs and remember outputs.
+struct Stage {
+    arkmpc_ctx* ctx;
+    int rc = ARKMPC_OK;
+    struct Out { void* host; void* dev; size_t bytes; };
+    std::vector<Out> outs;
+    struct In { const void* host; size_t bytes; size_t off; };
+    std::vector<In> ins;
+    struct OutPlan { void* host; size_t bytes; size_t off; };
+    std::vector<OutPlan> oplan;
+    size_t total = 0;
+    bool planned = false;
+    explicit Stage(arkmpc_ctx* c) : ctx(c) {}
+
+    static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+    // pass 1 (host mode): declare buffers; pass 2: resolve.  To keep call sites linear we do a
+    // two-phase protocol: declare_* returns an index, then commit() uploads, and ptr(i) resolves.
+    int declare_in(const void* p, size_t bytes) {
+        if (!p && bytes) { rc = ark_bad(ctx, "null input pointer"); }
+        ins.push_back({p, bytes, total}); total += align_up(bytes);
+        return (int)ins.size() - 1;
+    }
+    int declare_out(void* p, size_t bytes) {
+        if (!p && bytes) { rc = ark_bad(ctx, "null output pointer"); }
+        oplan.push_back({p, bytes, total}); total += align_up(bytes);
+        return (int)oplan.size() - 1;
+    }
+    int commit() {
+        if (rc) return rc;
+        if (!ctx->host_buffers) {
+            for (auto& i : ins) if (((uintptr_t)i.host & 15) != 0) return rc = ark_bad(ctx, "device pointer not 16-byte aligned");
+            for (auto& o : oplan) if (((uintptr_t)o.host & 15) != 0) return rc = ark_bad(ctx, "device pointer not 16-byte aligned");
+            planned = true;
+            return ARKMPC_OK;
+        }
+        rc = arena_reserve(ctx, total);
+        if (rc) return rc;
+        for (auto& i : ins) {
+            if (!i.bytes) continue;
+            hipError_t e = hipMemcpyAsync(ctx->arena + i.off, i.host, i.bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { ctx->err = std::string("H2D: ") + hipGetErrorString(e); return rc = ARKMPC_ERR_HIP; }
+        }
+        planned = true;
+        return ARKMPC_OK;
+    }
+    template <class T> const T* in(int idx) const {
+        return ctx->host_buffers ? (const T*)(ctx->arena + ins[idx].off) : (const T*)ins[idx].host;
+    }
+    template <class T> T* out(int idx) const {
+        return ctx->host_buffers ? (T*)(ctx->arena + oplan[idx].off) : (T*)oplan[idx].host;
+    }
+    // download outputs (host mode) and, in host mode, block until they have landed
+    int finish() {
+        if (rc) return rc;
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(le); return ARKMPC_ERR_HIP; }
+        if (!ctx->host_buffers) return ARKMPC_OK;
+        for (auto& o : oplan) {
+            if (!o.bytes) continue;
+            hipError_t e = hipMemcpyAsync(o.host, ctx->arena + o.off, o.bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) { ctx->err = std::string("D2H: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+        }
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->err = std::string("sync: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+        return ARKMPC_OK;
+    }
+};
+
+static inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+// Fe kernel argument from a host 4 x u64
+static inline Fe fe_from_host(const uint64_t v[4]) {
+    Fe r;
+    for (int i = 0; i < 4; ++i) { r.v[2 * i] = (u32)v[i]; r.v[2 * i + 1] = (u32)(v[i] >> 32); }
+    return r;
+}
+
+// host-side SHA3-256 (sha3_host.cpp)
+struct Sha3State { uint64_t st[25]; unsigned char buf[136]; size_t fill; };
+void sha3_256_init(Sha3State* s);
+void sha3_256_update(Sha3State* s, const unsigned char* msg, size_t len);
+void sha3_256_final(Sha3State* s, unsigned char out[32]);
+// integer value of 32 big-endian bytes reduced mod p, returned in Montgomery form (host big-int)
+void host_from_be_bytes_mod_order(int field_id, const unsigned char be[32], uint64_t out_mont[4]);
+void host_to_bytes_be(int field_id, const uint64_t mont[4], unsigned char out[32]);

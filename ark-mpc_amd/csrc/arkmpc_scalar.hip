@@ -1,0 +1,663 @@
+// arkmpc_scalar.hip -- HIP kernels + C ABI for the scalar side of ark-mpc's authenticated-share
+// hot path: Scalar / ScalarShare batch ops, Beaver
+// multiplication (K1 mask, K2 combine, K3 finish), batch open + MAC check (K4, K5, K6, H1).
+//
+// Kernel shape: one thread per gate, 256-thread workgroups (4 wave64), grid = ceil(n/256) -- at
+// n = 2^20 that is 4096 workgroups over 256 CUs.  Gates are independent, so there is no LDS use
+// and no inter-workgroup traffic; every kernel is a pure stream over HBM.  Elements are read as
+// 16-byte vector loads (two per 32-byte field element); measured on MI355X the 64-byte-strided
+// AoS pattern reaches 96% of a planar layout's rate (profiles/ubench_r01.log), so the arkworks
+// AoS layout is consumed directly, with no transpose pass.
+#include "arkmpc_internal.hpp"
+
+#define TPB 256
+
+// A column of a ScalarShare vector: element i lives at base + i*stride (u64 units).
+struct Col {
+    const u64* p;
+    u32 stride;
+};
+struct ColOut {
+    u64* p;
+    u32 stride;
+};
+
+// ---------------------------------------------------------------------------------------------
+// elementwise Scalar kernels
+// ---------------------------------------------------------------------------------------------
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
+
+template <int F, int OP>
+__global__ void __launch_bounds__(TPB) k_scalar_binop(size_t n, const u64* a, const u64* b, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe x = fe_load(a + 4 * i), y = fe_load(b + 4 * i), r;
+    if (OP == OP_ADD) r = fe_add<F>(x, y);
+    if (OP == OP_SUB) r = fe_sub<F>(x, y);
+    if (OP == OP_MUL) r = fe_mul<F>(x, y);
+    fe_store(out + 4 * i, r);
+}
+template <int F>
+__global__ void __launch_bounds__(TPB) k_scalar_neg(size_t n, const u64* a, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(out + 4 * i, fe_neg<F>(fe_load(a + 4 * i)));
+}
+template <int F>
+__global__ void __launch_bounds__(TPB) k_from_canonical(size_t n, const u64* a, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(out + 4 * i, fe_from_canonical<F>(fe_reduce_once_loop<F>(fe_load(a + 4 * i))));
+}
+template <int F>
+__global__ void __launch_bounds__(TPB) k_to_canonical(size_t n, const u64* a, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(out + 4 * i, fe_to_canonical<F>(fe_load(a + 4 * i)));
+}
+// K6: Scalar::to_bytes_be (scalar.rs:118-127).  32 big-endian bytes = limbs reversed, bytes swapped.
+template <int F>
+__global__ void __launch_bounds__(TPB) k_to_bytes_be(size_t n, const u64* a, unsigned char* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe c = fe_to_canonical<F>(fe_load(a + 4 * i));
+    uint4* q = reinterpret_cast<uint4*>(out + 32 * i);
+    q[0] = make_uint4(__builtin_bswap32(c.v[7]), __builtin_bswap32(c.v[6]), __builtin_bswap32(c.v[5]), __builtin_bswap32(c.v[4]));
+    q[1] = make_uint4(__builtin_bswap32(c.v[3]), __builtin_bswap32(c.v[2]), __builtin_bswap32(c.v[1]), __builtin_bswap32(c.v[0]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// ScalarShare kernels (share.rs:72-133)
+// ---------------------------------------------------------------------------------------------
+// share.rs:85-91 / :95-101: component-wise on (share, mac)
+template <int F, int OP>
+__global__ void __launch_bounds__(TPB) k_share_binop(size_t n, const u64* a, const u64* b, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe as = fe_load(a + 8 * i), am = fe_load(a + 8 * i + 4), bs = fe_load(b + 8 * i), bm = fe_load(b + 8 * i + 4);
+    Fe rs = (OP == OP_ADD) ? fe_add<F>(as, bs) : fe_sub<F>(as, bs);
+    Fe rm = (OP == OP_ADD) ? fe_add<F>(am, bm) : fe_sub<F>(am, bm);
+    fe_store(out + 8 * i, rs);
+    fe_store(out + 8 * i + 4, rm);
+}
+// share.rs:115-121
+template <int F>
+__global__ void __launch_bounds__(TPB) k_share_neg(size_t n, const u64* a, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(out + 8 * i, fe_neg<F>(fe_load(a + 8 * i)));
+    fe_store(out + 8 * i + 4, fe_neg<F>(fe_load(a + 8 * i + 4)));
+}
+// share.rs:74-82: share (+/-)= rhs iff PARTY0 ; mac (+/-)= mac_key * rhs
+template <int F, bool SUB>
+__global__ void __launch_bounds__(TPB) k_share_addsub_public(size_t n, int party, Fe key, const u64* a, const u64* pub, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe as = fe_load(a + 8 * i), am = fe_load(a + 8 * i + 4), r = fe_load(pub + 4 * i);
+    if (SUB) r = fe_neg<F>(r);
+    Fe rs = (party == 0) ? fe_add<F>(as, r) : as;
+    Fe rm = fe_add<F>(am, fe_mul<F>(key, r));
+    fe_store(out + 8 * i, rs);
+    fe_store(out + 8 * i + 4, rm);
+}
+// share.rs:125-131
+template <int F>
+__global__ void __launch_bounds__(TPB) k_share_mul_public(size_t n, const u64* a, const u64* pub, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe as = fe_load(a + 8 * i), am = fe_load(a + 8 * i + 4), r = fe_load(pub + 4 * i);
+    fe_store(out + 8 * i, fe_mul<F>(as, r));
+    fe_store(out + 8 * i + 4, fe_mul<F>(am, r));
+}
+template <int F>
+__global__ void __launch_bounds__(TPB) k_share_extract(size_t n, const u64* a, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(out + 4 * i, fe_load(a + 8 * i));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Beaver multiplication (authenticated_scalar.rs:848-879)
+// ---------------------------------------------------------------------------------------------
+// K1: d_i = x_i.share - a_i.share ; e_i = y_i.share - b_i.share ; out = d || e  (:863-868, :141-145).
+// The MAC halves of d and e are dead in the reference (only `.share()` is sent), so they are not computed.
+template <int F>
+__global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col a, Col b, u64* out_de) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe xs = fe_load(x.p + (size_t)x.stride * i), as = fe_load(a.p + (size_t)a.stride * i);
+    Fe ys = fe_load(y.p + (size_t)y.stride * i), bs = fe_load(b.p + (size_t)b.stride * i);
+    fe_store(out_de + 4 * i, fe_sub<F>(xs, as));
+    fe_store(out_de + 4 * (n + i), fe_sub<F>(ys, bs));
+}
+// K2: open_batch combine gate (:161-171)
+// (k_scalar_binop<F, OP_ADD> is used)
+
+// K3 (+K2 when FUSED): [xy] = de + d[b] + e[a] + [c]  (:871-878 == :835-840)
+//   share = d*b.share + e*a.share + c.share (+ d*e iff PARTY0)      (share.rs:74-77 add_public)
+//   mac   = d*b.mac   + e*a.mac   + c.mac   + mac_key*(d*e)
+// All sums are mod-p sums of canonical residues, so any association order is bit-identical to the
+// reference's ((db + de) + (ea + c)).
+template <int F, bool FUSED>
+__global__ void __launch_bounds__(TPB) k_beaver_finish(size_t n, int party, Fe key, const u64* de0, const u64* de1,
+                                                       const u64* e0, Col a_s, Col a_m, Col b_s, Col b_m, Col c_s, Col c_m,
+                                                       ColOut o_s, ColOut o_m) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe d, e;
+    if (FUSED) {  // de0 = my d||e, de1 = peer d||e
+        d = fe_add<F>(fe_load(de0 + 4 * i), fe_load(de1 + 4 * i));
+        e = fe_add<F>(fe_load(de0 + 4 * (n + i)), fe_load(de1 + 4 * (n + i)));
+    } else {  // de0 = opened d, e0 = opened e
+        d = fe_load(de0 + 4 * i);
+        e = fe_load(e0 + 4 * i);
+    }
+    const Fe bs = fe_load(b_s.p + (size_t)b_s.stride * i), bm = fe_load(b_m.p + (size_t)b_m.stride * i);
+    const Fe as = fe_load(a_s.p + (size_t)a_s.stride * i), am = fe_load(a_m.p + (size_t)a_m.stride * i);
+    const Fe cs = fe_load(c_s.p + (size_t)c_s.stride * i), cm = fe_load(c_m.p + (size_t)c_m.stride * i);
+    const Fe de = fe_mul<F>(d, e);
+    Fe rs = fe_add<F>(fe_add<F>(fe_mul<F>(d, bs), fe_mul<F>(e, as)), cs);
+    if (party == 0) rs = fe_add<F>(rs, de);
+    Fe rm = fe_add<F>(fe_add<F>(fe_mul<F>(d, bm), fe_mul<F>(e, am)), fe_add<F>(cm, fe_mul<F>(key, de)));
+    fe_store(o_s.p + (size_t)o_s.stride * i, rs);
+    fe_store(o_m.p + (size_t)o_m.stride * i, rm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch open + MAC check (authenticated_scalar.rs:278-354)
+// ---------------------------------------------------------------------------------------------
+// K4: chk_i = mac_key * opened_i - share_i.mac  (:299-311).  FUSED adds K2: opened_i = share_i.share + peer_i
+template <int F, bool FUSED>
+__global__ void __launch_bounds__(TPB) k_mac_check(size_t n, Fe key, const u64* opened_in, const u64* shares, const u64* peer,
+                                                   u64* out_opened, u64* out_chk) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe v;
+    if (FUSED) {
+        v = fe_add<F>(fe_load(shares + 8 * i), fe_load(peer + 4 * i));
+        fe_store(out_opened + 4 * i, v);
+    } else {
+        v = fe_load(opened_in + 4 * i);
+    }
+    Fe mac = fe_load(shares + 8 * i + 4);
+    fe_store(out_chk + 4 * i, fe_sub<F>(fe_mul<F>(key, v), mac));
+}
+// K5: all(mine_i + peer_i == 0)  (:218-219).  Sets *flag nonzero if any element fails.
+template <int F>
+__global__ void __launch_bounds__(TPB) k_mac_verify(size_t n, const u64* mine, const u64* peer, int* flag) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    bool bad = false;
+    if (i < n) bad = !fe_is_zero(fe_add<F>(fe_load(mine + 4 * i), fe_load(peer + 4 * i)));
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch helpers
+// ---------------------------------------------------------------------------------------------
+#define DISPATCH_FIELD(ctx, EXPR_F)                                                             \
+    switch ((ctx)->field_id) {                                                                  \
+        case 0: { constexpr int F = 0; EXPR_F; } break;                                         \
+        case 1: { constexpr int F = 1; EXPR_F; } break;                                         \
+        case 2: { constexpr int F = 2; EXPR_F; } break;                                         \
+        case 3: { constexpr int F = 3; EXPR_F; } break;                                         \
+        default: return ark_bad(ctx, "bad field id");                                           \
+    }
+
+#define ENTER(ctx)                                                                              \
+    if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
+    CtxGuard guard__(ctx);                                                                      \
+    if (guard__.rc) return guard__.rc;
+
+static inline bool party_ok(int p) { return p == 0 || p == 1; }
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: context
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* arkmpc_version(void) { return "arkmpc-hip 0.1 (gfx950)"; }
+
+int arkmpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int arkmpc_ctx_create(int field_id, int device, arkmpc_ctx** out_ctx) {
+    if (!out_ctx) return ARKMPC_ERR_BAD_ARG;
+    *out_ctx = nullptr;
+    if (field_id < 0 || field_id >= F_NFIELDS) return ARKMPC_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ARKMPC_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return ARKMPC_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ARKMPC_ERR_HIP;
+    arkmpc_ctx* c = new arkmpc_ctx();
+    c->field_id = field_id;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ARKMPC_ERR_HIP; }
+    c->own_stream = true;
+    if (hipMalloc((void**)&c->d_flag, 64) != hipSuccess || hipHostMalloc((void**)&c->h_flag, 64) != hipSuccess) {
+        delete c;
+        return ARKMPC_ERR_HIP;
+    }
+    *out_ctx = c;
+    return ARKMPC_OK;
+}
+
+int arkmpc_ctx_destroy(arkmpc_ctx* ctx) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->arena) (void)hipFree(ctx->arena);
+        if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+        if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->h_pin[i]) (void)hipHostFree(ctx->h_pin[i]);
+            if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+        }
+        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+    return ARKMPC_OK;
+}
+
+int arkmpc_ctx_set_stream(arkmpc_ctx* ctx, void* hip_stream) {
+    ENTER(ctx);
+    ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) { ARK_HIP(ctx, hipStreamDestroy(ctx->stream)); }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return ARKMPC_OK;
+}
+
+int arkmpc_ctx_set_host_buffers(arkmpc_ctx* ctx, int enabled) {
+    ENTER(ctx);
+    ctx->host_buffers = enabled != 0;
+    return ARKMPC_OK;
+}
+
+int arkmpc_sync(arkmpc_ctx* ctx) {
+    ENTER(ctx);
+    ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ARKMPC_OK;
+}
+
+const char* arkmpc_last_error(arkmpc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
+    ENTER(ctx);
+    if (!out_dptr) return ark_bad(ctx, "null out pointer");
+    ARK_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 16));
+    return ARKMPC_OK;
+}
+int arkmpc_free(arkmpc_ctx* ctx, void* dptr) {
+    ENTER(ctx);
+    ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ARK_HIP(ctx, hipFree(dptr));
+    return ARKMPC_OK;
+}
+int arkmpc_memcpy_h2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    ENTER(ctx);
+    ARK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ARKMPC_OK;
+}
+int arkmpc_memcpy_d2h(arkmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    ENTER(ctx);
+    ARK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ARKMPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: Scalar vectors
+// ---------------------------------------------------------------------------------------------
+static int scalar_binop(arkmpc_ctx* ctx, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 32), ib = st.declare_in(b, n * 32), io = st.declare_out(out, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) {
+        const u64 *da = st.in<u64>(ia), *db = st.in<u64>(ib);
+        u64* dout = st.out<u64>(io);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, {
+            if (op == OP_ADD) hipLaunchKernelGGL((k_scalar_binop<F, OP_ADD>), g, t, 0, ctx->stream, n, da, db, dout);
+            if (op == OP_SUB) hipLaunchKernelGGL((k_scalar_binop<F, OP_SUB>), g, t, 0, ctx->stream, n, da, db, dout);
+            if (op == OP_MUL) hipLaunchKernelGGL((k_scalar_binop<F, OP_MUL>), g, t, 0, ctx->stream, n, da, db, dout);
+        });
+    }
+    return st.finish();
+}
+int arkmpc_scalar_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return scalar_binop(ctx, OP_ADD, n, a, b, out); }
+int arkmpc_scalar_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return scalar_binop(ctx, OP_SUB, n, a, b, out); }
+int arkmpc_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return scalar_binop(ctx, OP_MUL, n, a, b, out); }
+int arkmpc_open_combine(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint64_t* out) { return scalar_binop(ctx, OP_ADD, n, mine, peer, out); }
+
+static int scalar_unop(arkmpc_ctx* ctx, int which, size_t n, const uint64_t* a, void* out, size_t out_elem_bytes) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 32), io = st.declare_out(out, n * out_elem_bytes);
+    if (st.commit()) return st.rc;
+    if (n) {
+        const u64* da = st.in<u64>(ia);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, {
+            if (which == 0) hipLaunchKernelGGL((k_scalar_neg<F>), g, t, 0, ctx->stream, n, da, st.out<u64>(io));
+            if (which == 1) hipLaunchKernelGGL((k_from_canonical<F>), g, t, 0, ctx->stream, n, da, st.out<u64>(io));
+            if (which == 2) hipLaunchKernelGGL((k_to_canonical<F>), g, t, 0, ctx->stream, n, da, st.out<u64>(io));
+            if (which == 3) hipLaunchKernelGGL((k_to_bytes_be<F>), g, t, 0, ctx->stream, n, da, st.out<unsigned char>(io));
+        });
+    }
+    return st.finish();
+}
+int arkmpc_scalar_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return scalar_unop(ctx, 0, n, a, out, 32); }
+int arkmpc_scalar_from_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out) { return scalar_unop(ctx, 1, n, in, out, 32); }
+int arkmpc_scalar_to_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out) { return scalar_unop(ctx, 2, n, in, out, 32); }
+int arkmpc_scalar_to_bytes_be(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint8_t* out_bytes) { return scalar_unop(ctx, 3, n, in, out_bytes, 32); }
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: ScalarShare vectors
+// ---------------------------------------------------------------------------------------------
+static int share_binop(arkmpc_ctx* ctx, int op, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64), io = st.declare_out(out, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) {
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, {
+            if (op == OP_ADD) hipLaunchKernelGGL((k_share_binop<F, OP_ADD>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+            if (op == OP_SUB) hipLaunchKernelGGL((k_share_binop<F, OP_SUB>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+        });
+    }
+    return st.finish();
+}
+int arkmpc_share_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return share_binop(ctx, OP_ADD, n, a, b, out); }
+int arkmpc_share_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return share_binop(ctx, OP_SUB, n, a, b, out); }
+
+int arkmpc_share_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 64), io = st.declare_out(out, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) {
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_neg<F>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.out<u64>(io)));
+    }
+    return st.finish();
+}
+int arkmpc_share_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(shares, n * 64), io = st.declare_out(out, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) {
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_extract<F>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.out<u64>(io)));
+    }
+    return st.finish();
+}
+
+static int share_addsub_public(arkmpc_ctx* ctx, bool sub, size_t n, int party, const uint64_t key[4], const uint64_t* a,
+                               const uint64_t* pub, uint64_t* out) {
+    ENTER(ctx);
+    if (!party_ok(party)) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 64), ip = st.declare_in(pub, n * 32), io = st.declare_out(out, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) {
+        Fe k = fe_from_host(key);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, {
+            if (sub) hipLaunchKernelGGL((k_share_addsub_public<F, true>), g, t, 0, ctx->stream, n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
+            else hipLaunchKernelGGL((k_share_addsub_public<F, false>), g, t, 0, ctx->stream, n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
+        });
+    }
+    return st.finish();
+}
+int arkmpc_share_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* a, const uint64_t* pub, uint64_t* out) {
+    return share_addsub_public(ctx, false, n, party_id, mac_key, a, pub, out);
+}
+int arkmpc_share_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* a, const uint64_t* pub, uint64_t* out) {
+    return share_addsub_public(ctx, true, n, party_id, mac_key, a, pub, out);
+}
+int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* pub, uint64_t* out) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 64), ip = st.declare_in(pub, n * 32), io = st.declare_out(out, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) {
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_mul_public<F>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io)));
+    }
+    return st.finish();
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: Beaver multiplication
+// ---------------------------------------------------------------------------------------------
+static bool stride_ok(size_t s) { return s >= 4 && (s % 2) == 0 && s <= 0xffffffffu; }
+
+int arkmpc_beaver_mask_v(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share,
+                         size_t y_stride, const uint64_t* a_share, size_t a_stride, const uint64_t* b_share, size_t b_stride,
+                         uint64_t* out_de) {
+    ENTER(ctx);
+    if (!stride_ok(x_stride) || !stride_ok(y_stride) || !stride_ok(a_stride) || !stride_ok(b_stride)) return ark_bad(ctx, "bad stride");
+    if (ctx->host_buffers) return ark_bad(ctx, "share-view entry points take device pointers only");
+    if (n && (!x_share || !y_share || !a_share || !b_share || !out_de)) return ark_bad(ctx, "null pointer");
+    if (((uintptr_t)x_share | (uintptr_t)y_share | (uintptr_t)a_share | (uintptr_t)b_share | (uintptr_t)out_de) & 15) return ark_bad(ctx, "device pointer not 16-byte aligned");
+    if (n) {
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        Col x{x_share, (u32)x_stride}, y{y_share, (u32)y_stride}, a{a_share, (u32)a_stride}, b{b_share, (u32)b_stride};
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_mask<F>), g, t, 0, ctx->stream, n, x, y, a, b, out_de));
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { ctx->err = hipGetErrorString(le); return ARKMPC_ERR_HIP; }
+    }
+    return ARKMPC_OK;
+}
+
+int arkmpc_beaver_mask(arkmpc_ctx* ctx, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a, const uint64_t* b, uint64_t* out_de) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ix = st.declare_in(x, n * 64), iy = st.declare_in(y, n * 64), ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64);
+    int io = st.declare_out(out_de, 2 * n * 32);
+    if (st.commit()) return st.rc;
+    if (n) {
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        Col cx{st.in<u64>(ix), 8}, cy{st.in<u64>(iy), 8}, ca{st.in<u64>(ia), 8}, cb{st.in<u64>(ib), 8};
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_mask<F>), g, t, 0, ctx->stream, n, cx, cy, ca, cb, st.out<u64>(io)));
+    }
+    return st.finish();
+}
+
+int arkmpc_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d, const uint64_t* e,
+                         const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out) {
+    ENTER(ctx);
+    if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int id = st.declare_in(d, n * 32), ie = st.declare_in(e, n * 32);
+    int ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64), ic = st.declare_in(c, n * 64), io = st.declare_out(out, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) {
+        Fe k = fe_from_host(mac_key);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        const u64 *pa = st.in<u64>(ia), *pb = st.in<u64>(ib), *pc = st.in<u64>(ic);
+        u64* po = st.out<u64>(io);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_finish<F, false>), g, t, 0, ctx->stream, n, party_id, k, st.in<u64>(id),
+                                               (const u64*)nullptr, st.in<u64>(ie), Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8}, Col{pb + 4, 8},
+                                               Col{pc, 8}, Col{pc + 4, 8}, ColOut{po, 8}, ColOut{po + 4, 8}));
+    }
+    return st.finish();
+}
+
+int arkmpc_beaver_finish_fused(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* my_de,
+                               const uint64_t* peer_de, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out) {
+    ENTER(ctx);
+    if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int i0 = st.declare_in(my_de, 2 * n * 32), i1 = st.declare_in(peer_de, 2 * n * 32);
+    int ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64), ic = st.declare_in(c, n * 64), io = st.declare_out(out, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) {
+        Fe k = fe_from_host(mac_key);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        const u64 *pa = st.in<u64>(ia), *pb = st.in<u64>(ib), *pc = st.in<u64>(ic);
+        u64* po = st.out<u64>(io);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_finish<F, true>), g, t, 0, ctx->stream, n, party_id, k, st.in<u64>(i0),
+                                               st.in<u64>(i1), (const u64*)nullptr, Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8}, Col{pb + 4, 8},
+                                               Col{pc, 8}, Col{pc + 4, 8}, ColOut{po, 8}, ColOut{po + 4, 8}));
+    }
+    return st.finish();
+}
+
+int arkmpc_beaver_finish_fused_v(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* my_de,
+                                 const uint64_t* peer_de, const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                                 const uint64_t* b_share, const uint64_t* b_mac, size_t b_stride, const uint64_t* c_share,
+                                 const uint64_t* c_mac, size_t c_stride, uint64_t* out_share, uint64_t* out_mac, size_t out_stride) {
+    ENTER(ctx);
+    if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    if (!stride_ok(a_stride) || !stride_ok(b_stride) || !stride_ok(c_stride) || !stride_ok(out_stride)) return ark_bad(ctx, "bad stride");
+    if (ctx->host_buffers) return ark_bad(ctx, "share-view entry points take device pointers only");
+    if (n && (!my_de || !peer_de || !a_share || !a_mac || !b_share || !b_mac || !c_share || !c_mac || !out_share || !out_mac)) return ark_bad(ctx, "null pointer");
+    if (((uintptr_t)my_de | (uintptr_t)peer_de | (uintptr_t)a_share | (uintptr_t)a_mac | (uintptr_t)b_share | (uintptr_t)b_mac |
+         (uintptr_t)c_share | (uintptr_t)c_mac | (uintptr_t)out_share | (uintptr_t)out_mac) & 15)
+        return ark_bad(ctx, "device pointer not 16-byte aligned");
+    if (n) {
+        Fe k = fe_from_host(mac_key);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_finish<F, true>), g, t, 0, ctx->stream, n, party_id, k, my_de, peer_de,
+                                               (const u64*)nullptr, Col{a_share, (u32)a_stride}, Col{a_mac, (u32)a_stride},
+                                               Col{b_share, (u32)b_stride}, Col{b_mac, (u32)b_stride}, Col{c_share, (u32)c_stride},
+                                               Col{c_mac, (u32)c_stride}, ColOut{out_share, (u32)out_stride}, ColOut{out_mac, (u32)out_stride}));
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { ctx->err = hipGetErrorString(le); return ARKMPC_ERR_HIP; }
+    }
+    return ARKMPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: batch open + MAC check
+// ---------------------------------------------------------------------------------------------
+int arkmpc_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* opened, const uint64_t* shares, uint64_t* out_chk) {
+    ENTER(ctx);
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int iv = st.declare_in(opened, n * 32), is = st.declare_in(shares, n * 64), io = st.declare_out(out_chk, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) {
+        Fe k = fe_from_host(mac_key);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_mac_check<F, false>), g, t, 0, ctx->stream, n, k, st.in<u64>(iv), st.in<u64>(is),
+                                               (const u64*)nullptr, (u64*)nullptr, st.out<u64>(io)));
+    }
+    return st.finish();
+}
+int arkmpc_open_and_mac_check(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* shares, const uint64_t* peer,
+                              uint64_t* out_opened, uint64_t* out_chk) {
+    ENTER(ctx);
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int is = st.declare_in(shares, n * 64), ip = st.declare_in(peer, n * 32);
+    int iv = st.declare_out(out_opened, n * 32), io = st.declare_out(out_chk, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) {
+        Fe k = fe_from_host(mac_key);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_mac_check<F, true>), g, t, 0, ctx->stream, n, k, (const u64*)nullptr, st.in<u64>(is),
+                                               st.in<u64>(ip), st.out<u64>(iv), st.out<u64>(io)));
+    }
+    return st.finish();
+}
+int arkmpc_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, int* out_ok) {
+    ENTER(ctx);
+    if (!out_ok) return ark_bad(ctx, "null out_ok");
+    Stage st(ctx);
+    int im = st.declare_in(mine, n * 32), ip = st.declare_in(peer, n * 32);
+    if (st.commit()) return st.rc;
+    ARK_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream));
+    if (n) {
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_mac_verify<F>), g, t, 0, ctx->stream, n, st.in<u64>(im), st.in<u64>(ip), ctx->d_flag));
+    }
+    ARK_HIP(ctx, hipGetLastError());
+    ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_ok = (*ctx->h_flag == 0) ? 1 : 0;
+    return ARKMPC_OK;
+}
+
+// H1: commitment.rs:63-89 / :30-43.  K6 on the GPU in chunks; D2H into pinned double buffers; the
+// sponge absorbs chunk c on the host while chunk c+1 is converted and copied.
+int arkmpc_commit_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* values, const uint64_t blinder[4], uint64_t out_commitment[4]) {
+    ENTER(ctx);
+    if (!blinder || !out_commitment) return ark_bad(ctx, "null blinder/out");
+    if (n && !values) return ark_bad(ctx, "null values");
+    const size_t CHUNK = (size_t)1 << 18;  // elements per chunk (8 MiB of bytes)
+    if (!ctx->h_pin[0]) {
+        for (int i = 0; i < 2; ++i) {
+            ARK_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin[i], CHUNK * 32));
+            ARK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+        }
+        ctx->h_pin_cap = CHUNK * 32;
+    }
+    // device staging: [2 x CHUNK*32 bytes out] (+ [2 x CHUNK*32 in] in host-buffer mode)
+    const size_t need = 2 * CHUNK * 32 * (ctx->host_buffers ? 2 : 1);
+    int rc = arena_reserve(ctx, need);
+    if (rc) return rc;
+    if (!ctx->host_buffers && ((uintptr_t)values & 15)) return ark_bad(ctx, "device pointer not 16-byte aligned");
+    unsigned char* d_out[2] = {(unsigned char*)ctx->arena, (unsigned char*)ctx->arena + CHUNK * 32};
+    u64* d_in[2] = {(u64*)(ctx->arena + 2 * CHUNK * 32), (u64*)(ctx->arena + 3 * CHUNK * 32)};
+    Sha3State sh;
+    sha3_256_init(&sh);
+    const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+    auto issue = [&](size_t c) -> int {
+        const size_t off = c * CHUNK, cnt = (n - off < CHUNK) ? (n - off) : CHUNK;
+        const int s = (int)(c & 1);
+        const u64* src = values + 4 * off;
+        if (ctx->host_buffers) {
+            ARK_HIP(ctx, hipMemcpyAsync(d_in[s], src, cnt * 32, hipMemcpyHostToDevice, ctx->stream));
+            src = d_in[s];
+        }
+        dim3 g(blocks_for(cnt, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_to_bytes_be<F>), g, t, 0, ctx->stream, cnt, src, d_out[s]));
+        ARK_HIP(ctx, hipGetLastError());
+        ARK_HIP(ctx, hipMemcpyAsync(ctx->h_pin[s], d_out[s], cnt * 32, hipMemcpyDeviceToHost, ctx->stream));
+        ARK_HIP(ctx, hipEventRecord(ctx->ev[s], ctx->stream));
+        return ARKMPC_OK;
+    };
+    if (nchunks) { rc = issue(0); if (rc) return rc; }
+    for (size_t c = 0; c < nchunks; ++c) {
+        const int s = (int)(c & 1);
+        ARK_HIP(ctx, hipEventSynchronize(ctx->ev[s]));
+        // slot s^1 was fully absorbed in the previous iteration, so it is free for chunk c+1
+        if (c + 1 < nchunks) { rc = issue(c + 1); if (rc) return rc; }
+        const size_t off = c * CHUNK, cnt = (n - off < CHUNK) ? (n - off) : CHUNK;
+        sha3_256_update(&sh, ctx->h_pin[s], cnt * 32);
+    }
+    unsigned char be[32], dig[32];
+    host_to_bytes_be(ctx->field_id, blinder, be);
+    sha3_256_update(&sh, be, 32);
+    sha3_256_final(&sh, dig);
+    host_from_be_bytes_mod_order(ctx->field_id, dig, out_commitment);
+    return ARKMPC_OK;
+}
+
+int arkmpc_sha3_256(const uint8_t* msg, size_t len, uint8_t out32[32]) {
+    if ((!msg && len) || !out32) return ARKMPC_ERR_BAD_ARG;
+    Sha3State sh;
+    sha3_256_init(&sh);
+    sha3_256_update(&sh, msg, len);
+    sha3_256_final(&sh, out32);
+    return ARKMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+"""ctypes binding of include/arkmpc.h.  Thin by design: argument marshalling and error mapping only."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FIELD_IDS = {"bn254_fr": 0, "bls12_381_fr": 1, "curve25519_fr": 2, "bn254_fq": 3}
+FIELD_MODULI = {
+    0: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001,
+    1: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+    2: 2**252 + 27742317777372353535851937790883648493,
+    3: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+}
+
+
+class ArkMpcError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libarkmpc_hip.so")
+
+
+def load_library():
+    """Load the HIP engine.  Raises (never falls back) when the library has not been built."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ArkMpcError(
+                "HIP engine not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+        _LIB = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+        _LIB.arkmpc_last_error.restype = ctypes.c_char_p
+        _LIB.arkmpc_version.restype = ctypes.c_char_p
+    return _LIB
+
+
+def declared_symbols(header=None):
+    """Every function name declared in include/arkmpc.h."""
+    header = header or os.path.join(_HERE, "..", "include", "arkmpc.h")
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(arkmpc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def exported_symbols():
+    lib = load_library()
+    return [s for s in declared_symbols() if hasattr(lib, s)]
+
+
+def _ptr(x):
+    """Device pointer (int), torch tensor (data_ptr) or numpy array (host pointer) -> c_void_p."""
+    if x is None:
+        return ctypes.c_void_p(0)
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ArkMpcError("numpy buffer must be C-contiguous")
+        return ctypes.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        return ctypes.c_void_p(x.data_ptr())
+    raise ArkMpcError("unsupported buffer type %r" % type(x))
+
+
+def _key(k):
+    a = np.ascontiguousarray(k, dtype=np.uint64).reshape(4)
+    return a, ctypes.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """One arkmpc context = one (field, GPU).  Buffers are device pointers / torch tensors, or numpy
+    arrays when constructed with host_buffers=True."""
+
+    def __init__(self, field, device=0, host_buffers=False, stream=None):
+        self.lib = load_library()
+        self.field_id = FIELD_IDS[field] if isinstance(field, str) else int(field)
+        self.host_buffers = bool(host_buffers)
+        h = ctypes.c_void_p()
+        rc = self.lib.arkmpc_ctx_create(self.field_id, int(device), ctypes.byref(h))
+        if rc != 0:
+            raise ArkMpcError("arkmpc_ctx_create failed with status %d (no GPU => no engine; there is no CPU fallback)" % rc)
+        self.h = h
+        if host_buffers:
+            self._ck(self.lib.arkmpc_ctx_set_host_buffers(self.h, 1))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.arkmpc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self.lib.arkmpc_last_error(self.h)
+            raise ArkMpcError("arkmpc status %d: %s" % (rc, msg.decode() if msg else ""))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.arkmpc_ctx_set_stream(self.h, ctypes.c_void_p(int(stream_ptr))))
+
+    def sync(self):
+        self._ck(self.lib.arkmpc_sync(self.h))
+
+    # ---- raw call helper: name, n, then pointers / scalars in ABI order
+    def call(self, name, *args):
+        fn = getattr(self.lib, "arkmpc_" + name)
+        conv = [self.h]
+        keep = []
+        for a in args:
+            if isinstance(a, tuple) and a[0] == "key":
+                arr, p = _key(a[1])
+                keep.append(arr)
+                conv.append(p)
+            elif isinstance(a, tuple) and a[0] == "size":
+                conv.append(ctypes.c_size_t(int(a[1])))
+            elif isinstance(a, tuple) and a[0] == "int":
+                conv.append(ctypes.c_int(int(a[1])))
+            elif isinstance(a, tuple) and a[0] == "ref":
+                conv.append(a[1])
+            else:
+                conv.append(_ptr(a))
+        self._ck(fn(*conv))
+
+    # ---- Scalar vectors
+    def scalar_add(self, n, a, b, out): self.call("scalar_add", ("size", n), a, b, out)
+    def scalar_sub(self, n, a, b, out): self.call("scalar_sub", ("size", n), a, b, out)
+    def scalar_mul(self, n, a, b, out): self.call("scalar_mul", ("size", n), a, b, out)
+    def scalar_neg(self, n, a, out): self.call("scalar_neg", ("size", n), a, out)
+    def scalar_from_canonical(self, n, a, out): self.call("scalar_from_canonical", ("size", n), a, out)
+    def scalar_to_canonical(self, n, a, out): self.call("scalar_to_canonical", ("size", n), a, out)
+    def scalar_to_bytes_be(self, n, a, out): self.call("scalar_to_bytes_be", ("size", n), a, out)
+
+    # ---- ScalarShare vectors
+    def share_add(self, n, a, b, out): self.call("share_add", ("size", n), a, b, out)
+    def share_sub(self, n, a, b, out): self.call("share_sub", ("size", n), a, b, out)
+    def share_neg(self, n, a, out): self.call("share_neg", ("size", n), a, out)
+    def share_extract(self, n, a, out): self.call("share_extract", ("size", n), a, out)
+    def share_add_public(self, n, party, key, a, pub, out): self.call("share_add_public", ("size", n), ("int", party), ("key", key), a, pub, out)
+    def share_sub_public(self, n, party, key, a, pub, out): self.call("share_sub_public", ("size", n), ("int", party), ("key", key), a, pub, out)
+    def share_mul_public(self, n, a, pub, out): self.call("share_mul_public", ("size", n), a, pub, out)
+
+    # ---- Beaver multiplication
+    def beaver_mask(self, n, x, y, a, b, out_de): self.call("beaver_mask", ("size", n), x, y, a, b, out_de)
+    def open_combine(self, n, mine, peer, out): self.call("open_combine", ("size", n), mine, peer, out)
+    def beaver_finish(self, n, party, key, d, e, a, b, c, out): self.call("beaver_finish", ("size", n), ("int", party), ("key", key), d, e, a, b, c, out)
+    def beaver_finish_fused(self, n, party, key, my_de, peer_de, a, b, c, out):
+        self.call("beaver_finish_fused", ("size", n), ("int", party), ("key", key), my_de, peer_de, a, b, c, out)
+    def beaver_mask_v(self, n, xs, xst, ys, yst, as_, ast, bs, bst, out_de):
+        self.call("beaver_mask_v", ("size", n), xs, ("size", xst), ys, ("size", yst), as_, ("size", ast), bs, ("size", bst), out_de)
+    def beaver_finish_fused_v(self, n, party, key, my_de, peer_de, a_s, a_m, ast, b_s, b_m, bst, c_s, c_m, cst, o_s, o_m, ost):
+        self.call("beaver_finish_fused_v", ("size", n), ("int", party), ("key", key), my_de, peer_de, a_s, a_m, ("size", ast),
+                  b_s, b_m, ("size", bst), c_s, c_m, ("size", cst), o_s, o_m, ("size", ost))
+
+    # ---- batch open + MAC check
+    def mac_check_shares(self, n, key, opened, shares, out): self.call("mac_check_shares", ("size", n), ("key", key), opened, shares, out)
+    def open_and_mac_check(self, n, key, shares, peer, out_opened, out_chk):
+        self.call("open_and_mac_check", ("size", n), ("key", key), shares, peer, out_opened, out_chk)
+    def mac_verify(self, n, mine, peer):
+        ok = ctypes.c_int(-1)
+        self.call("mac_verify", ("size", n), mine, peer, ("ref", ctypes.byref(ok)))
+        return bool(ok.value)
+    def commit_sha3(self, n, values, blinder):
+        out = np.zeros(4, dtype=np.uint64)
+        self.call("commit_sha3", ("size", n), values, ("key", blinder), out)
+        return out
+
+    # ---- BN254 G1
+    def g1_add(self, n, a, b, out): self.call("g1_add", ("size", n), a, b, out)
+    def g1_sub(self, n, a, b, out): self.call("g1_sub", ("size", n), a, b, out)
+    def g1_neg(self, n, a, out): self.call("g1_neg", ("size", n), a, out)
+    def g1_scalar_mul(self, n, pts, scalars, out): self.call("g1_scalar_mul", ("size", n), pts, scalars, out)
+    def g1_generator_mul(self, n, scalars, out): self.call("g1_generator_mul", ("size", n), scalars, out)
+    def g1_to_affine(self, n, pts, out_xy, out_inf): self.call("g1_to_affine", ("size", n), pts, out_xy, out_inf)
+    def g1_to_bytes(self, n, pts, out): self.call("g1_to_bytes", ("size", n), pts, out)
+    def pointshare_add(self, n, a, b, out): self.call("pointshare_add", ("size", n), a, b, out)
+    def pointshare_sub(self, n, a, b, out): self.call("pointshare_sub", ("size", n), a, b, out)
+    def pointshare_neg(self, n, a, out): self.call("pointshare_neg", ("size", n), a, out)
+    def pointshare_mul_public(self, n, shares, scalars, out): self.call("pointshare_mul_public", ("size", n), shares, scalars, out)
+    def pointshare_add_public(self, n, party, key, shares, pub, out):
+        self.call("pointshare_add_public", ("size", n), ("int", party), ("key", key), shares, pub, out)
+    def scalarshare_mul_generator(self, n, ss, out): self.call("scalarshare_mul_generator", ("size", n), ss, out)
+    def scalarshare_mul_point(self, n, ss, pts, out): self.call("scalarshare_mul_point", ("size", n), ss, pts, out)
+    def pointshare_extract(self, n, shares, out): self.call("pointshare_extract", ("size", n), shares, out)
+    def point_mac_check_shares(self, n, key, opened, shares, out): self.call("point_mac_check_shares", ("size", n), ("key", key), opened, shares, out)
+    def point_mac_verify(self, n, mine, peer, out_ok): self.call("point_mac_verify", ("size", n), mine, peer, out_ok)
+
+
+def sha3_256(data: bytes) -> bytes:
+    lib = load_library()
+    out = (ctypes.c_uint8 * 32)()
+    buf = (ctypes.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    rc = lib.arkmpc_sha3_256(buf, ctypes.c_size_t(len(data)), out)
+    if rc != 0:
+        raise ArkMpcError("arkmpc_sha3_256 status %d" % rc)
+    return bytes(out)

@@ -1,0 +1,179 @@
+/*
+ * arkmpc.h -- C ABI of the MI355X-native engine for ark-mpc's batched authenticated-share path.
+ *
+ * This is the drop-in boundary: the entry points a patched ark-mpc `batch_*` gate closure
+ * (online-phase/src/fabric.rs:841-854 `new_batch_gate_op`) would bind over Rust FFI -- see
+ * INTEGRATION.md for the `extern "C"` shim.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * DATA LAYOUT (identical to arkworks' in-memory layout, so a Rust `&[T]` can be passed as-is):
+ *   Scalar<C>       4 x u64  little-endian limbs, Montgomery form, R = 2^256   (scalar.rs:46)
+ *   ScalarShare<C>  8 x u64  = { share[4], mac[4] }                             (scalar/share.rs:32-37)
+ *   CurvePoint<C>   12 x u64 = short-Weierstrass Jacobian { x[4], y[4], z[4] }, identity z = 0
+ *                   (ark-ec `Projective`; BN254 G1 only)                        (curve/curve.rs:47)
+ *   PointShare<C>   24 x u64 = { share[12], mac[12] }                           (curve/share.rs:25-30)
+ * "share view" entry points (suffix _v) take the share and MAC columns as separate base pointers
+ * with an element stride, so the engine-native split layout (all shares, then all MACs; stride 4)
+ * and the arkworks AoS layout (stride 8, mac = share + 4) run through the same kernels.
+ *
+ * MEMORY SPACE: by default every buffer pointer is a DEVICE pointer (16-byte aligned) on the
+ * context's GPU and calls are asynchronous on the context's stream.  After
+ * arkmpc_ctx_set_host_buffers(ctx, 1) every buffer pointer is a HOST pointer; the call stages
+ * through device scratch and returns when the outputs are in host memory.
+ * `mac_key`, `blinder` and single-element outputs are always host pointers to 4 x u64.
+ *
+ * ERRORS: every function returns ARKMPC_OK (0) or a negative arkmpc_status; nothing throws or
+ * aborts across the ABI (the reference's closures are infallible and panic on misuse,
+ * fabric/result.rs:127-233; here misuse is a status code).  A MAC-check failure is a VALUE
+ * (out_ok = 0), surfaced by the caller as MpcError::AuthenticationError
+ * (authenticated_scalar.rs:368-385), not an error status.
+ *
+ * THREADING: a context may be used from any thread, one call at a time per context (calls on one
+ * context are serialised by an internal mutex); different contexts are independent -- this matches
+ * gates running concurrently on rayon workers (fabric/executor/multi_threaded/executor.rs:208-217).
+ */
+#ifndef ARKMPC_H
+#define ARKMPC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct arkmpc_ctx arkmpc_ctx;
+
+typedef enum {
+    ARKMPC_OK = 0,
+    ARKMPC_ERR_BAD_ARG = -1,      /* null pointer, bad field/party id, misaligned device pointer */
+    ARKMPC_ERR_HIP = -2,          /* HIP runtime failure; see arkmpc_last_error */
+    ARKMPC_ERR_UNSUPPORTED = -3,  /* op not defined for this context's field (e.g. curve ops on Fr ctx) */
+    ARKMPC_ERR_NO_DEVICE = -4     /* no usable GPU: the engine has no CPU fallback */
+} arkmpc_status;
+
+typedef enum {
+    ARKMPC_BN254_FR = 0,       /* scalar field of BN254 (ark-bn254, the reference's TestCurve: lib.rs:78) */
+    ARKMPC_BLS12_381_FR = 1,   /* scalar field of BLS12-381 */
+    ARKMPC_CURVE25519_FR = 2,  /* ed25519 group order (README.md:24 uses ark-curve25519) */
+    ARKMPC_BN254_FQ = 3        /* base field of BN254 (coordinates of G1 points) */
+} arkmpc_field;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* One context = one (field, GPU) pair with its own stream and scratch.  For point ops create the
+ * context with ARKMPC_BN254_FR: scalars are Fr elements, coordinates are Fq elements. */
+int arkmpc_ctx_create(int field_id, int device, arkmpc_ctx** out_ctx);
+int arkmpc_ctx_destroy(arkmpc_ctx* ctx);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int arkmpc_ctx_set_stream(arkmpc_ctx* ctx, void* hip_stream);
+int arkmpc_ctx_set_host_buffers(arkmpc_ctx* ctx, int enabled);
+int arkmpc_sync(arkmpc_ctx* ctx);
+const char* arkmpc_last_error(arkmpc_ctx* ctx);
+const char* arkmpc_version(void);
+int arkmpc_device_count(void);
+/* device memory helpers for callers without their own allocator (Rust shim, tests) */
+int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr);
+int arkmpc_free(arkmpc_ctx* ctx, void* dptr);
+int arkmpc_memcpy_h2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int arkmpc_memcpy_d2h(arkmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- Scalar<C> vectors: scalar.rs:210-267, scalar_result.rs:24-278 ------------------------- */
+int arkmpc_scalar_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
+int arkmpc_scalar_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
+int arkmpc_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out); /* ScalarResult::batch_mul, scalar_result.rs:257-278 */
+int arkmpc_scalar_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
+/* canonical little-endian integers (< 2^256, reduced mod p on the way in) <-> Montgomery form */
+int arkmpc_scalar_from_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);
+int arkmpc_scalar_to_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);
+/* K6: Scalar::to_bytes_be (scalar.rs:118-127): n x 32 big-endian bytes, the SHA3 commitment's input */
+int arkmpc_scalar_to_bytes_be(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint8_t* out_bytes);
+
+/* ---- ScalarShare<C> vectors: scalar/share.rs:72-133 via authenticated_scalar.rs batch_* ------ */
+int arkmpc_share_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);           /* batch_add :457-489 */
+int arkmpc_share_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);           /* batch_sub :662-688 */
+int arkmpc_share_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);                               /* batch_neg :745-765 */
+int arkmpc_share_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
+                            const uint64_t* a, const uint64_t* pub, uint64_t* out);                              /* batch_add_public :493-528 */
+int arkmpc_share_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
+                            const uint64_t* a, const uint64_t* pub, uint64_t* out);                              /* batch_sub_public :691-733 */
+int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* pub, uint64_t* out);  /* batch_mul_public :883-916 */
+
+/* ---- Beaver multiplication, authenticated_scalar.rs:848-879 -------------------------------- */
+/* K1  batch_sub(a,&beaver_a), batch_sub(b,&beaver_b) + the `.share()` projection of open_batch's
+ *     network op (:863-868, :141-145).  x,y,a,b: n ScalarShares.  out_de: 2n Scalars, d then e,
+ *     exactly the NetworkPayload::ScalarBatch this party sends. */
+int arkmpc_beaver_mask(arkmpc_ctx* ctx, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a,
+                       const uint64_t* b, uint64_t* out_de);
+/* K2  open_batch's combine gate (:161-171): out_i = mine_i + peer_i over n Scalars. */
+int arkmpc_open_combine(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint64_t* out);
+/* K3  de + d[b] + e[a] + [c] (:871-878 == the fused gate :835-840).  d,e: n opened Scalars each. */
+int arkmpc_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d,
+                         const uint64_t* e, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out);
+/* K2+K3 fused: my_de / peer_de are the two parties' 2n-Scalar d||e buffers from K1. */
+int arkmpc_beaver_finish_fused(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
+                               const uint64_t* my_de, const uint64_t* peer_de, const uint64_t* a, const uint64_t* b,
+                               const uint64_t* c, uint64_t* out);
+/* share-view forms: *_share / *_mac column pointers + stride in u64 units (8 = AoS, 4 = split) */
+int arkmpc_beaver_mask_v(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share,
+                         size_t y_stride, const uint64_t* a_share, size_t a_stride, const uint64_t* b_share,
+                         size_t b_stride, uint64_t* out_de);
+int arkmpc_beaver_finish_fused_v(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
+                                 const uint64_t* my_de, const uint64_t* peer_de,
+                                 const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                                 const uint64_t* b_share, const uint64_t* b_mac, size_t b_stride,
+                                 const uint64_t* c_share, const uint64_t* c_mac, size_t c_stride,
+                                 uint64_t* out_share, uint64_t* out_mac, size_t out_stride);
+
+/* ---- batch open + MAC check, authenticated_scalar.rs:278-354 ------------------------------- */
+/* the `.share()` projection sent by open_batch (:141-145): n ScalarShares -> n Scalars */
+int arkmpc_share_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share_values);
+/* K4  mac_key * value - share.mac() (:299-311) */
+int arkmpc_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* opened,
+                            const uint64_t* shares, uint64_t* out_chk);
+/* K2+K4 fused: opened_i = shares_i.share + peer_i ; chk_i = mac_key*opened_i - shares_i.mac */
+int arkmpc_open_and_mac_check(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* shares,
+                              const uint64_t* peer_share_values, uint64_t* out_opened, uint64_t* out_chk);
+/* K5  all(mine_i + peer_i == 0) (:218-219).  Blocking; *out_ok = 1 or 0. */
+int arkmpc_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, int* out_ok);
+/* H1  HashCommitmentResult::batch_commit / HashCommitment::verify (commitment.rs:63-89, :30-43):
+ *     out = from_be_bytes_mod_order(SHA3-256(BE(v_0)||...||BE(v_{n-1})||BE(blinder))).
+ *     K6 runs on the GPU, the sponge on the host (sequential by definition), overlapped with D2H.
+ *     Blocking; `blinder` and `out_commitment` are host pointers. */
+int arkmpc_commit_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* values, const uint64_t blinder[4],
+                       uint64_t out_commitment[4]);
+/* plain SHA3-256 of a host buffer (the `sha3` crate's Sha3_256) */
+int arkmpc_sha3_256(const uint8_t* msg, size_t len, uint8_t out32[32]);
+
+/* ---- BN254 G1 points (context field must be ARKMPC_BN254_FR) -------------------------------- */
+int arkmpc_g1_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);  /* curve.rs:203-209 */
+int arkmpc_g1_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);  /* curve.rs:282-288 */
+int arkmpc_g1_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);                      /* curve.rs:367-373 */
+/* K8  CurvePoint * Scalar (curve.rs:403-409); CurvePointResult::batch_mul (curve.rs:459-479) */
+int arkmpc_g1_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out);
+/* generator * scalar_i */
+int arkmpc_g1_generator_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* scalars, uint64_t* out);
+/* normalise to affine: out_xy = n x { x[4], y[4] } Montgomery Fq; out_inf[i] = 1 for the identity */
+int arkmpc_g1_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy, uint8_t* out_inf);
+/* CurvePoint::to_bytes (curve.rs:103-108): arkworks compressed encoding, n x 32 bytes */
+int arkmpc_g1_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes);
+/* PointShare ops, curve/share.rs:55-114 via authenticated_curve.rs batch_* */
+int arkmpc_pointshare_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);          /* :396-426 */
+int arkmpc_pointshare_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);          /* :520-550 */
+int arkmpc_pointshare_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);                              /* :604-621 */
+int arkmpc_pointshare_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, const uint64_t* scalars,
+                                 uint64_t* out);                                                                     /* :718-751 */
+int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
+                                 const uint64_t* shares, const uint64_t* pub_points, uint64_t* out);                 /* :429-463 */
+int arkmpc_scalarshare_mul_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out);      /* :754-780 */
+int arkmpc_scalarshare_mul_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, const uint64_t* points,
+                                 uint64_t* out);                                                                     /* curve.rs:483-517 */
+/* the `.share()` projection of AuthenticatedPointResult::open_batch (:74-89): n PointShares -> n points */
+int arkmpc_pointshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points);
+/* value * mac_key - share.mac() per element (authenticated_curve.rs:215-220) */
+int arkmpc_point_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* opened_points,
+                                  const uint64_t* shares, uint64_t* out_chk_points);
+/* all(mine_i + peer_i == identity) (authenticated_curve.rs:127-131), per element: out_ok[i] in {0,1} (host or device per mode) */
+int arkmpc_point_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARKMPC_H */

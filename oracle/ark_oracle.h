@@ -1,0 +1,139 @@
+/*
+ * ark_oracle.h -- CPU restatement of ark-mpc's batched authenticated-share arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is product code: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may link, load or call it, and only
+ * as the checker (or as the CPU baseline that is timed next to the GPU path).  The product
+ * path (ark-mpc_amd/csrc) never includes this header and never falls back to it.
+ *
+ * PARITY STATUS: "parity unpinned" by reference-held vectors.  The reference
+ * (renegade-fi/ark-mpc) is Rust over un-vendored arkworks 0.4 crates (online-phase/Cargo.toml:89-94,
+ * no Cargo.lock) and holds no golden vectors or known-answer files for this path (all of its tests
+ * draw thread_rng() inputs and compare against arkworks in-process).  No Rust toolchain exists in
+ * the build image, so the reference cannot be run to produce fixtures either.  What pins this
+ * oracle instead (tests/test_oracle_*.py):
+ *   - exact big-integer arithmetic in Python (the value of every field op is a unique canonical
+ *     residue, so any correct implementation -- arkworks included -- must produce it),
+ *   - arkworks' published Montgomery constants R, R^2, INV for the four fields,
+ *   - hashlib.sha3_256 / NIST SHA3-256 known answers for the commitment hash,
+ *   - the EIP-196 alt_bn128 (BN254 G1) published points for the curve arithmetic,
+ *   - the reference's own constant-valued assertions: PartyIDBeaverSource triples
+ *     (online-phase/src/offline_prep.rs:137-158) and the values derived from them.
+ *
+ * Memory layout everywhere: arkworks `Fp256<MontBackend<_,4>>` = 4 x u64 little-endian limbs in
+ * Montgomery form (R = 2^256); `ScalarShare{share, mac}` = 8 x u64 (online-phase/src/algebra/
+ * scalar/share.rs:32-37); SW `Projective{x,y,z}` Jacobian = 12 x u64; `PointShare` = 24 x u64
+ * (online-phase/src/algebra/curve/share.rs:25-30).
+ */
+#ifndef ARK_ORACLE_H
+#define ARK_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t u64;
+
+enum { ORA_BN254_FR = 0, ORA_BLS12_381_FR = 1, ORA_CURVE25519_FR = 2, ORA_BN254_FQ = 3, ORA_NFIELDS = 4 };
+
+typedef struct {
+    u64 p[4];   /* modulus */
+    u64 r[4];   /* R mod p  (Montgomery one) */
+    u64 r2[4];  /* R^2 mod p */
+    u64 inv;    /* -p^{-1} mod 2^64 */
+    int bits;   /* modulus bit length */
+} ora_field;
+
+/* ---- field (ark-ff Fp256<MontBackend>) ---- */
+const ora_field* ora_get_field(int field_id);
+void ora_fp_add(const ora_field* f, const u64 a[4], const u64 b[4], u64 out[4]);
+void ora_fp_sub(const ora_field* f, const u64 a[4], const u64 b[4], u64 out[4]);
+void ora_fp_neg(const ora_field* f, const u64 a[4], u64 out[4]);
+void ora_fp_mul(const ora_field* f, const u64 a[4], const u64 b[4], u64 out[4]);
+void ora_fp_inv(const ora_field* f, const u64 a[4], u64 out[4]);
+void ora_fp_from_canonical(const ora_field* f, const u64 a[4], u64 out[4]); /* reduces a mod p first */
+void ora_fp_to_canonical(const ora_field* f, const u64 a[4], u64 out[4]);
+void ora_fp_to_bytes_be(const ora_field* f, const u64 a[4], unsigned char out[32]);    /* scalar.rs:118-127 */
+void ora_fp_from_be_bytes_mod_order(const ora_field* f, const unsigned char* bytes, size_t len, u64 out[4]); /* scalar.rs:109-112 */
+/* batch forms over n contiguous elements */
+void ora_fp_batch_from_canonical(int field_id, size_t n, const u64* in, u64* out);
+void ora_fp_batch_to_canonical(int field_id, size_t n, const u64* in, u64* out);
+void ora_scalar_batch_add(int field_id, size_t n, const u64* a, const u64* b, u64* out);   /* scalar_result.rs batch_add */
+void ora_scalar_batch_sub(int field_id, size_t n, const u64* a, const u64* b, u64* out);
+void ora_scalar_batch_mul(int field_id, size_t n, const u64* a, const u64* b, u64* out);   /* scalar_result.rs:257-278 */
+void ora_scalar_batch_neg(int field_id, size_t n, const u64* a, u64* out);
+
+/* ---- ScalarShare batch ops (share.rs:72-133, authenticated_scalar.rs:457-949) ---- */
+void ora_share_batch_add(int field_id, size_t n, const u64* a, const u64* b, u64* out);          /* :457-489 */
+void ora_share_batch_sub(int field_id, size_t n, const u64* a, const u64* b, u64* out);          /* :662-688 */
+void ora_share_batch_neg(int field_id, size_t n, const u64* a, u64* out);                         /* :745-765 */
+void ora_share_batch_add_public(int field_id, size_t n, int party_id, const u64 mac_key[4],
+                                const u64* a, const u64* pub, u64* out);                          /* :493-528 */
+void ora_share_batch_sub_public(int field_id, size_t n, int party_id, const u64 mac_key[4],
+                                const u64* a, const u64* pub, u64* out);                          /* :691-733 */
+void ora_share_batch_mul_public(int field_id, size_t n, const u64* a, const u64* pub, u64* out); /* :883-916 */
+
+/* ---- the hot path, flat-batched (authenticated_scalar.rs:848-879, 129-172, 278-354) ---- */
+/* K1: out_de[0..n) = x_i.share - a_i.share ; out_de[n..2n) = y_i.share - b_i.share */
+void ora_beaver_mask(int field_id, size_t n, const u64* x, const u64* y, const u64* a, const u64* b, u64* out_de);
+/* K2: out_i = mine_i + peer_i */
+void ora_open_combine(int field_id, size_t n, const u64* mine, const u64* peer, u64* out);
+/* K3: out_i = d_i*[b_i] + e_i*[a_i] + [c_i] (+ public d_i e_i), d/e are opened values */
+void ora_beaver_finish(int field_id, size_t n, int party_id, const u64 mac_key[4], const u64* d, const u64* e,
+                       const u64* a, const u64* b, const u64* c, u64* out);
+/* The reference's literal 9-pass sequence (batch_sub x2 on full shares, combine, d*e, mul_public x2,
+ * add_public, add x2) -- used as the CPU baseline "port"; `scratch` must hold 8*n shares. */
+void ora_batch_mul_9pass_local(int field_id, size_t n, int party_id, const u64 mac_key[4], const u64* x, const u64* y,
+                               const u64* a, const u64* b, const u64* c, const u64* peer_de, u64* my_de, u64* out,
+                               u64* scratch);
+/* K4: chk_i = mac_key * opened_i - share_i.mac  (:299-311) */
+void ora_mac_check_shares(int field_id, size_t n, const u64 mac_key[4], const u64* opened, const u64* shares, u64* out);
+/* K5: all(mine_i + peer_i == 0) (:218-219) */
+int ora_mac_verify(int field_id, size_t n, const u64* mine, const u64* peer);
+
+/* ---- commitment (commitment.rs:30-43, 63-89) ---- */
+void ora_sha3_256(const unsigned char* msg, size_t len, unsigned char out[32]);
+/* commitment = from_be_bytes_mod_order(SHA3-256(BE(v_0)||...||BE(v_{n-1})||BE(blinder))) */
+void ora_commit_scalars(int field_id, size_t n, const u64* values, const u64 blinder[4], u64 out[4]);
+/* commitment over a byte string of pre-serialised values (used for compressed points) */
+void ora_commit_bytes(int field_id, const unsigned char* bytes, size_t len, const u64 blinder[4], u64 out[4]);
+
+/* ---- BN254 G1 (ark-ec short-Weierstrass Projective = Jacobian, a = 0, b = 3) ---- */
+void ora_g1_identity(u64 out[12]);
+void ora_g1_generator(u64 out[12]);
+void ora_g1_add(const u64 a[12], const u64 b[12], u64 out[12]);
+void ora_g1_double(const u64 a[12], u64 out[12]);
+void ora_g1_neg(const u64 a[12], u64 out[12]);
+/* scalar is a BN254 Fr element in Montgomery form (curve.rs:403-409) */
+void ora_g1_scalar_mul(const u64 pt[12], const u64 scalar_mont[4], u64 out[12]);
+int ora_g1_is_identity(const u64 a[12]);
+/* affine (x, y) in Montgomery form; returns 1 if identity (x = y = 0 then) */
+int ora_g1_to_affine(const u64 a[12], u64 out_xy[8]);
+int ora_g1_eq(const u64 a[12], const u64 b[12]);
+/* arkworks serialize_compressed (curve.rs:103-108): x LE 32 B, bit7 of last byte = y > -y, bit6 = infinity */
+void ora_g1_to_bytes(const u64 a[12], unsigned char out[32]);
+void ora_g1_batch_add(size_t n, const u64* a, const u64* b, u64* out);
+void ora_g1_batch_scalar_mul(size_t n, const u64* pts, const u64* scalars, u64* out);
+/* PointShare ops (curve/share.rs:55-114) */
+void ora_pointshare_batch_add(size_t n, const u64* a, const u64* b, u64* out);
+void ora_pointshare_batch_sub(size_t n, const u64* a, const u64* b, u64* out);
+void ora_pointshare_batch_neg(size_t n, const u64* a, u64* out);
+void ora_pointshare_batch_mul_public(size_t n, const u64* shares, const u64* scalars, u64* out);   /* authenticated_curve.rs:718-751 */
+void ora_pointshare_batch_add_public(size_t n, int party_id, const u64 mac_key[4], const u64* shares,
+                                     const u64* pub_points, u64* out);                              /* :429-463 */
+void ora_scalarshare_batch_mul_generator(size_t n, const u64* scalar_shares, u64* out);            /* :754-780 */
+void ora_scalarshare_batch_mul_point(size_t n, const u64* scalar_shares, const u64* points, u64* out); /* curve.rs:483-517 */
+void ora_g1_batch_to_affine(size_t n, const u64* pts, u64* out_xy, unsigned char* is_inf);
+
+/* ---- PartyIDBeaverSource (offline_prep.rs:88-170) ---- */
+void ora_dummy_mac_key_share(int field_id, int party_id, u64 out[4]);
+void ora_dummy_triples(int field_id, int party_id, size_t n, u64* a, u64* b, u64* c);
+void ora_dummy_local_input_masks(int field_id, int party_id, size_t n, u64* masks, u64* mask_shares);
+void ora_dummy_counterparty_input_masks(int field_id, int party_id, size_t n, u64* mask_shares);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

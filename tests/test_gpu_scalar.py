@@ -1,0 +1,239 @@
+"""GPU parity: every scalar-side C-ABI entry point vs the CPU oracle, bit-exact, on seeded inputs.
+Runs through the C ABI (include/arkmpc.h) in both buffer modes (host staging and device pointers)."""
+import numpy as np
+import pytest
+
+import pyref
+from helpers import (mont_array, from_mont_array, mixed_values, rand_values, limbs_to_ints, ints_to_limbs,
+                     authenticated_shares, interleave_shares)
+
+pytestmark = pytest.mark.gpu
+
+FIDS = [0, 1, 2, 3]
+NAMES = {0: "bn254_fr", 1: "bls12_381_fr", 2: "curve25519_fr", 3: "bn254_fq"}
+SIZES = [1, 63, 257, 1000]
+
+
+@pytest.fixture(scope="module")
+def engines(pkg):
+    return {fid: pkg.Engine(fid, device=0, host_buffers=True) for fid in FIDS}
+
+
+def _z(n, w):
+    return np.zeros(n * w, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("fid", FIDS)
+@pytest.mark.parametrize("n", SIZES)
+def test_scalar_ops(engines, oracle, fid, n):
+    e = engines[fid]
+    a = mont_array(fid, mixed_values(fid, n, seed=11 * n + fid))
+    b = mont_array(fid, list(reversed(mixed_values(fid, n, seed=13 * n + fid))))
+    for name, ora in [("scalar_add", oracle.scalar_add), ("scalar_sub", oracle.scalar_sub), ("scalar_mul", oracle.scalar_mul)]:
+        out = _z(n, 4)
+        getattr(e, name)(n, a, b, out)
+        assert np.array_equal(out, ora(fid, a, b)), name
+    out = _z(n, 4); e.scalar_neg(n, a, out)
+    assert np.array_equal(out, oracle.scalar_neg(fid, a))
+    out = _z(n, 4); e.open_combine(n, a, b, out)
+    assert np.array_equal(out, oracle.open_combine(fid, a, b))
+    out = _z(n, 4); e.scalar_to_canonical(n, a, out)
+    assert np.array_equal(out, oracle.to_canonical(fid, a))
+    raw = ints_to_limbs([(v * 3 + (1 << 255)) % (1 << 256) for v in limbs_to_ints(a)])  # includes values >= p
+    out = _z(n, 4); e.scalar_from_canonical(n, raw, out)
+    assert np.array_equal(out, oracle.from_canonical(fid, raw))
+    outb = np.zeros(32 * n, dtype=np.uint8); e.scalar_to_bytes_be(n, a, outb)
+    assert np.array_equal(outb, oracle.to_bytes_be(fid, a))
+
+
+@pytest.mark.parametrize("fid", FIDS)
+@pytest.mark.parametrize("n", [1, 300])
+@pytest.mark.parametrize("party", [0, 1])
+def test_share_ops(engines, oracle, fid, n, party):
+    e = engines[fid]
+    p = pyref.P[fid]
+    key = mont_array(fid, [rand_values(fid, 1, 99)[0]])
+    a = interleave_shares(mont_array(fid, mixed_values(fid, n, 1)), mont_array(fid, mixed_values(fid, n, 2)[::-1]))
+    b = interleave_shares(mont_array(fid, rand_values(fid, n, 3)), mont_array(fid, mixed_values(fid, n, 4)))
+    pub = mont_array(fid, mixed_values(fid, n, 5))
+    out = _z(n, 8); e.share_add(n, a, b, out); assert np.array_equal(out, oracle.share_add(fid, a, b))
+    out = _z(n, 8); e.share_sub(n, a, b, out); assert np.array_equal(out, oracle.share_sub(fid, a, b))
+    out = _z(n, 8); e.share_neg(n, a, out); assert np.array_equal(out, oracle.share_neg(fid, a))
+    out = _z(n, 8); e.share_mul_public(n, a, pub, out); assert np.array_equal(out, oracle.share_mul_public(fid, a, pub))
+    out = _z(n, 8); e.share_add_public(n, party, key, a, pub, out)
+    assert np.array_equal(out, oracle.share_add_public(fid, party, key, a, pub))
+    out = _z(n, 8); e.share_sub_public(n, party, key, a, pub, out)
+    assert np.array_equal(out, oracle.share_add_public(fid, party, key, a, pub, sub=True))
+    out = _z(n, 4); e.share_extract(n, a, out)
+    assert np.array_equal(out.reshape(-1, 4), a.reshape(-1, 8)[:, :4])
+
+
+def _two_party_inputs(fid, n, seed):
+    p = pyref.P[fid]
+    key0, key1 = rand_values(fid, 2, seed + 1)
+    key = (key0 + key1) % p
+    x = mixed_values(fid, n, seed + 2)
+    y = mixed_values(fid, n, seed + 3)[::-1]
+    ta = rand_values(fid, n, seed + 4)
+    tb = rand_values(fid, n, seed + 5)
+    tc = [(u * v) % p for u, v in zip(ta, tb)]
+    sh = {name: authenticated_shares(fid, vals, key, seed + 10 * i)
+          for i, (name, vals) in enumerate([("x", x), ("y", y), ("a", ta), ("b", tb), ("c", tc)])}
+    keys = [mont_array(fid, [key0]), mont_array(fid, [key1])]
+    return x, y, key, keys, sh
+
+
+@pytest.mark.parametrize("fid", FIDS)
+@pytest.mark.parametrize("n", [1, 64, 777])
+def test_beaver_mul_two_party(engines, oracle, fid, n):
+    """authenticated_scalar.rs test_batch_mul (:1571-1594) restated: open(batch_mul(x, y)) == x*y, MACs verify,
+    and every intermediate buffer equals the oracle's."""
+    e = engines[fid]
+    p = pyref.P[fid]
+    x, y, key, keys, sh = _two_party_inputs(fid, n, seed=1000 + n)
+    de, res, res_fused = [], [], []
+    for party in (0, 1):
+        out = _z(2 * n, 4)
+        e.beaver_mask(n, sh["x"][party], sh["y"][party], sh["a"][party], sh["b"][party], out)
+        assert np.array_equal(out, oracle.beaver_mask(fid, sh["x"][party], sh["y"][party], sh["a"][party], sh["b"][party]))
+        de.append(out)
+    opened = _z(2 * n, 4)
+    e.open_combine(2 * n, de[0], de[1], opened)
+    assert np.array_equal(opened, oracle.open_combine(fid, de[0], de[1]))
+    d, ee = opened[:4 * n].copy(), opened[4 * n:].copy()
+    for party in (0, 1):
+        out = _z(n, 8)
+        e.beaver_finish(n, party, keys[party], d, ee, sh["a"][party], sh["b"][party], sh["c"][party], out)
+        want = oracle.beaver_finish(fid, party, keys[party], d, ee, sh["a"][party], sh["b"][party], sh["c"][party])
+        assert np.array_equal(out, want)
+        res.append(out)
+        out2 = _z(n, 8)
+        e.beaver_finish_fused(n, party, keys[party], de[party], de[1 - party], sh["a"][party], sh["b"][party], sh["c"][party], out2)
+        assert np.array_equal(out2, want)
+        # the reference's literal 9-pass sequence gives the same bits
+        my_de9, out9 = oracle.batch_mul_9pass_local(fid, party, keys[party], sh["x"][party], sh["y"][party], sh["a"][party],
+                                                    sh["b"][party], sh["c"][party], de[1 - party])
+        assert np.array_equal(my_de9, de[party]) and np.array_equal(out9, want)
+    # protocol algebra: shares sum to x*y, MAC shares sum to key*x*y
+    r0 = np.asarray(res[0]).reshape(-1, 8); r1 = np.asarray(res[1]).reshape(-1, 8)
+    prod = [(u + v) % p for u, v in zip(from_mont_array(fid, r0[:, :4].reshape(-1)), from_mont_array(fid, r1[:, :4].reshape(-1)))]
+    macs = [(u + v) % p for u, v in zip(from_mont_array(fid, r0[:, 4:].reshape(-1)), from_mont_array(fid, r1[:, 4:].reshape(-1)))]
+    assert prod == [(u * v) % p for u, v in zip(x, y)]
+    assert macs == [(key * u * v) % p for u, v in zip(x, y)]
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 500])
+def test_open_authenticated_two_party(engines, oracle, fid, n):
+    """authenticated_scalar.rs:278-354 restated for both parties, incl. commitment and the bad-MAC / bad-share cases
+    (integration/src/authenticated_scalar.rs:49-75)."""
+    e = engines[fid]
+    p = pyref.P[fid]
+    key0, key1 = rand_values(fid, 2, 31)
+    key = (key0 + key1) % p
+    keys = [mont_array(fid, [key0]), mont_array(fid, [key1])]
+    vals = mixed_values(fid, n, 77)
+    shares = list(authenticated_shares(fid, vals, key, 555))
+    blinders = [mont_array(fid, [rand_values(fid, 1, 41)[0]]), mont_array(fid, [rand_values(fid, 1, 42)[0]])]
+
+    def run(sh):
+        mine = []
+        for party in (0, 1):
+            out = _z(n, 4); e.share_extract(n, sh[party], out); mine.append(out)
+        opened, chk, comm = [], [], []
+        for party in (0, 1):
+            o = _z(n, 4); c = _z(n, 4)
+            e.open_and_mac_check(n, keys[party], sh[party], mine[1 - party], o, c)
+            o_ref = oracle.open_combine(fid, mine[party], mine[1 - party])
+            assert np.array_equal(o, o_ref)
+            assert np.array_equal(c, oracle.mac_check_shares(fid, keys[party], o_ref, sh[party]))
+            c2 = _z(n, 4); e.mac_check_shares(n, keys[party], o, sh[party], c2)
+            assert np.array_equal(c2, c)
+            cm = e.commit_sha3(n, c, blinders[party])
+            assert np.array_equal(cm, oracle.commit_scalars(fid, c, blinders[party]))
+            opened.append(o); chk.append(c); comm.append(cm)
+        oks = []
+        for party in (0, 1):
+            # verify the peer's commitment opens to the peer's values, then the sums (batch_verify_mac_check :201-220)
+            recomputed = e.commit_sha3(n, chk[1 - party], blinders[1 - party])
+            ok_comm = np.array_equal(recomputed, comm[1 - party])
+            ok_sum = e.mac_verify(n, chk[party], chk[1 - party])
+            assert ok_sum == oracle.mac_verify(fid, chk[party], chk[1 - party])
+            oks.append(ok_comm and ok_sum)
+        return opened, oks
+
+    opened, oks = run(shares)
+    assert oks == [True, True]
+    assert from_mont_array(fid, opened[0]) == vals and np.array_equal(opened[0], opened[1])
+    # corrupt one MAC (modify_mac, authenticated_scalar.rs:1090-1097) -> check must fail
+    bad = [shares[0].copy(), shares[1].copy()]
+    idx = n // 2
+    bad[0][8 * idx + 4:8 * idx + 8] = mont_array(fid, [(pyref.from_mont(fid, limbs_to_ints(bad[0][8 * idx + 4:8 * idx + 8])[0]) + 1) % p])
+    _, oks = run(bad)
+    assert oks == [False, False]
+    # corrupt one share (modify_share :1100-1110) -> opened value shifts, MAC check must fail
+    bad = [shares[0].copy(), shares[1].copy()]
+    bad[1][8 * idx:8 * idx + 4] = mont_array(fid, [12345])
+    _, oks = run(bad)
+    assert oks == [False, False]
+
+
+def test_empty_and_errors(pkg, engines):
+    e = engines[0]
+    z = np.zeros(0, dtype=np.uint64)
+    e.scalar_add(0, z, z, z)          # empty batches are no-ops (batch_mul returns vec![] :853-855)
+    e.beaver_mask(0, z, z, z, z, z)
+    assert e.mac_verify(0, z, z) is True
+    with pytest.raises(pkg.ArkMpcError):
+        e.share_add_public(4, 2, np.zeros(4, dtype=np.uint64), np.zeros(32, dtype=np.uint64), np.zeros(16, dtype=np.uint64), np.zeros(32, dtype=np.uint64))
+    with pytest.raises(pkg.ArkMpcError):
+        pkg.Engine(7)
+    fq = engines[3]
+    with pytest.raises(pkg.ArkMpcError):  # curve ops need the Fr context
+        fq.g1_neg(1, np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("fid", [0])
+def test_device_pointer_mode_and_views(pkg, oracle, fid):
+    """device-pointer mode on torch-owned memory + the share-view (split layout) entry points."""
+    import torch
+    n = 1000
+    e = pkg.Engine(fid, device=0, host_buffers=False, stream=torch.cuda.current_stream().cuda_stream)
+    x, y, key, keys, sh = _two_party_inputs(fid, n, seed=4242)
+    dev = lambda a: torch.from_numpy(a.view(np.int64)).cuda()
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    for party in (0, 1):
+        dx, dy, da, db, dc = (dev(sh[k][party]) for k in "xyabc")
+        out = torch.zeros(2 * n * 4, dtype=torch.int64, device="cuda")
+        e.beaver_mask(n, dx, dy, da, db, out)
+        torch.cuda.synchronize()
+        want_de = oracle.beaver_mask(fid, sh["x"][party], sh["y"][party], sh["a"][party], sh["b"][party])
+        assert np.array_equal(host(out), want_de)
+        # split layout: all shares then all macs
+        def split(a):
+            r = a.reshape(-1, 8)
+            return dev(np.ascontiguousarray(r[:, :4]).reshape(-1)), dev(np.ascontiguousarray(r[:, 4:]).reshape(-1))
+        xs, _ = split(sh["x"][party]); ys, _ = split(sh["y"][party])
+        a_s, a_m = split(sh["a"][party]); b_s, b_m = split(sh["b"][party]); c_s, c_m = split(sh["c"][party])
+        out_v = torch.zeros_like(out)
+        e.beaver_mask_v(n, xs, 4, ys, 4, a_s, 4, b_s, 4, out_v)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(out_v), want_de)
+        peer = 1 - party
+        peer_de = dev(oracle.beaver_mask(fid, sh["x"][peer], sh["y"][peer], sh["a"][peer], sh["b"][peer]))
+        o_s = torch.zeros(n * 4, dtype=torch.int64, device="cuda"); o_m = torch.zeros_like(o_s)
+        e.beaver_finish_fused_v(n, party, keys[party], out, peer_de, a_s, a_m, 4, b_s, b_m, 4, c_s, c_m, 4, o_s, o_m, 4)
+        o_aos = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
+        e.beaver_finish_fused(n, party, keys[party], out, peer_de, da, db, dc, o_aos)
+        torch.cuda.synchronize()
+        opened = oracle.open_combine(fid, want_de, host(peer_de))
+        want = oracle.beaver_finish(fid, party, keys[party], opened[:4 * n].copy(), opened[4 * n:].copy(),
+                                    sh["a"][party], sh["b"][party], sh["c"][party])
+        assert np.array_equal(host(o_aos), want)
+        w = want.reshape(-1, 8)
+        assert np.array_equal(host(o_s).reshape(-1, 4), w[:, :4]) and np.array_equal(host(o_m).reshape(-1, 4), w[:, 4:])
+    # misaligned device pointer is rejected, not dereferenced
+    t = torch.zeros(64, dtype=torch.int64, device="cuda")
+    with pytest.raises(pkg.ArkMpcError):
+        e.scalar_add(1, t.data_ptr() + 8, t.data_ptr() + 8, t.data_ptr() + 8)
+    e.close()

@@ -1,0 +1,84 @@
+"""Pins the C oracle (oracle/ark_oracle.c) against exact big-int arithmetic and published constants.
+CPU only.  The reference holds no golden vectors for this path, so these are
+the anchors: Python ints, arkworks' published R/INV, hashlib SHA3."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+
+import pyref
+from helpers import mont_array, from_mont_array, mixed_values, limbs_to_ints, ints_to_limbs
+
+FIDS = [0, 1, 2, 3]
+
+
+class OraField(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_uint64 * 4), ("r", ctypes.c_uint64 * 4), ("r2", ctypes.c_uint64 * 4),
+                ("inv", ctypes.c_uint64), ("bits", ctypes.c_int)]
+
+
+@pytest.mark.parametrize("fid", FIDS)
+def test_montgomery_constants_match_published(oracle, fid):
+    f = ctypes.cast(oracle.lib.ora_get_field(ctypes.c_int(fid)), ctypes.POINTER(OraField)).contents
+    p = pyref.unlimbs(f.p)
+    assert p == pyref.P[fid]
+    assert pyref.unlimbs(f.r) == (1 << 256) % p == pyref.PUBLISHED_R[fid]
+    assert pyref.unlimbs(f.r2) == (1 << 512) % p
+    assert f.inv == (-pow(p, -1, 1 << 64)) % (1 << 64) == pyref.PUBLISHED_INV[fid]
+    assert f.bits == p.bit_length()
+
+
+@pytest.mark.parametrize("fid", FIDS)
+def test_field_ops_vs_bigint(oracle, fid):
+    p = pyref.P[fid]
+    a = mixed_values(fid, 200, seed=100 + fid)
+    b = list(reversed(mixed_values(fid, 200, seed=200 + fid)))
+    am, bm = mont_array(fid, a), mont_array(fid, b)
+    assert from_mont_array(fid, oracle.scalar_add(fid, am, bm)) == [(x + y) % p for x, y in zip(a, b)]
+    assert from_mont_array(fid, oracle.scalar_sub(fid, am, bm)) == [(x - y) % p for x, y in zip(a, b)]
+    assert from_mont_array(fid, oracle.scalar_mul(fid, am, bm)) == [(x * y) % p for x, y in zip(a, b)]
+    assert from_mont_array(fid, oracle.scalar_neg(fid, am)) == [(-x) % p for x in a]
+    # conversions: canonical <-> Montgomery, including inputs >= p that must be reduced first
+    raw = a + [p, p + 5, (1 << 256) - 1]
+    assert limbs_to_ints(oracle.from_canonical(fid, ints_to_limbs(raw))) == [pyref.to_mont(fid, v) for v in raw]
+    assert limbs_to_ints(oracle.to_canonical(fid, am)) == a
+    # outputs are canonical residues (< p) in Montgomery form
+    assert all(v < p for v in limbs_to_ints(oracle.scalar_mul(fid, am, bm)))
+
+
+@pytest.mark.parametrize("fid", FIDS)
+def test_inverse_and_bytes(oracle, fid):
+    p = pyref.P[fid]
+    vals = [v for v in mixed_values(fid, 40, seed=7) if v != 0]
+    f = ctypes.c_void_p(oracle.lib.ora_get_field(ctypes.c_int(fid)))
+    for v in vals[:12]:
+        inp = ints_to_limbs([pyref.to_mont(fid, v)])
+        out = np.zeros(4, dtype=np.uint64)
+        oracle.lib.ora_fp_inv(f, oracle._p(inp), oracle._p(out))
+        assert pyref.from_mont(fid, limbs_to_ints(out)[0]) == pow(v, -1, p)
+    be = oracle.to_bytes_be(fid, mont_array(fid, vals)).tobytes()
+    assert be == b"".join(pyref.to_bytes_be(fid, v) for v in vals)
+    # from_be_bytes_mod_order on 32-byte digests and on longer strings
+    for data in [b"\xff" * 32, bytes(range(32)), b"\x01" + b"\x00" * 40, b""]:
+        buf = np.frombuffer(data if data else b"\0", dtype=np.uint8).copy()
+        out = np.zeros(4, dtype=np.uint64)
+        oracle.lib.ora_fp_from_be_bytes_mod_order(f, oracle._p(buf), ctypes.c_size_t(len(data)), oracle._p(out))
+        assert pyref.from_mont(fid, limbs_to_ints(out)[0]) == int.from_bytes(data, "big") % p
+
+
+def test_sha3_known_answers(oracle):
+    # FIPS 202 known answers + hashlib over the padding boundaries (rate = 136 bytes)
+    assert oracle.sha3_256(b"").hex() == "a7ffc6f8bf1ed76651c14756a061d662f580ff4de43b49fa82d80a4b80f8434a"
+    assert oracle.sha3_256(b"abc").hex() == "3a985da74fe225b2045c172d6bd390bd855f086e3e9d525b46bfe24511431532"
+    for n in [1, 55, 135, 136, 137, 271, 272, 273, 1000, 4096 + 17]:
+        data = bytes((i * 131 + 7) & 0xFF for i in range(n))
+        assert oracle.sha3_256(data) == hashlib.sha3_256(data).digest()
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2])
+def test_commitment_vs_hashlib(oracle, fid):
+    vals = mixed_values(fid, 37, seed=5)
+    blinder = 0x1234567890abcdef1234567890abcdef % pyref.P[fid]
+    got = oracle.commit_scalars(fid, mont_array(fid, vals), mont_array(fid, [blinder]))
+    assert pyref.from_mont(fid, limbs_to_ints(got)[0]) == pyref.commit(fid, vals, blinder)
