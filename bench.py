@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py -- authenticated Beaver mul-gates/sec over BN254 Fr, batch 2^20 per GPU (BASELINE.json config[1]).
+
+A "step" is one complete two-party `AuthenticatedScalarResult::batch_mul` (reference:
+online-phase/src/algebra/scalar/authenticated_scalar.rs:848-879) over a batch of n gates, both
+parties simulated on the same GPU with the network mocked as a pointer swap (as
+online-phase/benches/batch_ops.rs:20-39 runs both parties in-process):
+
+    party0.K1 beaver_mask -> party1.K1 beaver_mask -> [exchange d||e] ->
+    party0.K2+K3 beaver_finish_fused -> party1.K2+K3 beaver_finish_fused        (4 kernel launches)
+
+All inputs are resident in HBM before the timed region.  Data is synthetic: uniformly random field
+elements, valid Beaver triples and valid SPDZ MACs generated on the GPU from a fixed seed.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]         (N = 1)
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.  Multi-GPU = the same batch size on every rank (weak scaling), gates
+are independent so there is no data-path collective; ranks only meet at the timing barriers.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "authenticated Beaver mul-gates/sec over BN254 Fr, batch 2^20, at 1/2/4/8 GPUs"
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_GATE = 1024       # two-party gate, SURVEY.md section 8(d)
+# apportioning of the 512 B / party-gate of SURVEY 8(d) between the two kernels of a party:
+ALG_BYTES_K1 = 192              # read x,y shares+MACs 128, write own d||e 64
+ALG_BYTES_K3 = 320              # read a,b,c shares+MACs 192, read peer d||e 64, write result 64
+FID = 0                         # BN254 Fr
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log2n", type=int, default=20, help="gates per GPU per step (default 2^20, the metric's batch)")
+    ap.add_argument("--layout", choices=["aos", "split"], default="aos",
+                    help="HBM layout of share vectors: arkworks AoS (drop-in) or engine-native split columns")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2n", type=int, default=18, help="CPU baseline sample size (gates)")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def rand_field_elems(eng, n, gen):
+    """n uniformly random BN254 Fr elements in Montgomery form (int64 tensor of 4n limbs), generated on the GPU."""
+    raw = torch.randint(-(2**63), 2**63 - 1, (4 * n,), dtype=torch.int64, device="cuda", generator=gen)
+    out = torch.empty_like(raw)
+    eng.scalar_from_canonical(n, raw, out)   # reduces mod p, then to Montgomery form
+    return out
+
+
+def additive_split(eng, n, v, gen):
+    s0 = rand_field_elems(eng, n, gen)
+    s1 = torch.empty_like(s0)
+    eng.scalar_sub(n, v, s0, s1)
+    return s0, s1
+
+
+def make_shares(eng, n, v, key, gen, layout):
+    """SPDZ-share the vector v under MAC key `key` (both Montgomery limb tensors) -> per-party share buffers."""
+    mac = torch.empty_like(v)
+    eng.scalar_mul(n, v, key.repeat(n), mac)
+    s0, s1 = additive_split(eng, n, v, gen)
+    m0, m1 = additive_split(eng, n, mac, gen)
+    if layout == "aos":   # [n][share(4) | mac(4)]
+        p0 = torch.cat([s0.view(n, 4), m0.view(n, 4)], dim=1).contiguous().view(-1)
+        p1 = torch.cat([s1.view(n, 4), m1.view(n, 4)], dim=1).contiguous().view(-1)
+    else:                 # [share column (4n) | mac column (4n)]
+        p0 = torch.cat([s0, m0]).contiguous()
+        p1 = torch.cat([s1, m1]).contiguous()
+    return p0, p1
+
+
+class Party:
+    pass
+
+
+def build_workload(eng, n, seed, layout):
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    key_sh = [rand_field_elems(eng, 1, gen), rand_field_elems(eng, 1, gen)]
+    key = torch.empty_like(key_sh[0])
+    eng.scalar_add(1, key_sh[0], key_sh[1], key)
+    x = rand_field_elems(eng, n, gen)
+    y = rand_field_elems(eng, n, gen)
+    a = rand_field_elems(eng, n, gen)
+    b = rand_field_elems(eng, n, gen)
+    c = torch.empty_like(a)
+    eng.scalar_mul(n, a, b, c)
+    parties = [Party(), Party()]
+    for name, v in (("x", x), ("y", y), ("a", a), ("b", b), ("c", c)):
+        p0, p1 = make_shares(eng, n, v, key, gen, layout)
+        setattr(parties[0], name, p0)
+        setattr(parties[1], name, p1)
+    for pid, p in enumerate(parties):
+        p.id = pid
+        p.key = key_sh[pid].cpu().numpy().view(np.uint64).copy()
+        p.de = torch.empty(2 * n * 4, dtype=torch.int64, device="cuda")
+        p.out = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    return parties, (x, y, key)
+
+
+def k1(eng, n, p, layout):
+    if layout == "aos":
+        eng.beaver_mask(n, p.x, p.y, p.a, p.b, p.de)
+    else:
+        eng.beaver_mask_v(n, p.x, 4, p.y, 4, p.a, 4, p.b, 4, p.de)
+
+
+def k3(eng, n, p, peer, layout):
+    if layout == "aos":
+        eng.beaver_finish_fused(n, p.id, p.key, p.de, peer.de, p.a, p.b, p.c, p.out)
+    else:
+        col = 4 * n * 8  # byte offset of the mac column
+        eng.beaver_finish_fused_v(n, p.id, p.key, p.de, peer.de,
+                                  p.a.data_ptr(), p.a.data_ptr() + col, 4, p.b.data_ptr(), p.b.data_ptr() + col, 4,
+                                  p.c.data_ptr(), p.c.data_ptr() + col, 4, p.out.data_ptr(), p.out.data_ptr() + col, 4)
+
+
+def step(eng, n, parties, layout, evs=None):
+    p0, p1 = parties
+    if evs is not None: evs[0].record()
+    k1(eng, n, p0, layout)
+    if evs is not None: evs[1].record()
+    k1(eng, n, p1, layout)
+    if evs is not None: evs[2].record()
+    k3(eng, n, p0, p1, layout)       # the "network": each party reads the peer's d||e buffer
+    if evs is not None: evs[3].record()
+    k3(eng, n, p1, p0, layout)
+    if evs is not None: evs[4].record()
+
+
+def check_results(eng, n, parties, truth, layout):
+    """open(batch_mul(x, y)) == x*y and the MAC relation holds (reference test_batch_mul, :1571-1594),
+    using only engine ops; the bit-exact comparison with the oracle is tests/ and smoke()."""
+    x, y, key = truth
+    p0, p1 = parties
+    if layout == "aos":
+        s0, m0 = p0.out.view(n, 8)[:, :4].contiguous().view(-1), p0.out.view(n, 8)[:, 4:].contiguous().view(-1)
+        s1, m1 = p1.out.view(n, 8)[:, :4].contiguous().view(-1), p1.out.view(n, 8)[:, 4:].contiguous().view(-1)
+    else:
+        s0, m0, s1, m1 = p0.out[:4 * n], p0.out[4 * n:], p1.out[:4 * n], p1.out[4 * n:]
+    prod = torch.empty_like(x); eng.scalar_mul(n, x, y, prod)
+    opened = torch.empty_like(x); eng.scalar_add(n, s0, s1, opened)
+    mac = torch.empty_like(x); eng.scalar_add(n, m0, m1, mac)
+    kprod = torch.empty_like(x); eng.scalar_mul(n, prod, key.repeat(n), kprod)
+    torch.cuda.synchronize()
+    return bool(torch.equal(opened, prod)) and bool(torch.equal(mac, kprod))
+
+
+def cpu_baseline(parties, n, log2n_cpu, layout):
+    """The oracle's restatement of the reference's literal 9-pass batch_mul (both parties), timed on this
+    host's cores on the first 2^log2n_cpu gates of the same workload.  kind = "port"."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    ora = oracle_api.load()
+    m = min(n, 1 << log2n_cpu)
+
+    def host_aos(t):
+        if layout == "aos":
+            return t[:8 * m].cpu().numpy().view(np.uint64).copy()
+        s = t[:4 * m].cpu().numpy().view(np.uint64).reshape(m, 4)
+        mm = t[4 * n:4 * n + 4 * m].cpu().numpy().view(np.uint64).reshape(m, 4)
+        return np.ascontiguousarray(np.concatenate([s, mm], axis=1).reshape(-1))
+
+    H = [{k: host_aos(getattr(p, k)) for k in "xyabc"} for p in parties]
+    keys = [p.key for p in parties]
+    cores = os.cpu_count() or 1
+
+    def run_range(lo, hi, party, peer_de, my_de_out, res_out, scratch):
+        cnt = hi - lo
+        sl8, sl4 = slice(8 * lo, 8 * hi), None
+        h = H[party]
+        args = [np.ascontiguousarray(h[k][sl8]) for k in "xyabc"]
+        pd = np.ascontiguousarray(np.concatenate([peer_de[4 * lo:4 * hi], peer_de[4 * m + 4 * lo:4 * m + 4 * hi]]))
+        md = np.zeros(8 * cnt, dtype=np.uint64)
+        out = np.zeros(8 * cnt, dtype=np.uint64)
+        ora._call("ora_batch_mul_9pass_local", FID, cnt, party, keys[party], args[0], args[1], args[2], args[3], args[4], pd, md, out, scratch)
+        res_out[sl8] = out
+
+    # the peers' d||e (needed as input by each party's finish passes): precompute untimed
+    de = [ora.beaver_mask(FID, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"]) for p in (0, 1)]
+    res = [np.zeros(8 * m, dtype=np.uint64) for _ in (0, 1)]
+
+    def timed(nthreads):
+        bounds = [m * i // nthreads for i in range(nthreads + 1)]
+        scr = [np.zeros(64 * (bounds[i + 1] - bounds[i]), dtype=np.uint64) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for party in (0, 1):
+            ths = [threading.Thread(target=run_range, args=(bounds[i], bounds[i + 1], party, de[1 - party], None, res[party], scr[i]))
+                   for i in range(nthreads)]
+            for t in ths: t.start()
+            for t in ths: t.join()
+        return time.perf_counter() - t0
+
+    timed(cores)  # warm
+    reps, tot = 0, 0.0
+    while tot < 4.0 and reps < 20:
+        tot += timed(cores); reps += 1
+    t_all = tot / reps
+    t_one = timed(1)
+    return {
+        "value": m / t_all, "unit": "gates/s", "cores": cores, "kind": "port",
+        "sample": "first 2^%d gates of the same seeded workload, both parties, reference's literal 9-pass batch_mul "
+                  "(oracle/ark_oracle.c ora_batch_mul_9pass_local), %d threads static range split, mean of %d runs" % (int(np.log2(m)), cores, reps),
+        "single_thread_value": m / t_one,
+    }, res, m
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+    pkg = importlib.import_module("ark-mpc_amd")
+    eng = pkg.Engine(FID, device=dev, host_buffers=False, stream=torch.cuda.current_stream().cuda_stream)
+    n = 1 << args.log2n
+    parties, truth = build_workload(eng, n, seed=0xA11CE002 + rank, layout=args.layout)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(eng, n, parties, args.layout)
+    barrier()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(eng, n, parties, args.layout, evs[s])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # per-kernel durations from the in-stream HIP events of the timed region
+    seg = np.array([[evs[s][i].elapsed_time(evs[s][i + 1]) for i in range(4)] for s in range(args.steps)])  # ms
+    k1_ms = float(seg[:, :2].mean())
+    k3_ms = float(seg[:, 2:].mean())
+    dev_ms_per_step = float(np.mean([evs[s][0].elapsed_time(evs[s][4]) for s in range(args.steps)]))
+
+    ok = True if args.no_check else check_results(eng, n, parties, truth, args.layout)
+
+    out = None
+    if rank == 0:
+        gates = n * world * args.steps
+        value = gates / elapsed
+        ach = n * ALG_BYTES_K3 / (k3_ms * 1e-3) / 1e9
+        out = {
+            "metric": METRIC, "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)", "data": "synthetic",
+            "config": {"workload": "2^%d AuthenticatedScalar Beaver muls over BN254 Fr per GPU per step, two parties in-process, "
+                                   "mock net (BASELINE.json configs[1])" % args.log2n,
+                       "gates_per_gpu": n, "field": "bn254_fr", "layout": args.layout, "launches_per_step": 4,
+                       "parallelism": "gate-range sharding, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_beaver_finish<0,true> (K2+K3 fused)", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": n * ALG_BYTES_K3, "avg_launch_ms": k3_ms},
+            "pipeline": {"algorithmic_GBps": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9,
+                         "frac_of_hbm_peak": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "k1_avg_launch_ms": k1_ms, "k3_avg_launch_ms": k3_ms, "device_ms_per_step": dev_ms_per_step,
+                         "k1_achieved_GBps": n * ALG_BYTES_K1 / (k1_ms * 1e-3) / 1e9},
+            "results_check": "open(batch_mul(x,y)) == x*y and MAC shares sum to key*x*y: %s" % ("ok" if ok else "FAILED"),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, _, _ = cpu_baseline(parties, n, args.cpu_log2n, args.layout)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    if not ok:
+        raise SystemExit("result check failed")
+
+
+if __name__ == "__main__":
+    main()
