@@ -82,3 +82,55 @@ def splitmix64_stream(seed, count):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return z
+
+
+class EngineAdapter:
+    """Presents the HIP engine (host-buffer mode, through the C ABI) with the oracle binding's numpy-in /
+    numpy-out method shapes, so a golden test body can run against either backend."""
+
+    def __init__(self, pkg):
+        self.pkg = pkg
+        self.engines = {}
+
+    def eng(self, fid):
+        if fid not in self.engines:
+            self.engines[fid] = self.pkg.Engine(fid, device=0, host_buffers=True)
+        return self.engines[fid]
+
+    def _o(self, n, w):
+        return np.zeros(n * w, dtype=np.uint64)
+
+    def scalar_add(self, fid, a, b): n = len(a) // 4; o = self._o(n, 4); self.eng(fid).scalar_add(n, a, b, o); return o
+    def scalar_sub(self, fid, a, b): n = len(a) // 4; o = self._o(n, 4); self.eng(fid).scalar_sub(n, a, b, o); return o
+    def scalar_mul(self, fid, a, b): n = len(a) // 4; o = self._o(n, 4); self.eng(fid).scalar_mul(n, a, b, o); return o
+    def scalar_neg(self, fid, a): n = len(a) // 4; o = self._o(n, 4); self.eng(fid).scalar_neg(n, a, o); return o
+    def from_canonical(self, fid, a): n = len(a) // 4; o = self._o(n, 4); self.eng(fid).scalar_from_canonical(n, a, o); return o
+    def to_canonical(self, fid, a): n = len(a) // 4; o = self._o(n, 4); self.eng(fid).scalar_to_canonical(n, a, o); return o
+    def to_bytes_be(self, fid, a):
+        n = len(a) // 4; o = np.zeros(32 * n, dtype=np.uint8); self.eng(fid).scalar_to_bytes_be(n, a, o); return o
+    def beaver_mask(self, fid, x, y, a, b): n = len(x) // 8; o = self._o(2 * n, 4); self.eng(fid).beaver_mask(n, x, y, a, b, o); return o
+    def open_combine(self, fid, mine, peer): n = len(mine) // 4; o = self._o(n, 4); self.eng(fid).open_combine(n, mine, peer, o); return o
+    def beaver_finish(self, fid, party, key, d, e, a, b, c):
+        n = len(a) // 8; o = self._o(n, 8); self.eng(fid).beaver_finish(n, party, key, d, e, a, b, c, o); return o
+    def share_add_public(self, fid, party, key, a, pub, sub=False):
+        n = len(a) // 8; o = self._o(n, 8)
+        (self.eng(fid).share_sub_public if sub else self.eng(fid).share_add_public)(n, party, key, a, pub, o); return o
+    def mac_check_shares(self, fid, key, opened, shares):
+        n = len(opened) // 4; o = self._o(n, 4); self.eng(fid).mac_check_shares(n, key, opened, shares, o); return o
+    def mac_verify(self, fid, mine, peer): return self.eng(fid).mac_verify(len(mine) // 4, mine, peer)
+    def commit_scalars(self, fid, values, blinder): return self.eng(fid).commit_sha3(len(values) // 4, values, blinder)
+    # curve (context field = BN254 Fr)
+    def g1_batch_add(self, a, b): n = len(a) // 12; o = self._o(n, 12); self.eng(0).g1_add(n, a, b, o); return o
+    def g1_neg(self, a): n = len(a) // 12; o = self._o(n, 12); self.eng(0).g1_neg(n, a, o); return o
+    def g1_batch_scalar_mul(self, pts, sc): n = len(pts) // 12; o = self._o(n, 12); self.eng(0).g1_scalar_mul(n, pts, sc, o); return o
+    def g1_batch_to_affine(self, pts):
+        n = len(pts) // 12; xy = self._o(n, 8); inf = np.zeros(n, dtype=np.uint8); self.eng(0).g1_to_affine(n, pts, xy, inf); return xy, inf
+    def g1_to_bytes(self, pts): n = len(pts) // 12; o = np.zeros(32 * n, dtype=np.uint8); self.eng(0).g1_to_bytes(n, pts, o); return o
+    def pointshare_add(self, a, b, sub=False):
+        n = len(a) // 24; o = self._o(n, 24); (self.eng(0).pointshare_sub if sub else self.eng(0).pointshare_add)(n, a, b, o); return o
+    def pointshare_neg(self, a): n = len(a) // 24; o = self._o(n, 24); self.eng(0).pointshare_neg(n, a, o); return o
+    def pointshare_mul_public(self, sh, sc): n = len(sh) // 24; o = self._o(n, 24); self.eng(0).pointshare_mul_public(n, sh, sc, o); return o
+    def pointshare_add_public(self, party, key, sh, pub):
+        n = len(sh) // 24; o = self._o(n, 24); self.eng(0).pointshare_add_public(n, party, key, sh, pub, o); return o
+    def scalarshare_mul_generator(self, ss): n = len(ss) // 8; o = self._o(n, 24); self.eng(0).scalarshare_mul_generator(n, ss, o); return o
+    def scalarshare_mul_point(self, ss, pts): n = len(ss) // 8; o = self._o(n, 24); self.eng(0).scalarshare_mul_point(n, ss, pts, o); return o

@@ -1,0 +1,134 @@
+"""GPU parity for the curve side (BN254 G1): HIP kernels through the C ABI vs the CPU oracle.
+Points are compared on AFFINE coordinates (what arkworks' equality and wire format see); the Jacobian
+representative depends on the addition chain."""
+import numpy as np
+import pytest
+
+import pyref
+from helpers import mont_array, rand_values, limbs_to_ints, EngineAdapter
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(pkg):
+    return EngineAdapter(pkg)
+
+
+def jac(points, zs):
+    return np.array(sum((pyref.g1_jacobian_mont(p, z) for p, z in zip(points, zs)), []), dtype=np.uint64)
+
+
+def random_points(n, seed, with_identity=True):
+    ks = rand_values(0, n, seed)
+    pts = [pyref.g1_mul(pyref.G, k) for k in ks]
+    if with_identity and n >= 4:
+        pts[1] = None
+    zs = [1 + (seed * 31 + 7 * i) % 997 for i in range(n)]
+    return pts, jac(pts, zs)
+
+
+def affine_equal(hip, oracle, a, b):
+    xa, ia = hip.g1_batch_to_affine(np.ascontiguousarray(a))
+    xb, ib = oracle.g1_batch_to_affine(np.ascontiguousarray(b))
+    return np.array_equal(ia, ib) and np.array_equal(xa, xb)
+
+
+def test_add_sub_neg(hip, oracle):
+    n = 40
+    _, P = random_points(n, 1)
+    _, Q = random_points(n, 2)
+    Q[12 * 5:12 * 6] = P[12 * 5:12 * 6]                                  # P + P through add
+    Q[12 * 6:12 * 7] = oracle.g1_neg(P[12 * 6:12 * 7].copy())           # P + (-P)
+    assert affine_equal(hip, oracle, hip.g1_batch_add(P, Q), oracle.g1_batch_add(P, Q))
+    assert affine_equal(hip, oracle, hip.g1_neg(P), oracle.g1_neg(P))
+    o = np.zeros(12 * n, dtype=np.uint64); hip.eng(0).g1_sub(n, P, Q, o)
+    assert affine_equal(hip, oracle, o, oracle.g1_batch_add(P, oracle.g1_neg(Q)))
+    # identity outputs are stored in arkworks' canonical form (1, 1, 0)
+    s = hip.g1_batch_add(P[12 * 6:12 * 7].copy(), Q[12 * 6:12 * 7].copy())
+    assert np.array_equal(s, oracle.g1_identity())
+
+
+def test_scalar_mul(hip, oracle):
+    n = 24
+    pts, P = random_points(n, 3)
+    ks = [0, 1, 2, pyref.RORD - 1] + rand_values(0, n - 4, 4)
+    S = mont_array(0, ks)
+    got = hip.g1_batch_scalar_mul(P, S)
+    assert affine_equal(hip, oracle, got, oracle.g1_batch_scalar_mul(P, S))
+    # and against the Python group law directly
+    xy, inf = hip.g1_batch_to_affine(got)
+    for i in range(n):
+        want = pyref.g1_mul(pts[i], ks[i])
+        if want is None:
+            assert inf[i] == 1
+        else:
+            x, y = limbs_to_ints(xy[8 * i:8 * i + 8])
+            assert (pyref.from_mont(3, x), pyref.from_mont(3, y)) == want
+    o = np.zeros(12 * n, dtype=np.uint64); hip.eng(0).g1_generator_mul(n, S, o)
+    G = jac([pyref.G] * n, [1] * n)
+    assert affine_equal(hip, oracle, o, oracle.g1_batch_scalar_mul(G, S))
+    assert np.array_equal(hip.g1_to_bytes(got), oracle.g1_to_bytes(oracle.g1_batch_scalar_mul(P, S)))
+
+
+@pytest.mark.parametrize("party", [0, 1])
+def test_pointshare_ops(hip, oracle, party):
+    n = 10
+    _, A = random_points(2 * n, 5)
+    _, B = random_points(2 * n, 6)
+    S = mont_array(0, [0, 1] + rand_values(0, n - 2, 7))
+    key = mont_array(0, rand_values(0, 1, 8))
+    _, PUB = random_points(n, 9)
+    SS = mont_array(0, rand_values(0, 2 * n, 10))   # n ScalarShares = 2n scalars
+    assert affine_equal(hip, oracle, hip.pointshare_add(A, B), oracle.pointshare_add(A, B))
+    assert affine_equal(hip, oracle, hip.pointshare_add(A, B, sub=True), oracle.pointshare_add(A, B, sub=True))
+    assert affine_equal(hip, oracle, hip.pointshare_neg(A), oracle.pointshare_neg(A))
+    assert affine_equal(hip, oracle, hip.pointshare_mul_public(A, S), oracle.pointshare_mul_public(A, S))
+    assert affine_equal(hip, oracle, hip.pointshare_add_public(party, key, A, PUB), oracle.pointshare_add_public(party, key, A, PUB))
+    assert affine_equal(hip, oracle, hip.scalarshare_mul_generator(SS), oracle.scalarshare_mul_generator(SS))
+    assert affine_equal(hip, oracle, hip.scalarshare_mul_point(SS, PUB), oracle.scalarshare_mul_point(SS, PUB))
+    o = np.zeros(12 * n, dtype=np.uint64); hip.eng(0).pointshare_extract(n, A, o)
+    assert np.array_equal(o.reshape(-1, 12), A.reshape(-1, 24)[:, :12])
+
+
+def test_point_open_authenticated(hip, oracle):
+    """AuthenticatedPointResult::open_authenticated_batch (authenticated_curve.rs:190-283) for both parties:
+    value*mac_key - mac per party sums to the identity; a corrupted MAC is caught (modify_mac :839-849)."""
+    n = 6
+    r = pyref.RORD
+    k0, k1 = rand_values(0, 2, 11)
+    key = (k0 + k1) % r
+    vals = rand_values(0, n, 12)                     # discrete logs of the shared points
+    s0 = rand_values(0, n, 13); s1 = [(v - a) % r for v, a in zip(vals, s0)]
+    m0 = rand_values(0, n, 14); m1 = [(key * v - a) % r for v, a in zip(vals, m0)]
+    mk = lambda ss, ms: jac(sum(([pyref.g1_mul(pyref.G, s), pyref.g1_mul(pyref.G, m)] for s, m in zip(ss, ms)), []), [1 + i for i in range(2 * n)])
+    sh = [mk(s0, m0), mk(s1, m1)]
+    keys = [mont_array(0, [k0]), mont_array(0, [k1])]
+    e = hip.eng(0)
+    mine = []
+    for p in (0, 1):
+        o = np.zeros(12 * n, dtype=np.uint64); e.pointshare_extract(n, sh[p], o); mine.append(o)
+    opened = hip.g1_batch_add(mine[0], mine[1])
+    xy, inf = hip.g1_batch_to_affine(opened)
+    for i in range(n):
+        x, y = limbs_to_ints(xy[8 * i:8 * i + 8])
+        assert (pyref.from_mont(3, x), pyref.from_mont(3, y)) == pyref.g1_mul(pyref.G, vals[i])
+
+    def checks(shares):
+        out = []
+        for p in (0, 1):
+            o = np.zeros(12 * n, dtype=np.uint64); e.point_mac_check_shares(n, keys[p], opened, shares[p], o); out.append(o)
+        ok = np.zeros(n, dtype=np.uint8); e.point_mac_verify(n, out[0], out[1], ok)
+        return out, ok
+
+    chk, ok = checks(sh)
+    assert ok.tolist() == [1] * n
+    # oracle agreement on the per-party check points
+    for p in (0, 1):
+        kv = oracle.g1_batch_scalar_mul(opened, np.tile(keys[p], n))
+        macs = np.ascontiguousarray(sh[p].reshape(-1, 24)[:, 12:].reshape(-1))
+        assert affine_equal(hip, oracle, chk[p], oracle.g1_batch_add(kv, oracle.g1_neg(macs)))
+    bad = [sh[0].copy(), sh[1].copy()]
+    bad[0][24 * 2 + 12:24 * 3] = jac([pyref.g1_mul(pyref.G, 999)], [1])
+    _, ok = checks(bad)
+    assert ok.tolist() == [1, 1, 0, 1, 1, 1]
