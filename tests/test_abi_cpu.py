@@ -1,0 +1,45 @@
+"""CPU-only checks of the boundary: the C-ABI library loads, exports every symbol include/arkmpc.h declares,
+refuses to run without a GPU (no silent CPU fallback), and its host-side SHA3 matches hashlib."""
+import ctypes
+import hashlib
+import importlib
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    eng = importlib.import_module("ark-mpc_amd.engine")
+    declared = eng.declared_symbols()
+    assert len(declared) >= 50
+    lib = pkg.load_library()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert missing == []
+    assert b"gfx950" in lib.arkmpc_version()
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = pkg.load_library()
+    assert lib.arkmpc_device_count() == 0
+    h = ctypes.c_void_p()
+    assert lib.arkmpc_ctx_create(0, 0, ctypes.byref(h)) == -4          # ARKMPC_ERR_NO_DEVICE
+    with pytest.raises(pkg.ArkMpcError):
+        pkg.Engine("bn254_fr")
+
+
+def test_null_and_bad_args(pkg):
+    lib = pkg.load_library()
+    assert lib.arkmpc_ctx_create(0, 0, None) == -1
+    h = ctypes.c_void_p()
+    assert lib.arkmpc_ctx_create(9, 0, ctypes.byref(h)) == -1
+    assert lib.arkmpc_scalar_add(None, ctypes.c_size_t(1), None, None, None) == -1
+    assert lib.arkmpc_sync(None) == -1
+
+
+def test_host_sha3_matches_hashlib(pkg):
+    eng = importlib.import_module("ark-mpc_amd.engine")
+    for n in [0, 1, 135, 136, 137, 272, 1000, 100003]:
+        data = bytes((i * 7 + 3) & 0xFF for i in range(n))
+        assert eng.sha3_256(data) == hashlib.sha3_256(data).digest()
