@@ -133,6 +133,29 @@ class Engine:
                 conv.append(_ptr(a))
         self._ck(fn(*conv))
 
+    def prepare(self, name, *args):
+        """Pre-convert the arguments of one entry point and return a zero-argument callable that replays the call
+        (for launch-bound loops: no per-call marshalling). Buffers must stay alive and in place."""
+        fn = getattr(self.lib, "arkmpc_" + name)
+        conv, keep = [self.h], []
+        for a in args:
+            if isinstance(a, tuple) and a[0] == "key":
+                arr, p = _key(a[1]); keep.append(arr); conv.append(p)
+            elif isinstance(a, tuple) and a[0] == "size":
+                conv.append(ctypes.c_size_t(int(a[1])))
+            elif isinstance(a, tuple) and a[0] == "int":
+                conv.append(ctypes.c_int(int(a[1])))
+            else:
+                conv.append(_ptr(a))
+        conv = tuple(conv)
+        ck, h, lib = self._ck, self.h, self.lib
+
+        def replay(_fn=fn, _conv=conv, _keep=keep):
+            rc = _fn(*_conv)
+            if rc != 0:
+                ck(rc)
+        return replay
+
     # ---- Scalar vectors
     def scalar_add(self, n, a, b, out): self.call("scalar_add", ("size", n), a, b, out)
     def scalar_sub(self, n, a, b, out): self.call("scalar_sub", ("size", n), a, b, out)
