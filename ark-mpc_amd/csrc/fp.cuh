@@ -41,6 +41,23 @@ __device__ __forceinline__ void fe_store(u64* p, const Fe& a) {
     q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
 
+// non-temporal forms for data that is streamed exactly once (keeps it from displacing reusable lines in L2 / MALL)
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Fe fe_load_nt(const u64* p) {
+    const u32x4_t* q = reinterpret_cast<const u32x4_t*>(p);
+    u32x4_t lo = __builtin_nontemporal_load(q), hi = __builtin_nontemporal_load(q + 1);
+    Fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void fe_store_nt(u64* p, const Fe& a) {
+    u32x4_t* q = reinterpret_cast<u32x4_t*>(p);
+    u32x4_t lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+    __builtin_nontemporal_store(lo, q);
+    __builtin_nontemporal_store(hi, q + 1);
+}
+
 template <int F> __host__ __device__ __forceinline__ Fe fe_zero() {
     Fe r;
 #pragma unroll

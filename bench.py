@@ -46,11 +46,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=20, help="gates per GPU per step (default 2^20, the metric's batch)")
-    ap.add_argument("--layout", choices=["aos", "split"], default="aos",
+    ap.add_argument("--layout", choices=["aos", "split"], default="split",
                     help="HBM layout of share vectors: arkworks AoS (drop-in) or engine-native split columns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=18, help="CPU baseline sample size (gates)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--sets", type=int, default=2, help="independent workload sets rotated step by step, so that no input line of step s "
+                    "can still be cached (256 MiB Infinity Cache) when step s+1 runs; 1 = reuse the same buffers every step")
+    ap.add_argument("--chunks", type=int, default=1, help="split each step's batch into this many gate ranges, each run K1,K1,K3,K3 "
+                    "(shortens the K1->K3 reuse distance so d||e and a.s/b.s re-reads can hit the 256 MiB Infinity Cache)")
     return ap.parse_args()
 
 
@@ -114,31 +118,42 @@ def build_workload(eng, n, seed, layout):
     return parties, (x, y, key)
 
 
-def prepare_step(eng, n, parties, layout):
-    """Pre-bind the four launches of a step (arguments marshalled once; buffers are fixed for the whole run)."""
+def prepare_step(eng, n, parties, layout, chunks=1):
+    """Pre-bind the launches of a step (arguments marshalled once; buffers are fixed for the whole run).
+    With chunks > 1 the batch is cut into gate ranges and each range runs K1(P0), K1(P1), K3(P0), K3(P1)."""
     S = lambda v: ("size", v)
+    P = lambda t: t.data_ptr()
     calls = []
-    for p in parties:   # K1 for party 0, then party 1
-        if layout == "aos":
-            calls.append(eng.prepare("beaver_mask", S(n), p.x, p.y, p.a, p.b, p.de))
-        else:
-            calls.append(eng.prepare("beaver_mask_v", S(n), p.x, S(4), p.y, S(4), p.a, S(4), p.b, S(4), p.de))
-    for p, peer in ((parties[0], parties[1]), (parties[1], parties[0])):   # K2+K3; the "network" = reading the peer's d||e
-        if layout == "aos":
-            calls.append(eng.prepare("beaver_finish_fused", S(n), ("int", p.id), ("key", p.key), p.de, peer.de, p.a, p.b, p.c, p.out))
-        else:
-            col = 4 * n * 8  # byte offset of the mac column
-            P = lambda t: t.data_ptr()
-            calls.append(eng.prepare("beaver_finish_fused_v", S(n), ("int", p.id), ("key", p.key), p.de, peer.de,
-                                     P(p.a), P(p.a) + col, S(4), P(p.b), P(p.b) + col, S(4), P(p.c), P(p.c) + col, S(4),
-                                     P(p.out), P(p.out) + col, S(4)))
+    m = n // chunks
+    assert m * chunks == n
+    for c in range(chunks):
+        lo = c * m
+        o8, o4 = lo * 64, lo * 32          # byte offsets of gate `lo` in AoS records / 32-byte columns
+        de_off = c * 2 * m * 32             # each chunk owns a contiguous d||e block of 2m scalars
+        for p in parties:
+            if layout == "aos":
+                calls.append(eng.prepare("beaver_mask", S(m), P(p.x) + o8, P(p.y) + o8, P(p.a) + o8, P(p.b) + o8, P(p.de) + de_off))
+            else:
+                calls.append(eng.prepare("beaver_mask_v", S(m), P(p.x) + o4, S(4), P(p.y) + o4, S(4), P(p.a) + o4, S(4), P(p.b) + o4, S(4),
+                                         P(p.de) + de_off))
+        for p, peer in ((parties[0], parties[1]), (parties[1], parties[0])):   # the "network" = reading the peer's d||e
+            if layout == "aos":
+                calls.append(eng.prepare("beaver_finish_fused", S(m), ("int", p.id), ("key", p.key), P(p.de) + de_off, P(peer.de) + de_off,
+                                         P(p.a) + o8, P(p.b) + o8, P(p.c) + o8, P(p.out) + o8))
+            else:
+                col = 4 * n * 8  # byte offset of the mac column
+                calls.append(eng.prepare("beaver_finish_fused_v", S(m), ("int", p.id), ("key", p.key), P(p.de) + de_off, P(peer.de) + de_off,
+                                         P(p.a) + o4, P(p.a) + col + o4, S(4), P(p.b) + o4, P(p.b) + col + o4, S(4),
+                                         P(p.c) + o4, P(p.c) + col + o4, S(4), P(p.out) + o4, P(p.out) + col + o4, S(4)))
     return calls
 
 
 def step(calls, evs=None):
-    if evs is None:
+    if evs is None or len(calls) != 4:
+        if evs is not None: evs[0].record()
         for c in calls:
             c()
+        if evs is not None: evs[4].record()
         return
     evs[0].record()
     for i, c in enumerate(calls):
@@ -243,21 +258,22 @@ def main():
     pkg = importlib.import_module("ark-mpc_amd")
     eng = pkg.Engine(FID, device=dev, host_buffers=False, stream=torch.cuda.current_stream().cuda_stream)
     n = 1 << args.log2n
-    parties, truth = build_workload(eng, n, seed=0xA11CE002 + rank, layout=args.layout)
+    sets = [build_workload(eng, n, seed=0xA11CE002 + rank + 7919 * k, layout=args.layout) for k in range(max(1, args.sets))]
+    parties, truth = sets[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    calls = prepare_step(eng, n, parties, args.layout)
-    for _ in range(args.warmup):
-        step(calls)
+    call_sets = [prepare_step(eng, n, ps, args.layout, args.chunks) for ps, _ in sets]
+    for w in range(args.warmup):
+        step(call_sets[w % len(call_sets)])
     barrier()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(calls, evs[s])
+        step(call_sets[s % len(call_sets)], evs[s])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -265,12 +281,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # per-kernel durations from the in-stream HIP events of the timed region
-    seg = np.array([[evs[s][i].elapsed_time(evs[s][i + 1]) for i in range(4)] for s in range(args.steps)])  # ms
-    k1_ms = float(seg[:, :2].mean())
-    k3_ms = float(seg[:, 2:].mean())
+    if args.chunks == 1:
+        seg = np.array([[evs[s][i].elapsed_time(evs[s][i + 1]) for i in range(4)] for s in range(args.steps)])  # ms
+        k1_ms = float(seg[:, :2].mean())
+        k3_ms = float(seg[:, 2:].mean())
+    else:
+        k1_ms = k3_ms = float("nan")
     dev_ms_per_step = float(np.mean([evs[s][0].elapsed_time(evs[s][4]) for s in range(args.steps)]))
 
-    ok = True if args.no_check else check_results(eng, n, parties, truth, args.layout)
+    ok = True if args.no_check else all(check_results(eng, n, ps, tr, args.layout) for ps, tr in sets[:min(len(sets), args.steps)])
 
     out = None
     if rank == 0:
@@ -283,7 +302,8 @@ def main():
             "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": "2^%d AuthenticatedScalar Beaver muls over BN254 Fr per GPU per step, two parties in-process, "
                                    "mock net (BASELINE.json configs[1])" % args.log2n,
-                       "gates_per_gpu": n, "field": "bn254_fr", "layout": args.layout, "launches_per_step": 4,
+                       "gates_per_gpu": n, "field": "bn254_fr", "layout": args.layout, "launches_per_step": 4 * args.chunks,
+                       "workload_sets_rotated": len(sets),
                        "parallelism": "gate-range sharding, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_beaver_finish<0,true> (K2+K3 fused)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,

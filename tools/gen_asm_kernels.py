@@ -36,14 +36,19 @@ M32 = 0xFFFFFFFF
 R = 1 << 256
 JUNK = "s[60:61]"     # carry-out sink of v_mad_u64_u32 (never read)
 S_INV = "s62"         # -p^{-1} mod 2^32
-CLOBBER_SGPRS = ["s60", "s61", "s62"]
+CLOBBER_SGPRS = ["s60", "s61", "s62", "s64", "s65"]
 
 
 class Ins:
-    __slots__ = ("text", "op", "args", "srd", "swr")
+    """One instruction: assembler text + emulator op + every register it reads / writes (for the scheduler).
+    srd / swr are the SGPR-class registers (carry / mask) subject to hazard H1."""
+    __slots__ = ("text", "op", "args", "srd", "swr", "rd", "wr", "idx")
 
-    def __init__(self, text, op, args=(), srd=(), swr=()):
+    def __init__(self, text, op, args=(), srd=(), swr=(), rd=(), wr=()):
         self.text, self.op, self.args, self.srd, self.swr = text, op, args, tuple(srd), tuple(swr)
+        self.rd = set(rd) | set(srd)
+        self.wr = set(wr) | set(swr)
+        self.idx = -1
 
 
 def pr(pair):
@@ -64,16 +69,61 @@ def src(x):
     return x
 
 
-# ---- instruction constructors (VCC is the only carry register used) -----------------------------
-def i_mov(d, s): return Ins("v_mov_b32_e32 %s, %s" % (d, src(s)), "mov", (d, s))
-def i_mad(d, a, b, c): return Ins("v_mad_u64_u32 %s, %s, %s, %s, %s" % (pr(d), JUNK, a, b, "0" if c == 0 else pr(c)), "mad", (d, a, b, c))
-def i_mul_lo(d, a, b): return Ins("v_mul_lo_u32 %s, %s, %s" % (d, a, b), "mul_lo", (d, a, b))
-def i_addco(d, a, b): return Ins("v_add_co_u32_e32 %s, vcc, %s, %s" % (d, src(a), b), "addco", (d, a, b), swr=("vcc",))
-def i_addc(d, a, b): return Ins("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (d, src(a), b), "addc", (d, a, b), srd=("vcc",), swr=("vcc",))
-def i_subco(d, a, b): return Ins("v_sub_co_u32_e32 %s, vcc, %s, %s" % (d, src(a), b), "subco", (d, a, b), swr=("vcc",))
-def i_subb(d, a, b): return Ins("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (d, src(a), b), "subb", (d, a, b), srd=("vcc",), swr=("vcc",))
-def i_cnd(d, f, t): return Ins("v_cndmask_b32_e32 %s, %s, %s, vcc" % (d, f, t), "cnd", (d, f, t), srd=("vcc",))   # vcc ? t : f
-def i_and(d, a, b): return Ins("v_and_b32_e32 %s, %s, %s" % (d, src(a), b), "and", (d, a, b))
+def regs_of(*xs):
+    """register names among operands (ints are inline constants / literals)"""
+    out = []
+    for x in xs:
+        if isinstance(x, tuple):
+            out += list(x)
+        elif isinstance(x, str):
+            out.append(x)
+    return out
+
+
+CY2 = "s[64:65]"      # second carry register (VOP3 encodings); VCC is the first
+
+
+def _cyfmt(cy):
+    return cy
+
+
+# ---- instruction constructors.  cy = "vcc" (VOP2 encodings) or an SGPR pair (VOP3 encodings) -------------
+def i_mov(d, s): return Ins("v_mov_b32_e32 %s, %s" % (d, src(s)), "mov", (d, s), rd=regs_of(s), wr=[d])
+def i_mad(d, a, b, c):
+    return Ins("v_mad_u64_u32 %s, %s, %s, %s, %s" % (pr(d), JUNK, a, b, "0" if c == 0 else pr(c)), "mad", (d, a, b, c),
+               rd=regs_of(a, b, c if c != 0 else None), wr=list(d))
+def i_mul_lo(d, a, b): return Ins("v_mul_lo_u32 %s, %s, %s" % (d, a, b), "mul_lo", (d, a, b), rd=regs_of(a, b), wr=[d])
+def i_addco(d, a, b, cy="vcc"):
+    t = "v_add_co_u32_e32 %s, vcc, %s, %s" % (d, src(a), b) if cy == "vcc" else "v_add_co_u32_e64 %s, %s, %s, %s" % (d, cy, src(a), b)
+    return Ins(t, "addco", (d, a, b, cy), swr=(cy,), rd=regs_of(a, b), wr=[d])
+def i_addc(d, a, b, cy="vcc"):
+    t = "v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (d, src(a), b) if cy == "vcc" else "v_addc_co_u32_e64 %s, %s, %s, %s, %s" % (d, cy, src(a), b, cy)
+    return Ins(t, "addc", (d, a, b, cy), srd=(cy,), swr=(cy,), rd=regs_of(a, b), wr=[d])
+def i_subco(d, a, b, cy="vcc"):
+    t = "v_sub_co_u32_e32 %s, vcc, %s, %s" % (d, src(a), b) if cy == "vcc" else "v_sub_co_u32_e64 %s, %s, %s, %s" % (d, cy, src(a), b)
+    return Ins(t, "subco", (d, a, b, cy), swr=(cy,), rd=regs_of(a, b), wr=[d])
+def i_subb(d, a, b, cy="vcc"):
+    t = "v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (d, src(a), b) if cy == "vcc" else "v_subb_co_u32_e64 %s, %s, %s, %s, %s" % (d, cy, src(a), b, cy)
+    return Ins(t, "subb", (d, a, b, cy), srd=(cy,), swr=(cy,), rd=regs_of(a, b), wr=[d])
+def i_cnd(d, f, t, cy="vcc"):   # cy ? t : f
+    tx = "v_cndmask_b32_e32 %s, %s, %s, vcc" % (d, f, t) if cy == "vcc" else "v_cndmask_b32_e64 %s, %s, %s, %s" % (d, f, t, cy)
+    return Ins(tx, "cnd", (d, f, t, cy), srd=(cy,), rd=regs_of(f, t), wr=[d])
+def i_and(d, a, b): return Ins("v_and_b32_e32 %s, %s, %s" % (d, src(a), b), "and", (d, a, b), rd=regs_of(a, b), wr=[d])
+# Streams that are read / written exactly once per batch get the non-temporal hint in the split-column layout, so they
+# do not displace the lines K3 re-reads after K1 (own/peer d||e, a.s, b.s) from the 256 MiB Infinity Cache.
+# Measured on MI355X (2^20 gates, split layout): K3 80 -> 69 us.  In the AoS layout share and MAC halves share one
+# 64-byte line and the hint hurts, so the AoS variant carries none.
+NT_SPLIT = {"c_s", "c_m", "out_s", "out_m", "a_m", "b_m"}
+NT_BASES = set()
+
+
+def i_load(regs, off, base, half):
+    return Ins("global_load_dwordx4 %s, %%[%s], %%[%s]%s%s" % (quad(regs), off, base, " offset:16" if half else "", " nt" if base in NT_BASES else ""), "load", (regs, base, half),
+               rd=["MEMORDER"], wr=list(regs) + ["MEMORDER"])
+def i_store(regs, off, base, half):
+    return Ins("global_store_dwordx4 %%[%s], %s, %%[%s]%s%s" % (off, quad(regs), base, " offset:16" if half else "", " nt" if base in NT_BASES else ""), "store", (regs, base, half),
+               rd=list(regs) + ["MEMORDER"], wr=["MEMORDER"])
+def i_wait(n): return Ins("s_waitcnt vmcnt(%d)" % n, "wait", (n,))
 
 
 class Emitter:
@@ -100,6 +150,60 @@ class Emitter:
     def emit_all(self, seq):
         for i in seq:
             self.emit(i)
+
+    def schedule(self, seq, window=64):
+        """Dependency-aware list scheduling of a straight-line segment: any order that respects register RAW / WAR /
+        WAW (VGPRs and carry registers alike) is correct on an in-order-issue machine with interlocked VGPR
+        dependencies, so the earliest (in program order) ready instruction that needs no H1 wait states is issued;
+        s_nop is emitted only when every ready instruction inside the look-ahead window would violate H1."""
+        n = len(seq)
+        succ = [[] for _ in range(n)]
+        indeg = [0] * n
+        last_w, readers = {}, {}
+        for i, ins in enumerate(seq):
+            deps = set()
+            for r in ins.rd:
+                if r in last_w:
+                    deps.add(last_w[r])
+            for r in ins.wr:
+                if r in last_w:
+                    deps.add(last_w[r])
+                for j in readers.get(r, ()):
+                    deps.add(j)
+            deps.discard(i)
+            for j in deps:
+                succ[j].append(i)
+            indeg[i] = len(deps)
+            for r in ins.wr:
+                last_w[r] = i
+                readers[r] = []
+            for r in ins.rd:
+                readers.setdefault(r, []).append(i)
+        done = [False] * n
+        lowest = 0
+        remaining = n
+        while remaining:
+            while done[lowest]:
+                lowest += 1
+            best, best_need = None, None
+            for i in range(lowest, min(n, lowest + window)):
+                if done[i] or indeg[i]:
+                    continue
+                need = 0
+                for r in seq[i].srd:
+                    if r in self.lastw:
+                        need = max(need, self.lastw[r] + 3 - self.slot)
+                if need <= 0:
+                    best, best_need = i, 0
+                    break
+                if best is None or need < best_need:
+                    best, best_need = i, need
+            assert best is not None
+            self.emit(seq[best])
+            done[best] = True
+            remaining -= 1
+            for j in succ[best]:
+                indeg[j] -= 1
 
     def raw(self, text, op="raw", args=()):
         self.emit(Ins(text, op, args))
@@ -137,91 +241,61 @@ def t_bounds(p, nprod):
     return before, t
 
 
-def montmul_sum_rows(p, prods, T, Tz, q, m, P):
-    """Rows of the CIOS evaluation of REDC(sum_k a_k*b_k).  T[j] is the low half of the pair Tz[j] whose high
-    half holds 0 for the whole kernel.  Each row = (pre, mads[8], chain); chain element i (0-based) is the
-    instruction after which the NEXT row's mad_i may be issued (it has produced T_i and released q_i)."""
+def montmul_sum_seq(p, prods, T, Tz, q, m, P, row0=0):
+    """Straight-line CIOS evaluation of REDC(sum_k a_k*b_k) (before the final conditional subtraction).
+    T[j] is the low half of the pair Tz[j] whose high half holds 0 for the whole kernel.  Rows alternate between
+    the two carry registers so that the scheduler can keep two carry chains in flight (next row's chain starts
+    while this row's is still running) and hazard H1 is met by useful instructions."""
     nprod = len(prods)
     before, _ = t_bounds(p, nprod)
     assert before < (1 << 288), "accumulator needs a 10th limb for this field / product count"
-    rows = []
+    seq = []
     first = True
+    row = row0
     for r in range(8):
         for (a, b) in prods:
-            mads = [i_mad(q[j], a[j], b[r], 0 if first else Tz[j]) for j in range(8)]
-            chain = [i_mov(T[0], q[0][0]), i_addco(T[1], q[1][0], q[0][1])]
-            chain += [i_addc(T[j], q[j][0], q[j - 1][1]) for j in range(2, 8)]
-            chain += [i_addc(T[8], 0 if first else T[8], q[7][1])]
-            # release points: next.mad_j needs T_j (chain[j]) and q_j free (read by chain[j], chain[j+1])
-            rel = [min(j + 1, 8) for j in range(8)]
-            rows.append(("mul", [], mads, chain, rel, 0))
+            cy = "vcc" if row % 2 == 0 else CY2
+            row += 1
+            seq += [i_mad(q[j], a[j], b[r], 0 if first else Tz[j]) for j in range(8)]
+            seq += [i_mov(T[0], q[0][0]), i_addco(T[1], q[1][0], q[0][1], cy)]
+            seq += [i_addc(T[j], q[j][0], q[j - 1][1], cy) for j in range(2, 8)]
+            seq += [i_addc(T[8], 0 if first else T[8], q[7][1], cy)]
             first = False
-        pre = [i_mul_lo(m, T[0], S_INV)]
-        mads = [i_mad(q[j], m, P[j], Tz[j]) for j in range(8)]
-        chain = [i_addco(T[0], q[1][0], q[0][1])]
-        chain += [i_addc(T[j - 1], q[j][0], q[j - 1][1]) for j in range(2, 8)]
-        chain += [i_addc(T[7], T[8], q[7][1]), i_addc(T[8], 0, Tz[8][1])]   # Tz[8][1] holds 0 (VOP2 src1 must be a VGPR)
-        # chain[i] writes T_i (i = 0..7); q_j is read by chain[j-1] (lo) and chain[j] (hi)
-        rel = [min(j, 7) for j in range(8)]
-        rows.append(("red", pre, mads, chain, rel, 0))
-    return rows
+        cy = "vcc" if row % 2 == 0 else CY2
+        row += 1
+        seq += [i_mul_lo(m, T[0], S_INV)]
+        seq += [i_mad(q[j], m, P[j], Tz[j]) for j in range(8)]
+        seq += [i_addco(T[0], q[1][0], q[0][1], cy)]
+        seq += [i_addc(T[j - 1], q[j][0], q[j - 1][1], cy) for j in range(2, 8)]
+        seq += [i_addc(T[7], T[8], q[7][1], cy), i_addc(T[8], 0, Tz[8][1], cy)]   # Tz[8][1] holds 0 (src1 must be a VGPR)
+    return seq, row
 
 
-def pipeline_rows(rows):
-    """Flatten rows, issuing row k+1's multiplies inside row k's carry chain (next.mad_j right after the
-    chain element that releases it).  `pre` of the next row (the m = T0*inv multiply) needs the new T_0."""
-    seq = []
-    seq += rows[0][1] + rows[0][2]
-    for k, row in enumerate(rows):
-        chain, rel = row[3], row[4]
-        nxt = rows[k + 1] if k + 1 < len(rows) else None
-        if nxt is None:
-            seq += chain
-            break
-        npre, nmads, nrel_by_mad = nxt[1], nxt[2], rel
-        pending = list(range(8))
-        pre_done = False
-        for ci, c in enumerate(chain):
-            seq.append(c)
-            if not pre_done and ci >= 0:
-                seq += npre          # T_0 is produced by chain[0] in both row kinds
-                pre_done = True
-            while pending and nrel_by_mad[pending[0]] <= ci:
-                seq.append(nmads[pending.pop(0)])
-                break                # at most one multiply per chain link keeps the links evenly spaced
-        for j in pending:
-            seq.append(nmads[j])
-    return seq
-
-
-def cond_sub_final(p, nprod, T, P, tmp, out):
+def cond_sub_final(p, nprod, T, P, tmp, out, cy="vcc"):
     """T (9 limbs) < p*(1 + nprod*p/R) + 1 -> canonical `out` by K conditional subtractions."""
     bound = (nprod * (p - 1) * (p - 1) + (R - 1) * p) // R + 1
     K = (bound + p - 1) // p - 1
-    nine = bound >= R
+    assert bound < R, "9-limb final subtraction not implemented"
     seq = []
     cur = T
     for k in range(K):
         last = k == K - 1
         dst = out if last else T
-        seq.append(i_subco(tmp[0], cur[0], P[0]))
-        seq += [i_subb(tmp[j], cur[j], P[j]) for j in range(1, 8)]
-        if nine:
-            seq.append(i_subb(tmp[8], cur[8], "v_zero"))
-        seq += [i_cnd(dst[j], tmp[j], cur[j]) for j in range(8)]          # borrow -> value < p -> keep cur
-        if nine and not last:
-            seq.append(i_cnd(T[8], tmp[8], cur[8]))
+        seq.append(i_subco(tmp[0], cur[0], P[0], cy))
+        seq += [i_subb(tmp[j], cur[j], P[j], cy) for j in range(1, 8)]
+        seq += [i_cnd(dst[j], tmp[j], cur[j], cy) for j in range(8)]          # borrow -> value < p -> keep cur
         cur = dst
     if K == 0:
         seq += [i_mov(out[j], T[j]) for j in range(8)]
     return seq
 
 
-def fe_add_seq(P, a, b, out, tmp):
-    """out = a + b mod p for canonical a, b (p < 2^255: no 257th bit). `out` may alias a or b; tmp may not."""
-    seq = [i_addco(tmp[0], a[0], b[0])] + [i_addc(tmp[j], a[j], b[j]) for j in range(1, 8)]
-    seq += [i_subco(out[0], tmp[0], P[0])] + [i_subb(out[j], tmp[j], P[j]) for j in range(1, 8)]
-    seq += [i_cnd(out[j], out[j], tmp[j]) for j in range(8)]
+def fe_add_seq(P, a, b, out, tmp, cy_add="vcc", cy_sub=CY2):
+    """out = a + b mod p for canonical a, b (p < 2^255: no 257th bit). `out` may alias a or b; tmp may not.
+    The add chain and the subtract chain use different carry registers so they overlap (skewed by one limb)."""
+    seq = [i_addco(tmp[0], a[0], b[0], cy_add)] + [i_addc(tmp[j], a[j], b[j], cy_add) for j in range(1, 8)]
+    seq += [i_subco(out[0], tmp[0], P[0], cy_sub)] + [i_subb(out[j], tmp[j], P[j], cy_sub) for j in range(1, 8)]
+    seq += [i_cnd(out[j], out[j], tmp[j], cy_sub) for j in range(8)]
     return seq
 
 
@@ -230,7 +304,7 @@ def fe_add_seq(P, a, b, out, tmp):
 # ------------------------------------------------------------------------------------------------
 class Emu:
     def __init__(self):
-        self.v, self.s, self.vcc = {}, {}, 0
+        self.v, self.s, self.c = {}, {}, {}
 
     def rd(self, x):
         if isinstance(x, int):
@@ -254,13 +328,13 @@ class Emu:
             elif op == "mul_lo":
                 self.v[a[0]] = (self.rd(a[1]) * self.rd(a[2])) & M32
             elif op in ("addco", "addc"):
-                r = self.rd(a[1]) + self.rd(a[2]) + (self.vcc if op == "addc" else 0)
-                self.v[a[0]], self.vcc = r & M32, r >> 32
+                r = self.rd(a[1]) + self.rd(a[2]) + (self.c[a[3]] if op == "addc" else 0)
+                self.v[a[0]], self.c[a[3]] = r & M32, r >> 32
             elif op in ("subco", "subb"):
-                r = self.rd(a[1]) - self.rd(a[2]) - (self.vcc if op == "subb" else 0)
-                self.v[a[0]], self.vcc = r & M32, 1 if r < 0 else 0
+                r = self.rd(a[1]) - self.rd(a[2]) - (self.c[a[3]] if op == "subb" else 0)
+                self.v[a[0]], self.c[a[3]] = r & M32, 1 if r < 0 else 0
             elif op == "cnd":
-                self.v[a[0]] = self.rd(a[2]) if self.vcc else self.rd(a[1])
+                self.v[a[0]] = self.rd(a[2]) if self.c[a[3]] else self.rd(a[1])
             elif op == "and":
                 self.v[a[0]] = self.rd(a[1]) & self.rd(a[2])
             elif op == "load":
@@ -289,7 +363,9 @@ class Emu:
 KEY_S = ["%%[k%d]" % i for i in range(8)]
 
 
-def build_beaver_finish(p, first_vgpr=8, key_names=None):
+def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
+    global NT_BASES
+    NT_BASES = NT_SPLIT if nt else set()
     """Emit the fused combine + finish body for modulus p.  Returns (Emitter, regmap)."""
     key = key_names or ["%[k" + str(i) + "]" for i in range(8)]
     rg = Regs(first_vgpr)
@@ -306,56 +382,52 @@ def build_beaver_finish(p, first_vgpr=8, key_names=None):
     nv = rg.next
     inv = (-pow(p, -1, 1 << 32)) & M32
     E = Emitter()
+    run = E.schedule if sched else E.emit_all
     E.raw("s_nop 1")                                                  # H1 guard for SGPR inputs written by VALU
     E.raw("s_mov_b32 %s, 0x%08x" % (S_INV, inv), "smov", (S_INV, inv))
     # ---- all first-wave loads up front (16 x dwordx4), in the order they are needed
-    loads = [(dm, "my_d"), (dp, "peer_d"), (em, "my_e"), (ep, "peer_e")]
-    cols = [(bs, "b_s"), (as_, "a_s"), (bm, "b_m"), (am, "a_m")]
-    for regs, nm in loads:
+    for regs, nm in ((dm, "my_d"), (dp, "peer_d"), (em, "my_e"), (ep, "peer_e")):
         for h in (0, 1):
-            E.emit(Ins("global_load_dwordx4 %s, %%[off_de], %%[%s]%s" % (quad(regs[4 * h:4 * h + 4]), nm, " offset:16" if h else ""), "load", (regs[4 * h:4 * h + 4], nm, h)))
-    for regs, nm in cols:
+            E.emit(i_load(regs[4 * h:4 * h + 4], "off_de", nm, h))
+    for regs, nm in ((bs, "b_s"), (as_, "a_s"), (bm, "b_m"), (am, "a_m")):
         for h in (0, 1):
-            E.emit(Ins("global_load_dwordx4 %s, %%[off_col], %%[%s]%s" % (quad(regs[4 * h:4 * h + 4]), nm, " offset:16" if h else ""), "load", (regs[4 * h:4 * h + 4], nm, h)))
+            E.emit(i_load(regs[4 * h:4 * h + 4], "off_col", nm, h))
     # constants while the loads fly
     for j in range(8):
         E.emit(i_mov(P[j], (p >> (32 * j)) & M32))
     for t in Tz:
         E.emit(i_mov(t[1], 0))
-    # ---- K2: d = my_d + peer_d, e = my_e + peer_e
-    E.raw("s_waitcnt vmcnt(8)", "wait")
-    E.emit_all(fe_add_seq(P, dm, dp, dm, qflat))
-    E.emit_all(fe_add_seq(P, em, ep, em, qflat))
+    # ---- segment 1: K2 (d = my_d + peer_d, e = my_e + peer_e) and de = d*e
+    E.emit(i_wait(8))
     d, e, de = dm, em, dp
-    # ---- de = d*e
-    E.emit_all(pipeline_rows(montmul_sum_rows(p, [(d, e)], T, Tz, q, m, P)))
-    E.emit_all(cond_sub_final(p, 1, T, P, qflat, de))
-    # ---- share' = d*b.s + e*a.s  (one reduction)
-    E.raw("s_waitcnt vmcnt(4)", "wait")
-    E.emit_all(pipeline_rows(montmul_sum_rows(p, [(d, bs), (e, as_)], T, Tz, q, m, P)))
+    seg = fe_add_seq(P, dm, dp, dm, qflat[:8]) + fe_add_seq(P, em, ep, em, qflat[8:])
+    mm, row = montmul_sum_seq(p, [(d, e)], T, Tz, q, m, P)
+    seg += mm + cond_sub_final(p, 1, T, P, qflat, de)
+    run(seg)
+    # ---- segment 2: share' = d*b.s + e*a.s (one reduction); then c is loaded over the dead b.s / a.s registers
+    E.emit(i_wait(4))
     rs = ep
-    E.emit_all(cond_sub_final(p, 2, T, P, qflat, rs))
-    # ---- c is loaded late, over the now-dead b.s / a.s registers; latency hides under the MAC rows
+    mm, row = montmul_sum_seq(p, [(d, bs), (e, as_)], T, Tz, q, m, P, row)
+    seg = mm + cond_sub_final(p, 2, T, P, qflat, rs)
     cs, cm = bs, as_
     for regs, nm in ((cs, "c_s"), (cm, "c_m")):
         for h in (0, 1):
-            E.emit(Ins("global_load_dwordx4 %s, %%[off_col], %%[%s]%s" % (quad(regs[4 * h:4 * h + 4]), nm, " offset:16" if h else ""), "load", (regs[4 * h:4 * h + 4], nm, h)))
-    # ---- mac' = d*b.m + e*a.m + key*de  (one reduction)
-    E.raw("s_waitcnt vmcnt(4)", "wait")
-    E.emit_all(pipeline_rows(montmul_sum_rows(p, [(d, bm), (e, am), (key, de)], T, Tz, q, m, P)))
+            seg.append(i_load(regs[4 * h:4 * h + 4], "off_col", nm, h))
+    run(seg)
+    # ---- segment 3: mac' = d*b.m + e*a.m + key*de (one reduction); the c loads' latency hides under these rows
+    E.emit(i_wait(4))
     rm = bm
-    E.emit_all(cond_sub_final(p, 3, T, P, qflat, rm))
-    # ---- share = share' + c.s + (PARTY0 ? de : 0) ; mac = mac' + c.m
-    E.raw("s_waitcnt vmcnt(0)", "wait")
+    mm, row = montmul_sum_seq(p, [(d, bm), (e, am), (key, de)], T, Tz, q, m, P, row)
+    run(mm + cond_sub_final(p, 3, T, P, qflat, rm))
+    # ---- segment 4: share = share' + c.s + (PARTY0 ? de : 0) ; mac = mac' + c.m ; stores
+    E.emit(i_wait(0))
     dem = am
-    for j in range(8):
-        E.emit(i_and(dem[j], "%[mask]", de[j]))
-    E.emit_all(fe_add_seq(P, rs, cs, rs, qflat))
-    E.emit_all(fe_add_seq(P, rs, dem, rs, qflat))
-    E.emit_all(fe_add_seq(P, rm, cm, rm, qflat))
+    seg = [i_and(dem[j], "%[mask]", de[j]) for j in range(8)]
+    seg += fe_add_seq(P, rs, cs, rs, qflat[:8]) + fe_add_seq(P, rm, cm, rm, qflat[8:]) + fe_add_seq(P, rs, dem, rs, qflat[:8])
     for regs, nm in ((rs, "out_s"), (rm, "out_m")):
         for h in (0, 1):
-            E.emit(Ins("global_store_dwordx4 %%[off_out], %s, %%[%s]%s" % (quad(regs[4 * h:4 * h + 4]), nm, " offset:16" if h else ""), "store", (regs[4 * h:4 * h + 4], nm, h)))
+            seg.append(i_store(regs[4 * h:4 * h + 4], "off_out", nm, h))
+    run(seg)
     regmap = dict(P=P, dm=dm, dp=dp, em=em, ep=ep, bs=bs, as_=as_, bm=bm, am=am, rs=rs, rm=rm, first=first_vgpr, nv=nv)
     return E, regmap
 
@@ -376,6 +448,7 @@ def selftest_finish(p, trials=40, seed=1):
             for i in range(8):
                 em.s["s%d" % (70 + i)] = (key >> (32 * i)) & M32
             em.s["%[mask]"] = M32 if party == 0 else 0
+            em.s["MEMORDER"] = 0
             em.s[S_INV] = (-pow(p, -1, 1 << 32)) & M32
             em.v["v_zero"] = 0
             em.run(E.order)
@@ -399,37 +472,39 @@ def emit_header(path):
     out = []
     out.append("// GENERATED by tools/gen_asm_kernels.py -- do not edit.  Hand-scheduled gfx950 bodies; see the generator for")
     out.append("// the hazard rules (H1-H4), the register map and the single-lane emulator that validates each stream.")
+    out.append("// beaver_finish_asm<F, NT>: NT = 1 adds non-temporal hints on once-streamed data (split-column layout).")
     out.append("#pragma once")
     stats = []
     for fid, (name, p) in enumerate(FIELDS):
         try:
             selftest_finish(p, trials=16, seed=fid)           # emulator check (uses placeholder SGPR names for the key)
-            E, mp = build_beaver_finish(p)                      # same stream with the asm operand names %[k0]..%[k7]
         except AssertionError as ex:
             if "10th limb" in str(ex):
                 out.append("// %s: lazy 3-product reduction needs a 10th accumulator limb -> no asm body, C++ kernel is used" % name)
                 out.append("template <> struct HasAsmFinish<%d> { static constexpr bool value = false; };" % fid)
                 continue
             raise
-        nvalu = sum(1 for i in E.order if i.op in ("mov", "mad", "mul_lo", "addco", "addc", "subco", "subb", "cnd", "and"))
-        nmad = sum(1 for i in E.order if i.op == "mad")
-        stats.append((name, nvalu, nmad, E.nops, mp["nv"]))
-        clob = ['"memory"', '"vcc"'] + ['"%s"' % s for s in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mp["first"], mp["nv"])]
-        out.append("// %s: %d VALU (%d v_mad_u64_u32), %d H1 wait states, VGPRs v%d..v%d" % (name, nvalu, nmad, E.nops, mp["first"], mp["nv"] - 1))
         out.append("template <> struct HasAsmFinish<%d> { static constexpr bool value = true; };" % fid)
-        out.append("template <> __device__ __forceinline__ void beaver_finish_asm<%d>(u32 off_de, u32 off_col, u32 off_out, const u64* my_d, const u64* my_e," % fid)
-        out.append("        const u64* peer_d, const u64* peer_e, const u64* a_s, const u64* a_m, const u64* b_s, const u64* b_m, const u64* c_s, const u64* c_m,")
-        out.append("        u64* out_s, u64* out_m, const Fe& key, u32 mask) {")
-        out.append("    asm volatile(")
-        text = [ln.replace("v_zero", "v%d" % (mp["nv"])) for ln in E.lines]
-        out.append(c_string(text))
-        out.append("        :")
-        out.append('        : [off_de] "v"(off_de), [off_col] "v"(off_col), [off_out] "v"(off_out), [my_d] "s"(my_d), [my_e] "s"(my_e),')
-        out.append('          [peer_d] "s"(peer_d), [peer_e] "s"(peer_e), [a_s] "s"(a_s), [a_m] "s"(a_m), [b_s] "s"(b_s), [b_m] "s"(b_m),')
-        out.append('          [c_s] "s"(c_s), [c_m] "s"(c_m), [out_s] "s"(out_s), [out_m] "s"(out_m), [mask] "s"(mask),')
-        out.append("          " + ", ".join('[k%d] "s"(key.v[%d])' % (i, i) for i in range(8)))
-        out.append("        : " + ", ".join(clob) + ");")
-        out.append("}")
+        for nt in (0, 1):
+            E, mp = build_beaver_finish(p, nt=bool(nt))        # same stream with the asm operand names %[k0]..%[k7]
+            nvalu = sum(1 for i in E.order if i.op in ("mov", "mad", "mul_lo", "addco", "addc", "subco", "subb", "cnd", "and"))
+            nmad = sum(1 for i in E.order if i.op == "mad")
+            if nt == 0:
+                stats.append((name, nvalu, nmad, E.nops, mp["nv"]))
+            clob = ['"memory"', '"vcc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mp["first"], mp["nv"])]
+            out.append("// %s (NT=%d): %d VALU (%d v_mad_u64_u32), %d H1 wait states, VGPRs v%d..v%d" % (name, nt, nvalu, nmad, E.nops, mp["first"], mp["nv"] - 1))
+            out.append("template <> __device__ __forceinline__ void beaver_finish_asm<%d, %d>(u32 off_de, u32 off_col, u32 off_out, const u64* my_d, const u64* my_e," % (fid, nt))
+            out.append("        const u64* peer_d, const u64* peer_e, const u64* a_s, const u64* a_m, const u64* b_s, const u64* b_m, const u64* c_s, const u64* c_m,")
+            out.append("        u64* out_s, u64* out_m, const Fe& key, u32 mask) {")
+            out.append("    asm volatile(")
+            out.append(c_string(E.lines))
+            out.append("        :")
+            out.append('        : [off_de] "v"(off_de), [off_col] "v"(off_col), [off_out] "v"(off_out), [my_d] "s"(my_d), [my_e] "s"(my_e),')
+            out.append('          [peer_d] "s"(peer_d), [peer_e] "s"(peer_e), [a_s] "s"(a_s), [a_m] "s"(a_m), [b_s] "s"(b_s), [b_m] "s"(b_m),')
+            out.append('          [c_s] "s"(c_s), [c_m] "s"(c_m), [out_s] "s"(out_s), [out_m] "s"(out_m), [mask] "s"(mask),')
+            out.append("          " + ", ".join('[k%d] "s"(key.v[%d])' % (i, i) for i in range(8)))
+            out.append("        : " + ", ".join(clob) + ");")
+            out.append("}")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
     return stats
