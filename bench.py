@@ -296,6 +296,10 @@ def main():
         gates = n * world * args.steps
         value = gates / elapsed
         ach = n * ALG_BYTES_K3 / (k3_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per K3 launch from the committed PMC passes (same workload), see profiles/
+        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.layout)
+        if os.path.exists(tf) and args.log2n == 20 and args.chunks == 1:
+            traffic = json.load(open(tf))["k_beaver_finish_asm"]["hbm_bytes_per_launch"]
         out = {
             "metric": METRIC, "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -305,8 +309,8 @@ def main():
                        "gates_per_gpu": n, "field": "bn254_fr", "layout": args.layout, "launches_per_step": 4 * args.chunks,
                        "workload_sets_rotated": len(sets),
                        "parallelism": "gate-range sharding, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_beaver_finish<0,true> (K2+K3 fused)", "achieved": ach, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_beaver_finish_asm<0,NT> (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": n * ALG_BYTES_K3, "avg_launch_ms": k3_ms},
             "pipeline": {"algorithmic_GBps": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9,
                          "frac_of_hbm_peak": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
