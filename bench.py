@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--layout", choices=["aos", "split"], default="split",
                     help="HBM layout of share vectors: arkworks AoS (drop-in) or engine-native split columns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=18, help="CPU baseline sample size (gates)")
+    ap.add_argument("--cpu-log2n", type=int, default=20, help="CPU baseline sample size (gates)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--sets", type=int, default=2, help="independent workload sets rotated step by step, so that no input line of step s "
                     "can still be cached (256 MiB Infinity Cache) when step s+1 runs; 1 = reuse the same buffers every step")
@@ -180,9 +180,9 @@ def check_results(eng, n, parties, truth, layout):
 
 
 def cpu_baseline(parties, n, log2n_cpu, layout):
-    """The oracle's restatement of the reference's literal 9-pass batch_mul (both parties), timed on this
-    host's cores on the first 2^log2n_cpu gates of the same workload.  kind = "port"."""
-    import threading
+    """The oracle's restatement of the reference's literal 9-pass batch_mul (both parties), timed on this host's
+    cores on the first 2^log2n_cpu gates of the same workload (kind = "port"): all cores via a static range split
+    in C (upper bound for the reference's rayon executor) and one thread (its default single executor thread)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api
     ora = oracle_api.load()
@@ -197,44 +197,37 @@ def cpu_baseline(parties, n, log2n_cpu, layout):
 
     H = [{k: host_aos(getattr(p, k)) for k in "xyabc"} for p in parties]
     keys = [p.key for p in parties]
-    cores = os.cpu_count() or 1
-
-    def run_range(lo, hi, party, peer_de, my_de_out, res_out, scratch):
-        cnt = hi - lo
-        sl8, sl4 = slice(8 * lo, 8 * hi), None
-        h = H[party]
-        args = [np.ascontiguousarray(h[k][sl8]) for k in "xyabc"]
-        pd = np.ascontiguousarray(np.concatenate([peer_de[4 * lo:4 * hi], peer_de[4 * m + 4 * lo:4 * m + 4 * hi]]))
-        md = np.zeros(8 * cnt, dtype=np.uint64)
-        out = np.zeros(8 * cnt, dtype=np.uint64)
-        ora._call("ora_batch_mul_9pass_local", FID, cnt, party, keys[party], args[0], args[1], args[2], args[3], args[4], pd, md, out, scratch)
-        res_out[sl8] = out
-
-    # the peers' d||e (needed as input by each party's finish passes): precompute untimed
-    de = [ora.beaver_mask(FID, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"]) for p in (0, 1)]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    de = [ora.beaver_mask(FID, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"]) for p in (0, 1)]   # the peers' d||e: untimed input
     res = [np.zeros(8 * m, dtype=np.uint64) for _ in (0, 1)]
+    myde = [np.zeros(8 * m, dtype=np.uint64) for _ in (0, 1)]
+    fn = ora.lib.ora_batch_mul_9pass_mt
+    P = ora._p
 
     def timed(nthreads):
-        bounds = [m * i // nthreads for i in range(nthreads + 1)]
-        scr = [np.zeros(64 * (bounds[i + 1] - bounds[i]), dtype=np.uint64) for i in range(nthreads)]
         t0 = time.perf_counter()
         for party in (0, 1):
-            ths = [threading.Thread(target=run_range, args=(bounds[i], bounds[i + 1], party, de[1 - party], None, res[party], scr[i]))
-                   for i in range(nthreads)]
-            for t in ths: t.start()
-            for t in ths: t.join()
+            h = H[party]
+            rc = fn(ctypes.c_int(FID), ctypes.c_size_t(m), ctypes.c_int(party), P(keys[party]), P(h["x"]), P(h["y"]), P(h["a"]), P(h["b"]),
+                    P(h["c"]), P(de[1 - party]), P(myde[party]), P(res[party]), ctypes.c_int(nthreads))
+            assert rc == 0
         return time.perf_counter() - t0
 
     timed(cores)  # warm
     reps, tot = 0, 0.0
-    while tot < 4.0 and reps < 20:
+    while tot < 6.0 and reps < 50:
         tot += timed(cores); reps += 1
     t_all = tot / reps
-    t_one = timed(1)
+    reps1, tot1 = 0, 0.0
+    while tot1 < 4.0 and reps1 < 10:
+        tot1 += timed(1); reps1 += 1
+    t_one = tot1 / reps1
+    assert np.array_equal(myde[0], de[0]) and np.array_equal(myde[1], de[1])
     return {
         "value": m / t_all, "unit": "gates/s", "cores": cores, "kind": "port",
-        "sample": "first 2^%d gates of the same seeded workload, both parties, reference's literal 9-pass batch_mul "
-                  "(oracle/ark_oracle.c ora_batch_mul_9pass_local), %d threads static range split, mean of %d runs" % (int(np.log2(m)), cores, reps),
+        "sample": "first 2^%d gates of the same seeded workload, both parties, the reference's literal 9-pass batch_mul "
+                  "(oracle/ark_oracle.c ora_batch_mul_9pass_mt, gcc -O3), %d pthreads static range split, mean of %d runs; "
+                  "single_thread_value = 1 thread, mean of %d runs" % (int(np.log2(m)), cores, reps, reps1),
         "single_thread_value": m / t_one,
     }, res, m
 

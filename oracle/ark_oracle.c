@@ -10,6 +10,8 @@
  */
 #include "ark_oracle.h"
 #include <string.h>
+#include <stdlib.h>
+#include <pthread.h>
 
 typedef unsigned __int128 u128;
 
@@ -563,4 +565,52 @@ void ora_dummy_counterparty_input_masks(int fid, int party, size_t n, u64* mask_
     u64 v[4], three[4], pid[4], m[4]; small(f, 3, three); small(f, (u64)party, pid);
     ora_fp_mul(f, three, pid, v); ora_fp_mul(f, pid, v, m);
     for (size_t i = 0; i < n; ++i) { memcpy(mask_shares + 8 * i, v, 32); memcpy(mask_shares + 8 * i + 4, m, 32); }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-core form of the 9-pass batch_mul: static contiguous range split over `nthreads` pthreads, each
+ * running ora_batch_mul_9pass_local on its range -- the upper bound for the reference's rayon executor
+ * (fabric/executor/multi_threaded/executor.rs:208-217).  Used only by bench.py's cpu_baseline leg.
+ * peer_de / my_de are d||e buffers of the FULL batch (d at [0,n), e at [n,2n)).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int fid, party; size_t n, lo, hi; const u64 *key, *x, *y, *a, *b, *c, *peer_de; u64 *my_de, *out; int rc;
+} mt_job;
+static void* mt_worker(void* arg) {
+    mt_job* j = (mt_job*)arg;
+    const size_t cnt = j->hi - j->lo, n = j->n, lo = j->lo;
+    if (!cnt) return 0;
+    u64* scratch = (u64*)malloc(64 * cnt * sizeof(u64));
+    u64* pde = (u64*)malloc(8 * cnt * sizeof(u64));
+    u64* mde = (u64*)malloc(8 * cnt * sizeof(u64));
+    if (!scratch || !pde || !mde) { j->rc = 1; free(scratch); free(pde); free(mde); return 0; }
+    memcpy(pde, j->peer_de + 4 * lo, 32 * cnt);
+    memcpy(pde + 4 * cnt, j->peer_de + 4 * (n + lo), 32 * cnt);
+    ora_batch_mul_9pass_local(j->fid, cnt, j->party, j->key, j->x + 8 * lo, j->y + 8 * lo, j->a + 8 * lo, j->b + 8 * lo,
+                              j->c + 8 * lo, pde, mde, j->out + 8 * lo, scratch);
+    memcpy(j->my_de + 4 * lo, mde, 32 * cnt);
+    memcpy(j->my_de + 4 * (n + lo), mde + 4 * cnt, 32 * cnt);
+    free(scratch); free(pde); free(mde);
+    return 0;
+}
+int ora_batch_mul_9pass_mt(int fid, size_t n, int party, const u64 key[4], const u64* x, const u64* y, const u64* a,
+                           const u64* b, const u64* c, const u64* peer_de, u64* my_de, u64* out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    init_fields();
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+    mt_job* jobs = (mt_job*)malloc(sizeof(mt_job) * nthreads);
+    int rc = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        mt_job j = {fid, party, n, n * t / nthreads, n * (t + 1) / nthreads, key, x, y, a, b, c, peer_de, my_de, out, 0};
+        jobs[t] = j;
+        if (nthreads == 1) mt_worker(&jobs[t]);
+        else if (pthread_create(&th[t], 0, mt_worker, &jobs[t])) { jobs[t].rc = 2; mt_worker(&jobs[t]); th[t] = 0; }
+    }
+    for (int t = 0; t < nthreads; ++t) {
+        if (nthreads > 1 && jobs[t].rc != 2) pthread_join(th[t], 0);
+        if (jobs[t].rc == 1) rc = 1;
+    }
+    free(th); free(jobs);
+    return rc;
 }

@@ -88,6 +88,9 @@ void ora_beaver_finish(int field_id, size_t n, int party_id, const u64 mac_key[4
 void ora_batch_mul_9pass_local(int field_id, size_t n, int party_id, const u64 mac_key[4], const u64* x, const u64* y,
                                const u64* a, const u64* b, const u64* c, const u64* peer_de, u64* my_de, u64* out,
                                u64* scratch);
+/* the same, range-split over nthreads pthreads (cpu_baseline "all cores"); returns 0 on success */
+int ora_batch_mul_9pass_mt(int field_id, size_t n, int party_id, const u64 mac_key[4], const u64* x, const u64* y,
+                           const u64* a, const u64* b, const u64* c, const u64* peer_de, u64* my_de, u64* out, int nthreads);
 /* K4: chk_i = mac_key * opened_i - share_i.mac  (:299-311) */
 void ora_mac_check_shares(int field_id, size_t n, const u64 mac_key[4], const u64* opened, const u64* shares, u64* out);
 /* K5: all(mine_i + peer_i == 0) (:218-219) */
