@@ -60,16 +60,16 @@ def build_engine(force=False, verbose=False):
 
 
 def build_host(force=False, verbose=False):
-    """C++ host-side mirror (MpcFabric / AuthenticatedScalar batch API) linked against the engine."""
-    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")] if os.path.isdir(HOST) else []
-    if not srcs:
+    """C++ host-side mirror of the reference's fabric API (host/fabric.hpp, header-only) + its two-party driver."""
+    src = os.path.join(HOST, "mock_mpc_main.cpp")
+    if not os.path.exists(src):
         return None
-    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp") or f.endswith(".h")]
-    so = os.path.join(LIB, "libarkmpc_host.so")
-    if force or _newer(so, srcs + hdrs + [os.path.join(LIB, "libarkmpc_hip.so")]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-I", os.path.join(HERE, "..", "include"),
-              "-o", so] + srcs + ["-L", LIB, "-larkmpc_hip", "-Wl,-rpath,$ORIGIN"])
-    return so
+    exe = os.path.join(LIB, "arkmpc_mock_mpc")
+    deps = [src, os.path.join(HOST, "fabric.hpp"), os.path.join(HERE, "..", "include", "arkmpc.h"), os.path.join(LIB, "libarkmpc_hip.so")]
+    if force or _newer(exe, deps):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(HERE, "..", "include"), "-I", HOST, "-o", exe, src,
+              "-L", LIB, "-larkmpc_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
+    return exe
 
 
 def build_all(force=False, verbose=False):

@@ -1,0 +1,435 @@
+// fabric.hpp -- C++ host-side mirror of the slice of ark-mpc's public API that sits on the hot path, written above
+// the C ABI (include/arkmpc.h).  The reference is Rust and the image has no Rust toolchain, so this is the host
+// language fallback: same names, argument meaning and error behaviour as the reference, batch-granular.
+//
+//   reference (online-phase/src/...)                              here
+//   ------------------------------------------------------------  ------------------------------------------
+//   MpcFabric<C>                       fabric.rs:164              arkmpc::MpcFabric
+//   PreprocessingPhase<C>              offline_prep.rs:12-82      arkmpc::PreprocessingPhase
+//   PartyIDBeaverSource                offline_prep.rs:88-170     arkmpc::PartyIDBeaverSource
+//   MpcNetwork / UnboundedDuplexStream network.rs:148-157, network/mock.rs:63-88   arkmpc::MpcNetwork / MockNetwork
+//   Vec<ScalarResult<C>>               scalar_result.rs           arkmpc::ScalarBatch         (device resident)
+//   Vec<AuthenticatedScalarResult<C>>  authenticated_scalar.rs    arkmpc::AuthenticatedScalarBatch
+//   MpcError::AuthenticationError      error.rs:8-18              arkmpc::MpcError
+//   execute_mock_mpc                   lib.rs:116-128             arkmpc::execute_mock_mpc
+//
+// What is NOT mirrored (out of scope): the DAG executor and ResultHandle futures -- operations
+// here run eagerly on the GPU stream, and a "network op" is a blocking send/receive of the batch payload.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "arkmpc.h"
+
+namespace arkmpc {
+
+using PartyId = uint64_t;
+constexpr PartyId PARTY0 = 0;  // lib.rs:41
+constexpr PartyId PARTY1 = 1;  // lib.rs:43
+
+enum class MpcError { None, NetworkError, AuthenticationError, ArithmeticError };  // error.rs:8-18
+
+struct Scalar {  // scalar.rs:46 -- 4 x u64 Montgomery limbs
+    uint64_t l[4];
+};
+struct ScalarShare {  // scalar/share.rs:32-37
+    Scalar share, mac;
+};
+static_assert(sizeof(ScalarShare) == 64, "arkworks layout");
+
+inline void check(arkmpc_ctx* ctx, int rc, const char* what) {
+    if (rc != ARKMPC_OK) throw std::runtime_error(std::string(what) + ": arkmpc status " + std::to_string(rc) + " " + arkmpc_last_error(ctx));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Engine handle: one device context (device pointers) + one staging context (host pointers) per party
+// ---------------------------------------------------------------------------------------------------------------
+class Engine {
+  public:
+    Engine(int field_id, int device) : field_id_(field_id) {
+        int rc = arkmpc_ctx_create(field_id, device, &dev_);
+        if (rc != ARKMPC_OK) throw std::runtime_error("arkmpc_ctx_create failed (" + std::to_string(rc) + "): the engine needs a GPU, there is no CPU fallback");
+        rc = arkmpc_ctx_create(field_id, device, &host_);
+        if (rc != ARKMPC_OK) throw std::runtime_error("arkmpc_ctx_create failed");
+        check(host_, arkmpc_ctx_set_host_buffers(host_, 1), "set_host_buffers");
+    }
+    ~Engine() {
+        if (dev_) arkmpc_ctx_destroy(dev_);
+        if (host_) arkmpc_ctx_destroy(host_);
+    }
+    Engine(const Engine&) = delete;
+    arkmpc_ctx* dev() const { return dev_; }
+    arkmpc_ctx* host() const { return host_; }
+    int field_id() const { return field_id_; }
+    // Scalar::from(u64) and friends: canonical little-endian integers -> Montgomery form (scalar.rs:131-139)
+    std::vector<Scalar> from_canonical(const std::vector<Scalar>& c) const {
+        std::vector<Scalar> out(c.size());
+        if (!c.empty()) check(host_, arkmpc_scalar_from_canonical(host_, c.size(), &c[0].l[0], &out[0].l[0]), "from_canonical");
+        return out;
+    }
+    std::vector<Scalar> to_canonical(const std::vector<Scalar>& m) const {
+        std::vector<Scalar> out(m.size());
+        if (!m.empty()) check(host_, arkmpc_scalar_to_canonical(host_, m.size(), &m[0].l[0], &out[0].l[0]), "to_canonical");
+        return out;
+    }
+    Scalar from_u64(uint64_t v) const { return from_canonical({Scalar{{v, 0, 0, 0}}})[0]; }
+
+  private:
+    int field_id_;
+    arkmpc_ctx* dev_ = nullptr;
+    arkmpc_ctx* host_ = nullptr;
+};
+
+// RAII device allocation of `words` u64
+class DeviceBuf {
+  public:
+    DeviceBuf() = default;
+    DeviceBuf(std::shared_ptr<Engine> e, size_t words) : e_(std::move(e)), words_(words) {
+        void* p = nullptr;
+        check(e_->dev(), arkmpc_malloc(e_->dev(), words * 8, &p), "malloc");
+        p_ = static_cast<uint64_t*>(p);
+    }
+    ~DeviceBuf() { if (p_) arkmpc_free(e_->dev(), p_); }
+    DeviceBuf(DeviceBuf&& o) noexcept { *this = std::move(o); }
+    DeviceBuf& operator=(DeviceBuf&& o) noexcept {
+        if (this != &o) { if (p_) arkmpc_free(e_->dev(), p_); e_ = std::move(o.e_); p_ = o.p_; words_ = o.words_; o.p_ = nullptr; o.words_ = 0; }
+        return *this;
+    }
+    DeviceBuf(const DeviceBuf&) = delete;
+    uint64_t* ptr() const { return p_; }
+    size_t words() const { return words_; }
+    void upload(const void* host, size_t bytes) { if (bytes) check(e_->dev(), arkmpc_memcpy_h2d(e_->dev(), p_, host, bytes), "h2d"); }
+    void download(void* host, size_t bytes) const {
+        check(e_->dev(), arkmpc_sync(e_->dev()), "sync");
+        if (bytes) check(e_->dev(), arkmpc_memcpy_d2h(e_->dev(), host, p_, bytes), "d2h");
+    }
+
+  private:
+    std::shared_ptr<Engine> e_;
+    uint64_t* p_ = nullptr;
+    size_t words_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Network: network.rs:148-157.  Payloads on this path are batches of scalars (NetworkPayload::ScalarBatch, :45-60).
+// ---------------------------------------------------------------------------------------------------------------
+struct NetworkOutbound {
+    uint64_t result_id;            // ids are allocated in lock-step by both parties (fabric.rs:282-295)
+    std::vector<Scalar> payload;
+};
+class MpcNetwork {
+  public:
+    virtual ~MpcNetwork() = default;
+    virtual PartyId party_id() const = 0;
+    virtual void send(NetworkOutbound&& msg) = 0;
+    virtual NetworkOutbound receive() = 0;     // blocks; throws on a closed peer (MpcNetworkError::RecvError)
+    virtual void close() = 0;
+};
+// network/mock.rs:63-88: a pair of unbounded in-memory queues
+struct DuplexQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<NetworkOutbound> q;
+    bool closed = false;
+};
+class MockNetwork : public MpcNetwork {
+  public:
+    MockNetwork(PartyId id, std::shared_ptr<DuplexQueue> out, std::shared_ptr<DuplexQueue> in) : id_(id), out_(std::move(out)), in_(std::move(in)) {}
+    PartyId party_id() const override { return id_; }
+    void send(NetworkOutbound&& msg) override {
+        { std::lock_guard<std::mutex> lk(out_->mu); out_->q.push_back(std::move(msg)); }
+        out_->cv.notify_one();
+    }
+    NetworkOutbound receive() override {
+        std::unique_lock<std::mutex> lk(in_->mu);
+        in_->cv.wait(lk, [&] { return !in_->q.empty() || in_->closed; });
+        if (in_->q.empty()) throw std::runtime_error("MpcNetworkError::RecvError: peer closed");
+        NetworkOutbound m = std::move(in_->q.front());
+        in_->q.pop_front();
+        return m;
+    }
+    void close() override {
+        { std::lock_guard<std::mutex> lk(out_->mu); out_->closed = true; }
+        out_->cv.notify_all();
+    }
+
+  private:
+    PartyId id_;
+    std::shared_ptr<DuplexQueue> out_, in_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Preprocessing: offline_prep.rs:12-82
+// ---------------------------------------------------------------------------------------------------------------
+class PreprocessingPhase {
+  public:
+    virtual ~PreprocessingPhase() = default;
+    virtual Scalar get_mac_key_share() = 0;
+    virtual std::pair<std::vector<Scalar>, std::vector<ScalarShare>> next_local_input_mask_batch(size_t n) = 0;
+    virtual std::vector<ScalarShare> next_counterparty_input_mask_batch(size_t n) = 0;
+    virtual void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) = 0;
+};
+// offline_prep.rs:88-170: a = 2, b = 3, c = 6 statically split; MAC key share = party id
+class PartyIDBeaverSource : public PreprocessingPhase {
+  public:
+    PartyIDBeaverSource(PartyId party, const Engine& e) : party_(party) {
+        for (uint64_t v = 0; v <= 6; ++v) s_[v] = e.from_u64(v);
+    }
+    Scalar get_mac_key_share() override { return s_[party_]; }                                   // :108-110
+    std::pair<std::vector<Scalar>, std::vector<ScalarShare>> next_local_input_mask_batch(size_t n) override {  // :112-119
+        const Scalar v = s_[3], pv = s_[3 * party_];
+        return {std::vector<Scalar>(n, v), std::vector<ScalarShare>(n, ScalarShare{pv, pv})};
+    }
+    std::vector<ScalarShare> next_counterparty_input_mask_batch(size_t n) override {            // :121-127
+        const Scalar pv = s_[3 * party_];                                                        // value = 3*party, mac = party*value
+        return std::vector<ScalarShare>(n, ScalarShare{pv, pv});
+    }
+    void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) override {  // :137-158
+        const uint64_t k = party_;   // key share
+        ScalarShare ta, tb, tc;
+        if (party_ == 0) { ta.share = s_[1]; tb.share = s_[3]; tc.share = s_[2]; }
+        else { ta.share = s_[1]; tb.share = s_[0]; tc.share = s_[4]; }
+        ta.mac = s_[k * 2]; tb.mac = s_[k * 3]; tc.mac = s_[k * 6];
+        a.assign(n, ta); b.assign(n, tb); c.assign(n, tc);
+    }
+
+  private:
+    PartyId party_;
+    Scalar s_[7];
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fabric + result batches
+// ---------------------------------------------------------------------------------------------------------------
+class MpcFabric;
+
+// Vec<ScalarResult<C>>: n public scalars resident on the GPU
+struct ScalarBatch {
+    size_t n = 0;
+    DeviceBuf buf;
+    std::vector<Scalar> to_host() const { std::vector<Scalar> v(n); buf.download(v.data(), n * 32); return v; }
+};
+
+class AuthenticatedScalarBatch;
+struct AuthenticatedOpenResult {   // AuthenticatedScalarOpenResult, authenticated_scalar.rs:360-385
+    MpcError err = MpcError::None; // AuthenticationError unless the MAC check scalar equals 1
+    ScalarBatch value;
+};
+
+class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
+  public:
+    MpcFabric(PartyId party, std::shared_ptr<Engine> eng, std::unique_ptr<MpcNetwork> net, std::unique_ptr<PreprocessingPhase> prep)
+        : party_(party), eng_(std::move(eng)), net_(std::move(net)), prep_(std::move(prep)) {
+        mac_key_ = prep_->get_mac_key_share();                                                   // fabric.rs:446
+    }
+    PartyId party_id() const { return party_; }
+    const Scalar& mac_key() const { return mac_key_; }
+    std::shared_ptr<Engine> engine() const { return eng_; }
+    arkmpc_ctx* ctx() const { return eng_->dev(); }
+
+    ScalarBatch allocate_scalars(const std::vector<Scalar>& mont) {                               // fabric.rs:652-668
+        ScalarBatch b; b.n = mont.size(); b.buf = DeviceBuf(eng_, 4 * (mont.size() ? mont.size() : 1)); b.buf.upload(mont.data(), mont.size() * 32);
+        return b;
+    }
+    // send / receive / exchange of a scalar batch (fabric.rs:720-814): party 0 sends first then receives
+    void send_values(const ScalarBatch& v) { net_->send(NetworkOutbound{next_id_++, v.to_host()}); }
+    ScalarBatch receive_values() { NetworkOutbound m = net_->receive(); next_id_++; return allocate_scalars(m.payload); }
+    ScalarBatch exchange_values(const ScalarBatch& mine) {
+        if (party_ == PARTY0) { send_values(mine); return receive_values(); }
+        ScalarBatch peer = receive_values(); send_values(mine); return peer;
+    }
+    // batch_share_plaintext (fabric.rs:602-620): the sender's values become public on both sides
+    ScalarBatch batch_share_plaintext(const std::vector<Scalar>& mont, size_t n, PartyId sender) {
+        if (party_ == sender) { ScalarBatch b = allocate_scalars(mont); send_values(b); return b; }
+        (void)n; return receive_values();
+    }
+    void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c);  // fabric.rs:894-915
+    // fabric.rs:578-600
+    AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
+    AuthenticatedScalarBatch allocate_scalar_shares(const std::vector<ScalarShare>& s);
+
+  private:
+    PartyId party_;
+    std::shared_ptr<Engine> eng_;
+    std::unique_ptr<MpcNetwork> net_;
+    std::unique_ptr<PreprocessingPhase> prep_;
+    Scalar mac_key_;
+    uint64_t next_id_ = 6;   // N_CONSTANT_RESULTS (fabric.rs:55-70)
+};
+
+// Vec<AuthenticatedScalarResult<C>>: n ScalarShares resident on the GPU (arkworks AoS layout)
+class AuthenticatedScalarBatch {
+  public:
+    size_t n = 0;
+    DeviceBuf buf;
+    std::shared_ptr<MpcFabric> fabric;
+
+    static AuthenticatedScalarBatch alloc(const std::shared_ptr<MpcFabric>& f, size_t n) {
+        AuthenticatedScalarBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), 8 * (n ? n : 1)); return r;
+    }
+    std::vector<ScalarShare> to_host() const { std::vector<ScalarShare> v(n); buf.download(v.data(), n * 64); return v; }
+
+    // ---- linear ops (authenticated_scalar.rs:457-765) -------------------------------------------------------
+    static AuthenticatedScalarBatch batch_add(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {       // :457-489
+        same(a, b); auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_add(ctx(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_add"); return r;
+    }
+    static AuthenticatedScalarBatch batch_sub(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {       // :662-688
+        same(a, b); auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_sub(ctx(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_sub"); return r;
+    }
+    static AuthenticatedScalarBatch batch_neg(const AuthenticatedScalarBatch& a) {                                          // :745-765
+        auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_neg(ctx(a), a.n, a.buf.ptr(), r.buf.ptr()), "share_neg"); return r;
+    }
+    static AuthenticatedScalarBatch batch_add_public(const AuthenticatedScalarBatch& a, const ScalarBatch& b) {             // :493-528
+        if (a.n != b.n) throw std::invalid_argument("Cannot add batches of different sizes");
+        auto r = alloc(a.fabric, a.n);
+        check(ctx(a), arkmpc_share_add_public(ctx(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_add_public");
+        return r;
+    }
+    static AuthenticatedScalarBatch batch_sub_public(const AuthenticatedScalarBatch& a, const ScalarBatch& b) {             // :691-733
+        if (a.n != b.n) throw std::invalid_argument("Cannot add batches of different sizes");
+        auto r = alloc(a.fabric, a.n);
+        check(ctx(a), arkmpc_share_sub_public(ctx(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_sub_public");
+        return r;
+    }
+    static AuthenticatedScalarBatch batch_mul_public(const AuthenticatedScalarBatch& a, const ScalarBatch& b) {             // :883-916
+        if (a.n != b.n) throw std::invalid_argument("Cannot multiply batches of different sizes");
+        auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_mul_public(ctx(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_mul_public"); return r;
+    }
+    // ---- Beaver multiplication (:848-879) -------------------------------------------------------------------
+    static AuthenticatedScalarBatch batch_mul(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {
+        same(a, b);
+        const size_t n = a.n;
+        auto f = a.fabric;
+        if (n == 0) return alloc(f, 0);                                                       // :853-855
+        AuthenticatedScalarBatch ta, tb, tc;
+        f->next_triple_batch(n, ta, tb, tc);                                                  // :859
+        // masked_lhs = a - beaver_a, masked_rhs = b - beaver_b, all_masks = lhs || rhs; open_batch sends `.share()` (:863-868, :141-145)
+        ScalarBatch my_de; my_de.n = 2 * n; my_de.buf = DeviceBuf(f->engine(), 8 * n);
+        check(f->ctx(), arkmpc_beaver_mask(f->ctx(), n, a.buf.ptr(), b.buf.ptr(), ta.buf.ptr(), tb.buf.ptr(), my_de.buf.ptr()), "beaver_mask");
+        ScalarBatch peer_de = f->exchange_values(my_de);                                      // the one network round
+        if (peer_de.n != 2 * n) throw std::runtime_error("MpcNetworkError: unexpected payload size");
+        auto r = alloc(f, n);                                                                 // combine (:161-171) + de + d[b] + e[a] + [c] (:871-878)
+        check(f->ctx(), arkmpc_beaver_finish_fused(f->ctx(), n, (int)f->party_id(), f->mac_key().l, my_de.buf.ptr(), peer_de.buf.ptr(),
+                                                   ta.buf.ptr(), tb.buf.ptr(), tc.buf.ptr(), r.buf.ptr()), "beaver_finish_fused");
+        return r;
+    }
+    // ---- opening (:129-172, :278-354) -----------------------------------------------------------------------
+    ScalarBatch open_batch() const {
+        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(fabric->engine(), 4 * (n ? n : 1));
+        if (n == 0) return mine;
+        check(fabric->ctx(), arkmpc_share_extract(fabric->ctx(), n, buf.ptr(), mine.buf.ptr()), "share_extract");
+        ScalarBatch peer = fabric->exchange_values(mine);
+        ScalarBatch out; out.n = n; out.buf = DeviceBuf(fabric->engine(), 4 * n);
+        check(fabric->ctx(), arkmpc_open_combine(fabric->ctx(), n, mine.buf.ptr(), peer.buf.ptr(), out.buf.ptr()), "open_combine");
+        return out;
+    }
+    // `blinder` is injectable for reproducible tests; the reference draws it from thread_rng (commitment.rs:67-68)
+    AuthenticatedOpenResult open_authenticated_batch(const Scalar& blinder) const {
+        AuthenticatedOpenResult res;
+        auto f = fabric;
+        if (n == 0) return res;                                                                   // :279-281
+        arkmpc_ctx* c = f->ctx();
+        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(f->engine(), 4 * n);
+        check(c, arkmpc_share_extract(c, n, buf.ptr(), mine.buf.ptr()), "share_extract");
+        ScalarBatch peer = f->exchange_values(mine);                                              // round 1: open_batch
+        ScalarBatch opened; opened.n = n; opened.buf = DeviceBuf(f->engine(), 4 * n);
+        ScalarBatch chk; chk.n = n; chk.buf = DeviceBuf(f->engine(), 4 * n);
+        check(c, arkmpc_open_and_mac_check(c, n, f->mac_key().l, buf.ptr(), peer.buf.ptr(), opened.buf.ptr(), chk.buf.ptr()), "open_and_mac_check");   // :161-171 + :299-311
+        Scalar my_comm;
+        check(c, arkmpc_commit_sha3(c, n, chk.buf.ptr(), blinder.l, my_comm.l), "commit_sha3");  // batch_commit (commitment.rs:63-89)
+        ScalarBatch peer_comm = f->exchange_values(f->allocate_scalars({my_comm}));               // round 2: commitments
+        ScalarBatch peer_chk = f->exchange_values(chk);                                           // round 3: MAC-check shares
+        ScalarBatch peer_blinder = f->exchange_values(f->allocate_scalars({blinder}));            // round 4: blinders
+        // batch_verify_mac_check (:201-220): the peer's commitment opens correctly, and my_i + peer_i == 0 for all i
+        Scalar pb = peer_blinder.to_host()[0], pc = peer_comm.to_host()[0], recomputed;
+        check(c, arkmpc_commit_sha3(c, n, peer_chk.buf.ptr(), pb.l, recomputed.l), "commit_sha3(verify)");
+        int ok_sum = 0;
+        check(c, arkmpc_mac_verify(c, n, chk.buf.ptr(), peer_chk.buf.ptr(), &ok_sum), "mac_verify");
+        const bool ok = std::memcmp(recomputed.l, pc.l, 32) == 0 && ok_sum == 1;
+        res.err = ok ? MpcError::None : MpcError::AuthenticationError;                            // :368-385
+        res.value = std::move(opened);
+        return res;
+    }
+    // test helpers (authenticated_scalar.rs:1079-1111): overwrite the MAC / the share of element idx
+    void modify_mac(size_t idx, const Scalar& v) { poke(idx, 1, v); }
+    void modify_share(size_t idx, const Scalar& v) { poke(idx, 0, v); }
+
+  private:
+    static arkmpc_ctx* ctx(const AuthenticatedScalarBatch& a) { return a.fabric->ctx(); }
+    static void same(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {
+        if (a.n != b.n) throw std::invalid_argument("Cannot operate on batches of different sizes");   // assert_eq! in the reference
+    }
+    void poke(size_t idx, int half, const Scalar& v) {
+        std::vector<ScalarShare> h = to_host();
+        (half ? h.at(idx).mac : h.at(idx).share) = v;
+        buf.upload(h.data(), n * 64);
+    }
+};
+
+inline AuthenticatedScalarBatch MpcFabric::allocate_scalar_shares(const std::vector<ScalarShare>& s) {
+    auto r = AuthenticatedScalarBatch::alloc(shared_from_this(), s.size());
+    r.buf.upload(s.data(), s.size() * 64);
+    return r;
+}
+inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c) {
+    std::vector<ScalarShare> ha, hb, hc;
+    prep_->next_triplet_batch(n, ha, hb, hc);
+    if (ha.size() != n || hb.size() != n || hc.size() != n) throw std::runtime_error("preprocessing exhausted");   // structs.rs:189 asserts
+    next_id_ += 3 * n;
+    a = allocate_scalar_shares(ha); b = allocate_scalar_shares(hb); c = allocate_scalar_shares(hc);
+}
+// fabric.rs:578-600: the sender broadcasts val - mask; both sides do mask_share.add_public(masked)
+inline AuthenticatedScalarBatch MpcFabric::batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender) {
+    ScalarBatch masked;
+    std::vector<ScalarShare> mask_shares;
+    if (party_ == sender) {
+        auto lm = prep_->next_local_input_mask_batch(n);
+        ScalarBatch vals = allocate_scalars(vals_mont), masks = allocate_scalars(lm.first);
+        masked.n = n; masked.buf = DeviceBuf(eng_, 4 * (n ? n : 1));
+        if (n) check(ctx(), arkmpc_scalar_sub(ctx(), n, vals.buf.ptr(), masks.buf.ptr(), masked.buf.ptr()), "scalar_sub");
+        send_values(masked);
+        mask_shares = std::move(lm.second);
+    } else {
+        mask_shares = prep_->next_counterparty_input_mask_batch(n);
+        masked = receive_values();
+    }
+    AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
+    return AuthenticatedScalarBatch::batch_add_public(shares, masked);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// lib.rs:116-128: run the same closure as both parties over an in-process duplex
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+std::pair<T, T> execute_mock_mpc(int field_id, int device,
+                                 const std::function<std::unique_ptr<PreprocessingPhase>(PartyId, const Engine&)>& make_prep,
+                                 const std::function<T(std::shared_ptr<MpcFabric>)>& f) {
+    auto q01 = std::make_shared<DuplexQueue>(), q10 = std::make_shared<DuplexQueue>();
+    T out[2];
+    std::exception_ptr err[2];
+    auto run = [&](PartyId p) {
+        try {
+            auto eng = std::make_shared<Engine>(field_id, device);
+            std::unique_ptr<MpcNetwork> net(new MockNetwork(p, p == 0 ? q01 : q10, p == 0 ? q10 : q01));
+            MpcNetwork* raw = net.get();
+            auto fab = std::make_shared<MpcFabric>(p, eng, std::move(net), make_prep(p, *eng));
+            try { out[p] = f(fab); } catch (...) { raw->close(); throw; }
+        } catch (...) { err[p] = std::current_exception(); }
+    };
+    std::thread t0(run, PARTY0), t1(run, PARTY1);
+    t0.join(); t1.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
+    return {std::move(out[0]), std::move(out[1])};
+}
+
+}  // namespace arkmpc

@@ -1,0 +1,87 @@
+// mock_mpc_main.cpp -- two-party scenarios over the in-process mock network, written against fabric.hpp the way the
+// reference's own tests are written against ark-mpc (execute_mock_mpc + PartyIDBeaverSource, lib.rs:116-128):
+//   batch_mul       benches/batch_ops.rs:20-39 / authenticated_scalar.rs test_batch_mul (:1571-1594)
+//   share_and_open  integration/src/fabric.rs:15-32
+//   circuit         add / sub / neg / mul / mul_public / add_public / sub_public composition
+//   + --bad-mac / --bad-share: integration/src/authenticated_scalar.rs:49-75 (open_authenticated must fail)
+// usage: arkmpc_mock_mpc <scenario> <field_id> <n> <in_file> <out_file> [--bad-mac|--bad-share]
+// in_file : n canonical a values then n canonical b values (32-byte little-endian each)
+// out_file: per party: u64 error code (0 ok, 2 AuthenticationError), then n canonical opened values
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "fabric.hpp"
+
+using namespace arkmpc;
+
+struct PartyOut {
+    uint64_t err = 0;
+    std::vector<Scalar> opened;   // canonical
+};
+
+int main(int argc, char** argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: %s <scenario> <field_id> <n> <in_file> <out_file> [--bad-mac|--bad-share]\n", argv[0]); return 2; }
+    const std::string scenario = argv[1];
+    const int field_id = std::atoi(argv[2]);
+    const size_t n = std::strtoull(argv[3], nullptr, 10);
+    bool bad_mac = false, bad_share = false;
+    for (int i = 6; i < argc; ++i) { if (std::string(argv[i]) == "--bad-mac") bad_mac = true; if (std::string(argv[i]) == "--bad-share") bad_share = true; }
+    std::vector<Scalar> a_c(n), b_c(n);
+    {
+        std::ifstream in(argv[4], std::ios::binary);
+        in.read(reinterpret_cast<char*>(a_c.data()), n * 32);
+        in.read(reinterpret_cast<char*>(b_c.data()), n * 32);
+        if (!in) { std::fprintf(stderr, "short input file\n"); return 2; }
+    }
+    try {
+        auto make_prep = [](PartyId p, const Engine& e) { return std::unique_ptr<PreprocessingPhase>(new PartyIDBeaverSource(p, e)); };
+        auto program = [&](std::shared_ptr<MpcFabric> fabric) -> PartyOut {
+            const Engine& eng = *fabric->engine();
+            std::vector<Scalar> a_m = eng.from_canonical(a_c), b_m = eng.from_canonical(b_c);
+            const Scalar blinder = eng.from_u64(0x1234567 + fabric->party_id());
+            AuthenticatedScalarBatch res;
+            if (scenario == "batch_mul") {
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                auto b = fabric->batch_share_scalar(b_m, n, PARTY0);
+                res = AuthenticatedScalarBatch::batch_mul(a, b);
+            } else if (scenario == "share_and_open") {
+                res = fabric->batch_share_scalar(a_m, n, PARTY1);
+            } else if (scenario == "circuit") {
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                auto b = fabric->batch_share_scalar(b_m, n, PARTY1);
+                auto t = AuthenticatedScalarBatch::batch_add(a, b);
+                auto u = AuthenticatedScalarBatch::batch_sub(a, b);
+                auto v = AuthenticatedScalarBatch::batch_mul(t, u);                       // a^2 - b^2
+                auto w = AuthenticatedScalarBatch::batch_neg(v);
+                ScalarBatch pa = fabric->batch_share_plaintext(a_m, n, PARTY0);           // a as a public value
+                ScalarBatch pb = b.open_batch();                                          // b opened (unauthenticated)
+                auto x = AuthenticatedScalarBatch::batch_mul_public(w, pa);
+                auto y = AuthenticatedScalarBatch::batch_add_public(x, pa);
+                res = AuthenticatedScalarBatch::batch_sub_public(y, pb);                  // -(a^2-b^2)*a + a - b
+            } else {
+                throw std::invalid_argument("unknown scenario " + scenario);
+            }
+            if (fabric->party_id() == PARTY0 && n) {
+                if (bad_mac) res.modify_mac(n / 2, eng.from_u64(42));
+                if (bad_share) res.modify_share(n / 2, eng.from_u64(42));
+            }
+            AuthenticatedOpenResult o = res.open_authenticated_batch(blinder);
+            PartyOut out;
+            out.err = (o.err == MpcError::None) ? 0 : 2;
+            if (n) out.opened = eng.to_canonical(o.value.to_host());
+            return out;
+        };
+        auto both = execute_mock_mpc<PartyOut>(field_id, 0, make_prep, program);
+        std::ofstream out(argv[5], std::ios::binary);
+        for (const PartyOut* po : {&both.first, &both.second}) {
+            out.write(reinterpret_cast<const char*>(&po->err), 8);
+            out.write(reinterpret_cast<const char*>(po->opened.data()), po->opened.size() * 32);
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "mock mpc failed: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
