@@ -92,9 +92,44 @@ __device__ __noinline__ G1 g1_add(const G1& p, const G1& q) {
     out = g1_select(pinf, q, out);
     return out;
 }
-// [s]P, s given in Montgomery form over Fr (curve.rs:403-409).  MSB-first double-and-add with
-// wave-uniform control flow: every lane doubles; the add is computed when any lane needs it and
+// [s]P, s given in Montgomery form over Fr (curve.rs:403-409).  Fixed 4-bit windows, MSB first: per window four
+// doublings and at most one addition of a table entry k*P (k = 1..15).  The table lives in an HBM workspace
+// (15 x 96 B per thread, entry-major so a wave's accesses to one entry are contiguous): 160 KiB of LDS could only
+// hold it at one wave per CU, and this kernel is integer-ALU bound (~3.0 k Fq multiplications per scalar-mul against
+// ~6 KiB of table reads).  Control flow is wave-uniform; the addition runs when any lane has a non-zero digit and is
 // merged per lane with a select.
+__device__ __forceinline__ G1 g1_scalar_mul_w4(const G1& p, const Fe& s_mont, u64* tab, size_t tid, size_t nthreads) {
+    const Fe s = fe_to_canonical<FR>(s_mont);
+    // table: T[k-1] = k*P
+    G1 t = p;
+    g1_store(tab + ((size_t)0 * nthreads + tid) * 12, t);
+    G1 t2 = g1_double(p);
+    g1_store(tab + ((size_t)1 * nthreads + tid) * 12, t2);
+    t = t2;
+    for (int k = 3; k <= 15; ++k) {
+        t = g1_add(t, p);
+        g1_store(tab + ((size_t)(k - 1) * nthreads + tid) * 12, t);
+    }
+    G1 acc = g1_identity();
+    for (int limb = 7; limb >= 0; --limb) {
+        const u32 w = s.v[limb];
+        for (int nib = 7; nib >= 0; --nib) {
+            acc = g1_double(acc);
+            acc = g1_double(acc);
+            acc = g1_double(acc);
+            acc = g1_double(acc);
+            const u32 d = (w >> (4 * nib)) & 15u;
+            if (__any(d != 0)) {
+                const u32 k = d ? d - 1 : 0;
+                G1 q = g1_load(tab + ((size_t)k * nthreads + tid) * 12);
+                G1 sum = g1_add(acc, q);
+                acc = g1_select(d != 0, sum, acc);
+            }
+        }
+    }
+    return acc;
+}
+// plain MSB-first double-and-add (used for the single uniform-key multiplications inside other kernels)
 __device__ __forceinline__ G1 g1_scalar_mul(const G1& p, const Fe& s_mont) {
     const Fe s = fe_to_canonical<FR>(s_mont);
     G1 acc = g1_identity();
@@ -156,12 +191,12 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_neg(size_t n, const u64* a, u64* 
 // PointShare*Scalar (curve/share.rs:108-114: two launches' worth, index i -> element i/2, scalar i/2),
 // ScalarShare*CurvePoint (scalar/share.rs:135-141) and ScalarShare*generator (authenticated_curve.rs:754-780).
 __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* points, u32 p_stride, u32 p_div,
-                                                           const u64* scalars, u32 s_stride, u32 s_div, u64* out) {
+                                                           const u64* scalars, u32 s_stride, u32 s_div, u64* out, u64* table_ws) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     G1 p = points ? g1_load(points + (size_t)p_stride * (i / p_div)) : g1_generator();
     Fe s = fe_load(scalars + (size_t)s_stride * (i / s_div));
-    g1_store(out + 12 * i, g1_scalar_mul(p, s));
+    g1_store(out + 12 * i, g1_scalar_mul_w4(p, s, table_ws, i, n));
 }
 // PointShare::add_public (curve/share.rs:57-60): share += rhs iff PARTY0 ; mac += mac_key * rhs
 __global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public(size_t n, int party, Fe key, const u64* shares, const u64* pub, u64* out) {
@@ -264,17 +299,27 @@ static int g1_neg_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* a, uint64_t* o
 int arkmpc_g1_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return g1_neg_impl(ctx, n, a, out); }
 int arkmpc_pointshare_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return g1_neg_impl(ctx, 2 * n, a, out); }
 
-// generic scalar-mul launcher: m output points; point index = i / p_div, scalar index = i / s_div
+// generic scalar-mul launcher: m output points; point index = i / p_div, scalar index = i / s_div.
+// Batches are processed in chunks of 2^20 scalar-muls so the window-table workspace stays at 1.4 GiB.
 static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n_points, u32 p_stride, u32 p_div,
                      const uint64_t* scalars, size_t scalar_bytes, u32 s_stride, u32 s_div, uint64_t* out) {
     ENTER_EC(ctx);
     Stage st(ctx);
     int ip = points ? st.declare_in(points, n_points * 96) : -1;
     int is = st.declare_in(scalars, scalar_bytes), io = st.declare_out(out, m * 96);
+    const size_t CH = (size_t)1 << 20;
+    const size_t chunk = m < CH ? m : CH;
+    int iw = st.declare_scratch(chunk * 15 * 96);
     if (st.commit()) return st.rc;
     if (m) {
-        hipLaunchKernelGGL(k_g1_scalar_mul, dim3(blocks_for(m, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, m,
-                           points ? st.in<u64>(ip) : (const u64*)nullptr, p_stride, p_div, st.in<u64>(is), s_stride, s_div, st.out<u64>(io));
+        // chunk boundaries must respect the point / scalar divisors (1 or 2)
+        for (size_t lo = 0; lo < m; lo += chunk) {
+            const size_t cnt = (m - lo < chunk) ? (m - lo) : chunk;
+            const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
+            const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
+            hipLaunchKernelGGL(k_g1_scalar_mul, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, pp, p_stride, p_div, sp,
+                               s_stride, s_div, st.out<u64>(io) + 12 * lo, st.scratch<u64>(iw));
+        }
     }
     return st.finish();
 }

@@ -96,15 +96,29 @@ struct Stage {
         oplan.push_back({p, bytes, total}); total += align_up(bytes);
         return (int)oplan.size() - 1;
     }
+    // device-only scratch (both buffer modes): carved from the arena
+    std::vector<size_t> scratch_off;
+    size_t scratch_total = 0;
+    int declare_scratch(size_t bytes) {
+        scratch_off.push_back(scratch_total); scratch_total += align_up(bytes);
+        return (int)scratch_off.size() - 1;
+    }
+    template <class T> T* scratch(int idx) const {
+        return (T*)(ctx->arena + (ctx->host_buffers ? total : 0) + scratch_off[idx]);
+    }
     int commit() {
         if (rc) return rc;
+        if (scratch_total) {
+            rc = arena_reserve(ctx, (ctx->host_buffers ? total : 0) + scratch_total);
+            if (rc) return rc;
+        }
         if (!ctx->host_buffers) {
             for (auto& i : ins) if (((uintptr_t)i.host & 15) != 0) return rc = ark_bad(ctx, "device pointer not 16-byte aligned");
             for (auto& o : oplan) if (((uintptr_t)o.host & 15) != 0) return rc = ark_bad(ctx, "device pointer not 16-byte aligned");
             planned = true;
             return ARKMPC_OK;
         }
-        rc = arena_reserve(ctx, total);
+        rc = arena_reserve(ctx, total + scratch_total);
         if (rc) return rc;
         for (auto& i : ins) {
             if (!i.bytes) continue;
