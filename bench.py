@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=20, help="CPU baseline sample size (gates)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for launch-path tests)")
     ap.add_argument("--sets", type=int, default=2, help="independent workload sets rotated step by step, so that no input line of step s "
                     "can still be cached (256 MiB Infinity Cache) when step s+1 runs; 1 = reuse the same buffers every step")
     ap.add_argument("--chunks", type=int, default=1, help="split each step's batch into this many gate ranges, each run K1,K1,K3,K3 "
@@ -242,8 +243,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = local_rank % torch.cuda.device_count()      # (tests may oversubscribe one GPU with the gloo backend)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -270,7 +275,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # per-kernel durations from the in-stream HIP events of the timed region

@@ -239,7 +239,7 @@ def test_device_pointer_mode_and_views(pkg, oracle, fid):
     e.close()
 
 
-@pytest.mark.parametrize("fid", [0, 2, 3])
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
 @pytest.mark.parametrize("layout", ["aos", "split"])
 def test_hand_scheduled_finish_matches_cpp_kernel_at_scale(pkg, oracle, fid, layout):
     """The hand-scheduled K2+K3 body (asm_kernels.inc) vs the plain C++ kernel (unfused entry point, which never
