@@ -114,6 +114,7 @@ def i_and(d, a, b): return Ins("v_and_b32_e32 %s, %s, %s" % (d, src(a), b), "and
 # Measured on MI355X (2^20 gates, split layout): K3 80 -> 69 us.  In the AoS layout share and MAC halves share one
 # 64-byte line and the hint hurts, so the AoS variant carries none.
 NT_SPLIT = {"c_s", "c_m", "out_s", "out_m", "a_m", "b_m"}
+NT_AOS = set(os.environ.get("ARKMPC_GEN_NT_AOS", "").split(",")) - {""}
 NT_BASES = set()
 
 
@@ -365,7 +366,7 @@ KEY_S = ["%%[k%d]" % i for i in range(8)]
 
 def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
     global NT_BASES
-    NT_BASES = NT_SPLIT if nt else set()
+    NT_BASES = NT_SPLIT if nt else NT_AOS
     """Emit the fused combine + finish body for modulus p.  Returns (Emitter, regmap)."""
     key = key_names or ["%[k" + str(i) + "]" for i in range(8)]
     rg = Regs(first_vgpr)
