@@ -258,6 +258,76 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_to_bytes(size_t n, const u64* pts
 }
 
 // ---------------------------------------------------------------------------------------------
+// K9: per-element hash commitments to points -- HashCommitmentResult::commit on each MAC-check point
+// (authenticated_curve.rs:227 -> commitment.rs:58-89 with one value):
+//     out_i = from_be_bytes_mod_order( SHA3-256( to_bytes(P_i) || to_bytes_be(blinder_i) ) )
+// Unlike the scalar batch commitment (one sequential sponge over all values), these are n independent 64-byte
+// messages = one Keccak-f[1600] each, so the whole thing runs on the GPU, one thread per commitment.
+// ---------------------------------------------------------------------------------------------
+__constant__ u64 KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+__device__ __forceinline__ u64 rotl64(u64 x, int s) { return (x << s) | (x >> (64 - s)); }
+
+__device__ __forceinline__ void keccak_f1600_dev(u64 (&a)[25]) {
+#pragma unroll 1
+    for (int r = 0; r < 24; ++r) {
+        u64 c[5], d[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+        for (int i = 0; i < 25; ++i) a[i] ^= d[i % 5];
+        // rho + pi: b[y + 5*((2x+3y)%5)] = rot(a[x + 5y], R[x][y])
+        b[0] = a[0];
+        b[10] = rotl64(a[1], 1);   b[20] = rotl64(a[2], 62);  b[5] = rotl64(a[3], 28);   b[15] = rotl64(a[4], 27);
+        b[16] = rotl64(a[5], 36);  b[1] = rotl64(a[6], 44);   b[11] = rotl64(a[7], 6);   b[21] = rotl64(a[8], 55);  b[6] = rotl64(a[9], 20);
+        b[7] = rotl64(a[10], 3);   b[17] = rotl64(a[11], 10); b[2] = rotl64(a[12], 43);  b[12] = rotl64(a[13], 25); b[22] = rotl64(a[14], 39);
+        b[23] = rotl64(a[15], 41); b[8] = rotl64(a[16], 45);  b[18] = rotl64(a[17], 15); b[3] = rotl64(a[18], 21);  b[13] = rotl64(a[19], 8);
+        b[14] = rotl64(a[20], 18); b[24] = rotl64(a[21], 2);  b[9] = rotl64(a[22], 61);  b[19] = rotl64(a[23], 56); b[4] = rotl64(a[24], 14);
+#pragma unroll
+        for (int y = 0; y < 5; ++y)
+#pragma unroll
+            for (int x = 0; x < 5; ++x) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= KECCAK_RC[r];
+    }
+}
+__device__ __forceinline__ u64 limb64(const Fe& f, int i) { return (u64)f.v[2 * i] | ((u64)f.v[2 * i + 1] << 32); }
+
+__global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* pts, const u64* blinders, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    // to_bytes(P): compressed encoding, as four little-endian u64 lanes (curve.rs:103-108)
+    Fe x, y; bool inf;
+    g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
+    Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(fe_neg<FQ>(y));
+    u32 br = 0, bo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nyc.v[k], yc.v[k], br, &bo); br = bo; }
+    if (inf) xc.v[7] |= 0x40000000u; else if (br) xc.v[7] |= 0x80000000u;
+    // to_bytes_be(blinder): 32 big-endian bytes = limbs reversed and byte-swapped (scalar.rs:118-127)
+    Fe bc = fe_to_canonical<FR>(fe_load(blinders + 4 * i));
+    u64 a[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) a[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = limb64(xc, k); a[4 + k] = __builtin_bswap64(limb64(bc, 3 - k)); }
+    a[8] ^= 0x06ULL;                    // SHA3 domain separation + first pad bit at byte 64
+    a[16] ^= 0x8000000000000000ULL;     // last pad bit at byte 135 (rate = 136)
+    keccak_f1600_dev(a);
+    // digest bytes (lanes 0..3, little-endian) read as ONE big-endian integer, reduced mod r (scalar.rs:109-112)
+    Fe v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { u64 w = __builtin_bswap64(a[3 - k]); v.v[2 * k] = (u32)w; v.v[2 * k + 1] = (u32)(w >> 32); }
+    fe_store(out + 4 * i, fe_from_canonical<FR>(fe_reduce_once_loop<FR>(v)));
+}
+
+// ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 #define ENTER_EC(ctx)                                                                           \
@@ -383,6 +453,14 @@ int arkmpc_point_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, con
     if (st.commit()) return st.rc;
     if (n) hipLaunchKernelGGL(k_point_mac_verify, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(im), st.in<u64>(ip),
                               st.out<unsigned char>(io));
+    return st.finish();
+}
+int arkmpc_commit_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* blinders, uint64_t* out_commitments) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(points, n * 96), ib = st.declare_in(blinders, n * 32), io = st.declare_out(out_commitments, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_commit_points, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.in<u64>(ib), st.out<u64>(io));
     return st.finish();
 }
 int arkmpc_g1_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy, uint8_t* out_inf) {

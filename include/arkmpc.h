@@ -170,6 +170,11 @@ int arkmpc_pointshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares,
 /* value * mac_key - share.mac() per element (authenticated_curve.rs:215-220) */
 int arkmpc_point_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* opened_points,
                                   const uint64_t* shares, uint64_t* out_chk_points);
+/* K9  per-element HashCommitmentResult::commit on points (authenticated_curve.rs:227 -> commitment.rs:58-89):
+ *     out_i = from_be_bytes_mod_order(SHA3-256(to_bytes(points_i) || to_bytes_be(blinders_i))).  n independent one-block
+ *     hashes, so unlike arkmpc_commit_sha3 this runs entirely on the GPU.  blinders / out: n Scalars (same space as points). */
+int arkmpc_commit_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* blinders,
+                              uint64_t* out_commitments);
 /* all(mine_i + peer_i == identity) (authenticated_curve.rs:127-131), per element: out_ok[i] in {0,1} (host or device per mode) */
 int arkmpc_point_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok);
 

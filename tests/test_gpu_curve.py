@@ -132,3 +132,20 @@ def test_point_open_authenticated(hip, oracle):
     bad[0][24 * 2 + 12:24 * 3] = jac([pyref.g1_mul(pyref.G, 999)], [1])
     _, ok = checks(bad)
     assert ok.tolist() == [1, 1, 0, 1, 1, 1]
+
+
+def test_point_commitments_on_gpu(hip, oracle):
+    """K9 vs the oracle's commit over to_bytes(point) || BE(blinder) (commitment.rs:71-86 with one value), incl. the identity."""
+    n = 33
+    pts, P = random_points(n, 21)
+    bl = mont_array(0, rand_values(0, n, 22))
+    out = np.zeros(4 * n, dtype=np.uint64)
+    hip.eng(0).commit_points_sha3(n, P, bl, out)
+    comp = oracle.g1_to_bytes(P).tobytes()
+    for i in range(n):
+        want = oracle.commit_bytes(0, comp[32 * i:32 * i + 32], bl[4 * i:4 * i + 4].copy())
+        assert np.array_equal(out[4 * i:4 * i + 4], want), i
+    # and against hashlib directly for one element
+    import hashlib
+    h = hashlib.sha3_256(pyref.g1_compress(pts[0]) + pyref.to_bytes_be(0, pyref.from_mont(0, limbs_to_ints(bl[:4])[0]))).digest()
+    assert pyref.from_mont(0, limbs_to_ints(out[:4])[0]) == int.from_bytes(h, "big") % pyref.P[0]
