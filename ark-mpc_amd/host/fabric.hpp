@@ -253,6 +253,18 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         if (party_ == sender) { ScalarBatch b = allocate_scalars(mont); send_values(b); return b; }
         (void)n; return receive_values();
     }
+    // point payloads travel as 12 x u64 per point packed into the scalar-vector payload (NetworkPayload::PointBatch, network.rs:45-60)
+    template <class PB> PB exchange_points(const PB& mine) {
+        std::vector<uint64_t> h = mine.to_host();
+        std::vector<Scalar> pay(3 * mine.n);
+        std::memcpy(pay.data(), h.data(), h.size() * 8);
+        NetworkOutbound got;
+        if (party_ == PARTY0) { net_->send(NetworkOutbound{next_id_++, std::move(pay)}); got = net_->receive(); next_id_++; }
+        else { got = net_->receive(); next_id_++; net_->send(NetworkOutbound{next_id_++, std::move(pay)}); }
+        PB r; r.n = mine.n; r.buf = DeviceBuf(eng_, 12 * (mine.n ? mine.n : 1));
+        r.buf.upload(got.payload.data(), mine.n * 96);
+        return r;
+    }
     void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c);  // fabric.rs:894-915
     // fabric.rs:578-600
     AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
@@ -374,6 +386,121 @@ class AuthenticatedScalarBatch {
         (half ? h.at(idx).mac : h.at(idx).share) = v;
         buf.upload(h.data(), n * 64);
     }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Points: CurvePointResult batches and AuthenticatedPointResult batches (BN254 G1, 12 / 24 x u64 per element)
+// ---------------------------------------------------------------------------------------------------------------
+struct PointBatch {   // Vec<CurvePointResult<C>>: n public Jacobian points on the GPU
+    size_t n = 0;
+    DeviceBuf buf;
+    std::vector<uint64_t> to_host() const { std::vector<uint64_t> v(12 * n); buf.download(v.data(), n * 96); return v; }
+};
+struct PointOpenResult {   // AuthenticatedPointOpenResult (authenticated_curve.rs:286-322), one MAC-check flag per element
+    std::vector<uint8_t> ok;     // 1 = commitment opened correctly and MAC shares sum to the identity
+    PointBatch value;
+    MpcError err() const { for (auto b : ok) if (!b) return MpcError::AuthenticationError; return MpcError::None; }
+};
+
+class AuthenticatedPointBatch {
+  public:
+    size_t n = 0;
+    DeviceBuf buf;
+    std::shared_ptr<MpcFabric> fabric;
+    static AuthenticatedPointBatch alloc(const std::shared_ptr<MpcFabric>& f, size_t n) {
+        AuthenticatedPointBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), 24 * (n ? n : 1)); return r;
+    }
+    static PointBatch alloc_points(const std::shared_ptr<MpcFabric>& f, size_t n) {
+        PointBatch r; r.n = n; r.buf = DeviceBuf(f->engine(), 12 * (n ? n : 1)); return r;
+    }
+    // ---- linear ops (authenticated_curve.rs:396-621) ----
+    static AuthenticatedPointBatch batch_add(const AuthenticatedPointBatch& a, const AuthenticatedPointBatch& b) {   // :396-426
+        auto r = alloc(a.fabric, a.n); check(c(a), arkmpc_pointshare_add(c(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_add"); return r;
+    }
+    static AuthenticatedPointBatch batch_sub(const AuthenticatedPointBatch& a, const AuthenticatedPointBatch& b) {   // :520-550
+        auto r = alloc(a.fabric, a.n); check(c(a), arkmpc_pointshare_sub(c(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_sub"); return r;
+    }
+    static AuthenticatedPointBatch batch_neg(const AuthenticatedPointBatch& a) {                                     // :604-621
+        auto r = alloc(a.fabric, a.n); check(c(a), arkmpc_pointshare_neg(c(a), a.n, a.buf.ptr(), r.buf.ptr()), "pointshare_neg"); return r;
+    }
+    static AuthenticatedPointBatch batch_add_public(const AuthenticatedPointBatch& a, const PointBatch& b) {         // :429-463
+        auto r = alloc(a.fabric, a.n);
+        check(c(a), arkmpc_pointshare_add_public(c(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_add_public");
+        return r;
+    }
+    static AuthenticatedPointBatch batch_mul_public(const ScalarBatch& s, const AuthenticatedPointBatch& b) {        // :718-751
+        auto r = alloc(b.fabric, b.n); check(c(b), arkmpc_pointshare_mul_public(c(b), b.n, b.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "pointshare_mul_public"); return r;
+    }
+    static AuthenticatedPointBatch batch_mul_generator(const AuthenticatedScalarBatch& a) {                           // :754-780
+        auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), arkmpc_scalarshare_mul_generator(a.fabric->ctx(), a.n, a.buf.ptr(), r.buf.ptr()), "mul_generator"); return r;
+    }
+    // CurvePointResult::batch_mul (curve.rs:459-479) and batch_mul_authenticated (curve.rs:483-517)
+    static PointBatch point_batch_mul(const std::shared_ptr<MpcFabric>& f, const ScalarBatch& s, const PointBatch& p) {
+        auto r = alloc_points(f, p.n); check(f->ctx(), arkmpc_g1_scalar_mul(f->ctx(), p.n, p.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "g1_scalar_mul"); return r;
+    }
+    static AuthenticatedPointBatch batch_mul_authenticated(const AuthenticatedScalarBatch& a, const PointBatch& p) {
+        auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), arkmpc_scalarshare_mul_point(a.fabric->ctx(), a.n, a.buf.ptr(), p.buf.ptr(), r.buf.ptr()), "scalarshare_mul_point"); return r;
+    }
+    // ---- opening (:66-109) ----
+    PointBatch open_batch() const {
+        auto f = fabric;
+        PointBatch mine = alloc_points(f, n);
+        if (n == 0) return mine;
+        check(f->ctx(), arkmpc_pointshare_extract(f->ctx(), n, buf.ptr(), mine.buf.ptr()), "pointshare_extract");
+        PointBatch peer = f->exchange_points(mine);
+        PointBatch out = alloc_points(f, n);
+        check(f->ctx(), arkmpc_g1_add(f->ctx(), n, mine.buf.ptr(), peer.buf.ptr(), out.buf.ptr()), "g1_add");
+        return out;
+    }
+    // :190-283 -- per-element commitments (n separate SHA3 commits, :227), three exchanges, per-element verification
+    PointOpenResult open_authenticated_batch(const std::vector<Scalar>& blinders_mont) const {
+        PointOpenResult res;
+        auto f = fabric;
+        if (n == 0) return res;
+        arkmpc_ctx* cx = f->ctx();
+        PointBatch opened = open_batch();
+        PointBatch chk = alloc_points(f, n);                                                       // value*mac_key - mac (:215-220)
+        check(cx, arkmpc_point_mac_check_shares(cx, n, f->mac_key().l, opened.buf.ptr(), buf.ptr(), chk.buf.ptr()), "point_mac_check_shares");
+        ScalarBatch bl = f->allocate_scalars(blinders_mont);
+        ScalarBatch comm; comm.n = n; comm.buf = DeviceBuf(f->engine(), 4 * n);
+        check(cx, arkmpc_commit_points_sha3(cx, n, chk.buf.ptr(), bl.buf.ptr(), comm.buf.ptr()), "commit_points_sha3");
+        ScalarBatch peer_comm = f->exchange_values(comm);                                          // commitments
+        PointBatch peer_chk = f->exchange_points(chk);                                             // MAC-check points
+        ScalarBatch peer_bl = f->exchange_values(bl);                                              // blinders
+        ScalarBatch recomputed; recomputed.n = n; recomputed.buf = DeviceBuf(f->engine(), 4 * n);
+        check(cx, arkmpc_commit_points_sha3(cx, n, peer_chk.buf.ptr(), peer_bl.buf.ptr(), recomputed.buf.ptr()), "commit_points_sha3(verify)");
+        DeviceBuf okd(f->engine(), (n + 7) / 8 + 1);
+        check(cx, arkmpc_point_mac_verify(cx, n, chk.buf.ptr(), peer_chk.buf.ptr(), reinterpret_cast<uint8_t*>(okd.ptr())), "point_mac_verify");
+        res.ok.resize(n);
+        okd.download(res.ok.data(), n);
+        std::vector<Scalar> rc = recomputed.to_host(), pc = peer_comm.to_host();
+        for (size_t i = 0; i < n; ++i) if (std::memcmp(rc[i].l, pc[i].l, 32) != 0) res.ok[i] = 0;  // verify_mac_check (:112-138)
+        res.value = std::move(opened);
+        return res;
+    }
+    // ---- Beaver point x shared-scalar multiplication (:682-714): [x * yG] = deG + d[bG] + [a]eG + [c]G ----
+    static AuthenticatedPointBatch batch_mul(const AuthenticatedScalarBatch& a, const AuthenticatedPointBatch& b) {
+        const size_t n = a.n;
+        auto f = a.fabric;
+        if (n == 0) return alloc(f, 0);
+        AuthenticatedScalarBatch ta, tb, tc;
+        f->next_triple_batch(n, ta, tb, tc);
+        AuthenticatedPointBatch beaver_b_gen = batch_mul_generator(tb);                           // :696
+        AuthenticatedScalarBatch masked_rhs = AuthenticatedScalarBatch::batch_sub(a, ta);          // :698
+        AuthenticatedPointBatch masked_lhs = batch_sub(b, beaver_b_gen);                           // :699
+        PointBatch eG_open = masked_lhs.open_batch();                                              // :701
+        ScalarBatch d_open = masked_rhs.open_batch();                                              // :702
+        PointBatch deG = point_batch_mul(f, d_open, eG_open);                                      // :705
+        AuthenticatedPointBatch dbG = batch_mul_public(d_open, beaver_b_gen);                      // :706
+        AuthenticatedPointBatch aeG = batch_mul_authenticated(ta, eG_open);                        // :707
+        AuthenticatedPointBatch cG = batch_mul_generator(tc);                                      // :708
+        AuthenticatedPointBatch de_db_G = batch_add_public(dbG, deG);                              // :710
+        AuthenticatedPointBatch ae_c_G = batch_add(aeG, cG);                                       // :711
+        return batch_add(de_db_G, ae_c_G);                                                         // :713
+    }
+
+  private:
+    static arkmpc_ctx* c(const AuthenticatedPointBatch& a) { return a.fabric->ctx(); }
 };
 
 inline AuthenticatedScalarBatch MpcFabric::allocate_scalar_shares(const std::vector<ScalarShare>& s) {

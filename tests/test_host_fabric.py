@@ -86,3 +86,25 @@ def test_open_authenticated_detects_corruption(tmp_path, flag):
 def test_empty_batch(tmp_path):
     res = run(tmp_path, "batch_mul", 0, [], [])
     assert res[0] == (0, []) and res[1] == (0, [])
+
+
+@pytest.mark.gpu
+def test_point_beaver_mul_and_authenticated_open(tmp_path):
+    """authenticated_curve.rs test_batch_mul (:1222-1244) restated: open(batch_mul([x], [y]G)) == (x*y) G for both parties,
+    with the per-element commitment + MAC check passing; then one corrupted MAC point is caught for exactly that element."""
+    fid, n = 0, 12
+    r = pyref.RORD
+    x, y = [0, 1, r - 1] + rand_values(fid, n - 3, 41), [5, 7, 2] + rand_values(fid, n - 3, 42)
+    want = b"".join(pyref.g1_compress(pyref.g1_mul(pyref.G, (u * v) % r)) for u, v in zip(x, y))
+    for flags, fails in (((), 0), (("--bad-mac",), 1)):
+        inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+        inp.write_bytes(ints_to_limbs(x).tobytes() + ints_to_limbs(y).tobytes())
+        rr = subprocess.run([EXE, "point_mul", str(fid), str(n), str(inp), str(outp), *flags], capture_output=True, text=True, timeout=600)
+        assert rr.returncode == 0, rr.stderr
+        raw = outp.read_bytes()
+        off = 0
+        for party in range(2):
+            nfail = struct.unpack_from("<Q", raw, off)[0]; off += 8
+            got = raw[off:off + 32 * n]; off += 32 * n
+            assert nfail == fails
+            assert got == want          # opening is unaffected by a corrupted MAC
