@@ -178,6 +178,7 @@ class PreprocessingPhase {
     virtual std::pair<std::vector<Scalar>, std::vector<ScalarShare>> next_local_input_mask_batch(size_t n) = 0;
     virtual std::vector<ScalarShare> next_counterparty_input_mask_batch(size_t n) = 0;
     virtual void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) = 0;
+    virtual std::vector<ScalarShare> next_shared_value_batch(size_t n) = 0;                       // offline_prep.rs:45-50
 };
 // offline_prep.rs:88-170: a = 2, b = 3, c = 6 statically split; MAC key share = party id
 class PartyIDBeaverSource : public PreprocessingPhase {
@@ -201,6 +202,10 @@ class PartyIDBeaverSource : public PreprocessingPhase {
         else { ta.share = s_[1]; tb.share = s_[0]; tc.share = s_[4]; }
         ta.mac = s_[k * 2]; tb.mac = s_[k * 3]; tc.mac = s_[k * 6];
         a.assign(n, ta); b.assign(n, tb); c.assign(n, tc);
+    }
+
+    std::vector<ScalarShare> next_shared_value_batch(size_t n) override {                       // :166-168: (party_id, party_id)
+        return std::vector<ScalarShare>(n, ScalarShare{s_[party_], s_[party_]});
     }
 
   private:
@@ -266,6 +271,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         return r;
     }
     void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c);  // fabric.rs:894-915
+    AuthenticatedScalarBatch random_shared_scalars(size_t n);                                    // fabric.rs:917-928
     // fabric.rs:578-600
     AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
     AuthenticatedScalarBatch allocate_scalar_shares(const std::vector<ScalarShare>& s);
@@ -334,6 +340,18 @@ class AuthenticatedScalarBatch {
         check(f->ctx(), arkmpc_beaver_finish_fused(f->ctx(), n, (int)f->party_id(), f->mac_key().l, my_de.buf.ptr(), peer_de.buf.ptr(),
                                                    ta.buf.ptr(), tb.buf.ptr(), tc.buf.ptr(), r.buf.ptr()), "beaver_finish_fused");
         return r;
+    }
+    // ---- inversion (:55-82): mask with a shared random r, open authenticated, invert in public, multiply back ----
+    static AuthenticatedScalarBatch batch_inverse(const AuthenticatedScalarBatch& values, const Scalar& blinder, MpcError* err = nullptr) {
+        if (values.n == 0) throw std::invalid_argument("cannot invert empty batch of scalars");   // assert! :60
+        auto f = values.fabric;
+        AuthenticatedScalarBatch r = f->random_shared_scalars(values.n);                           // step 1
+        AuthenticatedScalarBatch masked = batch_mul(values, r);                                    // step 2: m_i = r_i * x_i
+        AuthenticatedOpenResult opened = masked.open_authenticated_batch(blinder);
+        if (err) *err = opened.err;
+        ScalarBatch inv; inv.n = values.n; inv.buf = DeviceBuf(f->engine(), 4 * values.n);         // step 3: ScalarResult::batch_inverse
+        check(f->ctx(), arkmpc_scalar_batch_inverse(f->ctx(), values.n, opened.value.buf.ptr(), inv.buf.ptr()), "scalar_batch_inverse");
+        return batch_mul_public(r, inv);                                                           // step 4: m_i^-1 * r_i = x_i^-1
     }
     // ---- opening (:129-172, :278-354) -----------------------------------------------------------------------
     ScalarBatch open_batch() const {
@@ -514,6 +532,11 @@ inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, 
     if (ha.size() != n || hb.size() != n || hc.size() != n) throw std::runtime_error("preprocessing exhausted");   // structs.rs:189 asserts
     next_id_ += 3 * n;
     a = allocate_scalar_shares(ha); b = allocate_scalar_shares(hb); c = allocate_scalar_shares(hc);
+}
+inline AuthenticatedScalarBatch MpcFabric::random_shared_scalars(size_t n) {
+    std::vector<ScalarShare> v = prep_->next_shared_value_batch(n);
+    next_id_ += n;
+    return allocate_scalar_shares(v);
 }
 // fabric.rs:578-600: the sender broadcasts val - mask; both sides do mask_share.add_public(masked)
 inline AuthenticatedScalarBatch MpcFabric::batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender) {

@@ -60,6 +60,10 @@ int main(int argc, char** argv) {
                 auto x = AuthenticatedScalarBatch::batch_mul_public(w, pa);
                 auto y = AuthenticatedScalarBatch::batch_add_public(x, pa);
                 res = AuthenticatedScalarBatch::batch_sub_public(y, pb);                  // -(a^2-b^2)*a + a - b
+            } else if (scenario == "inverse") {
+                // AuthenticatedScalarResult::batch_inverse (authenticated_scalar.rs:55-82, test :1640-1660): open(inverse(x)) == x^-1
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                res = AuthenticatedScalarBatch::batch_inverse(a, eng.from_u64(777 + fabric->party_id()));
             } else if (scenario == "point_mul") {
                 // AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714, test :1222-1244): share x, share y,
                 // Y = [y]G, Z = batch_mul(x, Y), open_authenticated; out = compressed points of Z  (expected (x*y) G)

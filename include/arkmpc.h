@@ -80,6 +80,9 @@ int arkmpc_scalar_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64
 int arkmpc_scalar_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
 int arkmpc_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out); /* ScalarResult::batch_mul, scalar_result.rs:257-278 */
 int arkmpc_scalar_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
+/* Scalar::batch_inverse / ScalarResult::batch_inverse (scalar.rs:93-100, scalar_result.rs:50-61): non-zero elements are
+ * replaced by their inverses, zeros stay zero (ark_ff::batch_inversion).  In-place allowed. */
+int arkmpc_scalar_batch_inverse(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
 /* canonical little-endian integers (< 2^256, reduced mod p on the way in) <-> Montgomery form */
 int arkmpc_scalar_from_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);
 int arkmpc_scalar_to_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);

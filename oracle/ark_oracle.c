@@ -175,6 +175,14 @@ void ora_scalar_batch_mul(int fid, size_t n, const u64* a, const u64* b, u64* ou
     const ora_field* f = ora_get_field(fid);
     for (size_t i = 0; i < n; ++i) ora_fp_mul(f, a + 4 * i, b + 4 * i, out + 4 * i);
 }
+/* scalar.rs:93-100 -> ark_ff::batch_inversion: non-zero elements inverted, zeros unchanged */
+void ora_scalar_batch_inverse(int fid, size_t n, const u64* a, u64* out) {
+    const ora_field* f = ora_get_field(fid);
+    for (size_t i = 0; i < n; ++i) {
+        if (is_zero4(a + 4 * i)) memset(out + 4 * i, 0, 32);
+        else ora_fp_inv(f, a + 4 * i, out + 4 * i);
+    }
+}
 void ora_scalar_batch_neg(int fid, size_t n, const u64* a, u64* out) {
     const ora_field* f = ora_get_field(fid);
     for (size_t i = 0; i < n; ++i) ora_fp_neg(f, a + 4 * i, out + 4 * i);

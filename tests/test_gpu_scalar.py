@@ -279,3 +279,15 @@ def test_hand_scheduled_finish_matches_cpp_kernel_at_scale(pkg, oracle, fid, lay
             want = oracle.beaver_finish(fid, party, key, sl4(opened[:4 * n]), sl4(opened[4 * n:]), sl8(aos["a"]), sl8(aos["b"]), sl8(aos["c"]))
             assert np.array_equal(sl8(ref), want)
     e.close()
+
+
+@pytest.mark.parametrize("fid", FIDS)
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 1000])
+def test_batch_inverse(engines, oracle, fid, n):
+    a = mont_array(fid, mixed_values(fid, n, seed=3 * n + fid))      # zeros included
+    out = _z(n, 4); engines[fid].scalar_batch_inverse(n, a, out)
+    assert np.array_equal(out, oracle.scalar_batch_inverse(fid, a))
+    prod = _z(n, 4); engines[fid].scalar_mul(n, a, out, prod)         # a * a^-1 == 1 (or 0)
+    one = mont_array(fid, [1])
+    for i in range(n):
+        assert np.array_equal(prod[4 * i:4 * i + 4], one) or not a[4 * i:4 * i + 4].any()

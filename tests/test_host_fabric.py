@@ -108,3 +108,15 @@ def test_point_beaver_mul_and_authenticated_open(tmp_path):
             got = raw[off:off + 32 * n]; off += 32 * n
             assert nfail == fails
             assert got == want          # opening is unaffected by a corrupted MAC
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fid", [0, 2])
+def test_batch_inverse_protocol(tmp_path, fid):
+    """authenticated_scalar.rs:55-82: two-round inversion via a shared random mask; open(inverse(x)) == x^-1 mod p."""
+    n = 65
+    p = pyref.P[fid]
+    a = [v for v in mixed_values(fid, n + 5, 51) if v != 0][:n]
+    res = run(tmp_path, "inverse", fid, a, a)
+    want = [pow(v, -1, p) for v in a]
+    assert res[0] == (0, want) and res[1] == (0, want)

@@ -82,3 +82,11 @@ def test_commitment_vs_hashlib(oracle, fid):
     blinder = 0x1234567890abcdef1234567890abcdef % pyref.P[fid]
     got = oracle.commit_scalars(fid, mont_array(fid, vals), mont_array(fid, [blinder]))
     assert pyref.from_mont(fid, limbs_to_ints(got)[0]) == pyref.commit(fid, vals, blinder)
+
+
+@pytest.mark.parametrize("fid", FIDS)
+def test_batch_inverse_vs_bigint(oracle, fid):
+    p = pyref.P[fid]
+    vals = mixed_values(fid, 50, seed=9)            # includes 0, which must stay 0 (ark_ff::batch_inversion)
+    got = from_mont_array(fid, oracle.scalar_batch_inverse(fid, mont_array(fid, vals)))
+    assert got == [0 if v == 0 else pow(v, -1, p) for v in vals]
