@@ -149,3 +149,18 @@ def test_point_commitments_on_gpu(hip, oracle):
     import hashlib
     h = hashlib.sha3_256(pyref.g1_compress(pts[0]) + pyref.to_bytes_be(0, pyref.from_mont(0, limbs_to_ints(bl[:4])[0]))).digest()
     assert pyref.from_mont(0, limbs_to_ints(out[:4])[0]) == int.from_bytes(h, "big") % pyref.P[0]
+
+
+def test_glv_scalar_mul_many_scalars(hip, oracle):
+    """GLV decomposition robustness: 1500 random scalars plus values around lambda, r/2, r/3 and powers of two, against the
+    oracle's plain double-and-add (affine comparison) -- and the two device algorithms agree with each other."""
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    r = pyref.RORD
+    special = [0, 1, 2, 15, 16, r - 1, r - 2, lam, lam - 1, lam + 1, r - lam, r // 2, r // 2 + 1, r // 3, (1 << 127), (1 << 128) - 1, 1 << 128, (1 << 253)]
+    ks = special + rand_values(0, 1500 - len(special), 77)
+    n = len(ks)
+    pts, P = random_points(n, 78, with_identity=True)
+    S = mont_array(0, ks)
+    got = hip.g1_batch_scalar_mul(P, S)
+    want = oracle.g1_batch_scalar_mul(P, S)
+    assert affine_equal(hip, oracle, got, want)
