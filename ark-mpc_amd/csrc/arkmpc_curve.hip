@@ -11,7 +11,19 @@
 // These kernels are integer-ALU bound (a scalar-mul is ~6k Fq multiplications against 128 B of
 // traffic), one thread per point.
 #include "arkmpc_internal.hpp"
+#include "fp_asm.cuh"
 #include <cstdlib>
+
+// Fq multiplication used by the point formulas.  Default: the plain C++ core.  -DARKMPC_EC_ASM switches to the
+// hand-scheduled block (fe_mul_fast): bit-identical (the curve tests pass with it) but MEASURED SLOWER here -- config 4
+// 15.3 ms vs 14.2 ms -- because its 35 fixed temporaries on top of the formulas' ~10 live field elements push the
+// functions into spills and one wave per SIMD.  It pays only once a whole point operation owns its register file.
+#ifdef ARKMPC_EC_ASM
+#define FQ_MUL(a, b) fe_mul_fast<F_BN254_FQ>(a, b)
+#else
+#define FQ_MUL(a, b) fe_mul<F_BN254_FQ>(a, b)
+#endif
+#define FQ_SQR(a) FQ_MUL(a, a)
 
 #define TPB_EC 128
 constexpr int FQ = F_BN254_FQ;
@@ -56,25 +68,25 @@ __device__ __forceinline__ G1 g1_neg(const G1& a) {
 }
 // dbl-2009-l (a = 0).  z = 0 in -> z = 0 out, so the identity needs no branch.
 __device__ __noinline__ G1 g1_double(const G1& p) {
-    Fe A = fe_sqr<FQ>(p.x), B = fe_sqr<FQ>(p.y), C = fe_sqr<FQ>(B);
-    Fe t = fe_sqr<FQ>(fe_add<FQ>(p.x, B));
+    Fe A = FQ_SQR(p.x), B = FQ_SQR(p.y), C = FQ_SQR(B);
+    Fe t = FQ_SQR(fe_add<FQ>(p.x, B));
     Fe D = fe_dbl<FQ>(fe_sub<FQ>(fe_sub<FQ>(t, A), C));
     Fe E = fe_add<FQ>(fe_dbl<FQ>(A), A);
-    Fe Fq_ = fe_sqr<FQ>(E);
+    Fe Fq_ = FQ_SQR(E);
     G1 r;
     r.x = fe_sub<FQ>(Fq_, fe_dbl<FQ>(D));
     Fe C8 = fe_dbl<FQ>(fe_dbl<FQ>(fe_dbl<FQ>(C)));
-    r.y = fe_sub<FQ>(fe_mul<FQ>(E, fe_sub<FQ>(D, r.x)), C8);
-    r.z = fe_dbl<FQ>(fe_mul<FQ>(p.y, p.z));
+    r.y = fe_sub<FQ>(FQ_MUL(E, fe_sub<FQ>(D, r.x)), C8);
+    r.z = fe_dbl<FQ>(FQ_MUL(p.y, p.z));
     return r;
 }
 // add-2007-bl with the exceptional cases of the group law handled explicitly
 // (identity operands, P + P, P + (-P)), as ark-ec's `Projective += Projective` does.
 __device__ __noinline__ G1 g1_add(const G1& p, const G1& q) {
     const bool pinf = fe_is_zero(p.z), qinf = fe_is_zero(q.z);
-    Fe Z1Z1 = fe_sqr<FQ>(p.z), Z2Z2 = fe_sqr<FQ>(q.z);
-    Fe U1 = fe_mul<FQ>(p.x, Z2Z2), U2 = fe_mul<FQ>(q.x, Z1Z1);
-    Fe S1 = fe_mul<FQ>(fe_mul<FQ>(p.y, q.z), Z2Z2), S2 = fe_mul<FQ>(fe_mul<FQ>(q.y, p.z), Z1Z1);
+    Fe Z1Z1 = FQ_SQR(p.z), Z2Z2 = FQ_SQR(q.z);
+    Fe U1 = FQ_MUL(p.x, Z2Z2), U2 = FQ_MUL(q.x, Z1Z1);
+    Fe S1 = FQ_MUL(FQ_MUL(p.y, q.z), Z2Z2), S2 = FQ_MUL(FQ_MUL(q.y, p.z), Z1Z1);
     Fe H = fe_sub<FQ>(U2, U1);
     Fe rr = fe_dbl<FQ>(fe_sub<FQ>(S2, S1));
     G1 out;
@@ -82,13 +94,13 @@ __device__ __noinline__ G1 g1_add(const G1& p, const G1& q) {
         if (fe_is_zero(rr)) return g1_double(p);
         return g1_identity();
     }
-    Fe I = fe_sqr<FQ>(fe_dbl<FQ>(H));
-    Fe J = fe_mul<FQ>(H, I);
-    Fe V = fe_mul<FQ>(U1, I);
-    out.x = fe_sub<FQ>(fe_sub<FQ>(fe_sqr<FQ>(rr), J), fe_dbl<FQ>(V));
-    out.y = fe_sub<FQ>(fe_mul<FQ>(rr, fe_sub<FQ>(V, out.x)), fe_dbl<FQ>(fe_mul<FQ>(S1, J)));
-    Fe zz = fe_sub<FQ>(fe_sub<FQ>(fe_sqr<FQ>(fe_add<FQ>(p.z, q.z)), Z1Z1), Z2Z2);
-    out.z = fe_mul<FQ>(zz, H);
+    Fe I = FQ_SQR(fe_dbl<FQ>(H));
+    Fe J = FQ_MUL(H, I);
+    Fe V = FQ_MUL(U1, I);
+    out.x = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(rr), J), fe_dbl<FQ>(V));
+    out.y = fe_sub<FQ>(FQ_MUL(rr, fe_sub<FQ>(V, out.x)), fe_dbl<FQ>(FQ_MUL(S1, J)));
+    Fe zz = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(fe_add<FQ>(p.z, q.z)), Z1Z1), Z2Z2);
+    out.z = FQ_MUL(zz, H);
     out = g1_select(qinf, p, out);
     out = g1_select(pinf, q, out);
     return out;
@@ -227,7 +239,7 @@ __device__ __forceinline__ G1 g1_scalar_mul_glv(const G1& p, const Fe& s_mont, u
         }
         if (__any(d2 != 0)) {
             G1 q = g1_load(tab + ((size_t)(d2 ? d2 - 1 : 0) * nthreads + tid) * 12);
-            q.x = fe_mul<FQ>(q.x, beta);                 // phi on Jacobian coordinates: (beta X, Y, Z)
+            q.x = FQ_MUL(q.x, beta);                 // phi on Jacobian coordinates: (beta X, Y, Z)
             if (h2.neg) q.y = fe_neg<FQ>(q.y);
             G1 sum = g1_add(acc, q);
             acc = g1_select(d2 != 0, sum, acc);
@@ -260,8 +272,8 @@ __device__ __noinline__ Fe fq_inv(const Fe& a) {
         u32 w = P::P(limb);
         if (limb == 0) w -= 2u;  // p - 2 (p is odd and its low limb is > 2, so no borrow)
         for (int bit = 31; bit >= 0; --bit) {
-            acc = fe_sqr<FQ>(acc);
-            if ((w >> bit) & 1u) acc = fe_mul<FQ>(acc, a);
+            acc = FQ_SQR(acc);
+            if ((w >> bit) & 1u) acc = FQ_MUL(acc, a);
         }
     }
     return acc;
@@ -269,9 +281,9 @@ __device__ __noinline__ Fe fq_inv(const Fe& a) {
 __device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& inf) {
     inf = fe_is_zero(a.z);
     Fe zi = fq_inv(a.z);  // 0 -> 0
-    Fe zi2 = fe_sqr<FQ>(zi);
-    x = fe_mul<FQ>(a.x, zi2);
-    y = fe_mul<FQ>(a.y, fe_mul<FQ>(zi2, zi));
+    Fe zi2 = FQ_SQR(zi);
+    x = FQ_MUL(a.x, zi2);
+    y = FQ_MUL(a.y, FQ_MUL(zi2, zi));
     if (inf) { x = fe_zero<FQ>(); y = fe_zero<FQ>(); }
 }
 

@@ -23,15 +23,7 @@ struct ColOut {
     u32 stride;
 };
 
-// Hand-scheduled bodies (generated by tools/gen_asm_kernels.py; validated by its single-lane emulator and by the
-// GPU parity tests).  Fields without a body fall back to the C++ kernel below.
-template <int F> struct HasAsmFinish { static constexpr bool value = false; };
-template <int F, int NT>
-__device__ __forceinline__ void beaver_finish_asm(u32 off_de, u32 off_col, u32 off_out, const u64* my_d, const u64* my_e,
-                                                  const u64* peer_d, const u64* peer_e, const u64* a_s, const u64* a_m,
-                                                  const u64* b_s, const u64* b_m, const u64* c_s, const u64* c_m, u64* out_s,
-                                                  u64* out_m, const Fe& key, u32 mask);
-#include "asm_kernels.inc"
+#include "fp_asm.cuh"
 
 // ---------------------------------------------------------------------------------------------
 // elementwise Scalar kernels

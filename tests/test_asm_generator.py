@@ -19,6 +19,13 @@ def test_emulated_stream_matches_bigint(fid):
     assert mp["nv"] <= 128                                        # 4 waves/SIMD budget
 
 
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_single_montmul_block_matches_bigint(fid):
+    name, p = g.FIELDS[fid]
+    E, mp = g.selftest_montmul(p, trials=120, seed=fid)
+    assert E.nops <= 8 and mp["nv"] - mp["first"] == 35
+
+
 @pytest.mark.parametrize("fid", [0, 1])
 def test_h1_hazard_distance_in_final_text(fid):
     """Re-derive H1 from the emitted text alone: between a VALU that writes VCC / the second carry pair and a VALU that

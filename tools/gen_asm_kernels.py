@@ -242,7 +242,7 @@ def t_bounds(p, nprod):
     return before, t
 
 
-def montmul_sum_seq(p, prods, T, Tz, q, m, P, row0=0):
+def montmul_sum_seq(p, prods, T, Tz, q, m, P, row0=0, final_out=None):
     """Straight-line CIOS evaluation of REDC(sum_k a_k*b_k) (before the final conditional subtraction).
     T[j] is the low half of the pair Tz[j] whose high half holds 0 for the whole kernel.  Rows alternate between
     the two carry registers so that the scheduler can keep two carry chains in flight (next row's chain starts
@@ -266,9 +266,12 @@ def montmul_sum_seq(p, prods, T, Tz, q, m, P, row0=0):
         row += 1
         seq += [i_mul_lo(m, T[0], S_INV)]
         seq += [i_mad(q[j], m, P[j], Tz[j]) for j in range(8)]
-        seq += [i_addco(T[0], q[1][0], q[0][1], cy)]
-        seq += [i_addc(T[j - 1], q[j][0], q[j - 1][1], cy) for j in range(2, 8)]
-        seq += [i_addc(T[7], T[8], q[7][1], cy), i_addc(T[8], 0, Tz[8][1], cy)]   # Tz[8][1] holds 0 (src1 must be a VGPR)
+        D = final_out if (final_out is not None and r == 7) else T
+        seq += [i_addco(D[0], q[1][0], q[0][1], cy)]
+        seq += [i_addc(D[j - 1], q[j][0], q[j - 1][1], cy) for j in range(2, 8)]
+        seq += [i_addc(D[7], T[8], q[7][1], cy)]
+        if D is T:
+            seq += [i_addc(T[8], 0, Tz[8][1], cy)]   # Tz[8][1] holds 0 (src1 must be a VGPR)
     return seq, row
 
 
@@ -444,6 +447,63 @@ def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
     return E, regmap
 
 
+# ------------------------------------------------------------------------------------------------
+# single Montgomery multiplication as an inline-asm block for C++ callers (EC point formulas)
+# ------------------------------------------------------------------------------------------------
+MM_FIRST_VGPR = 32            # fixed temporaries v32..v66 (clobbered); operands are compiler-allocated ("v" constraints)
+MM_SGPR_P = ["s%d" % (21 + i) for i in range(8)]
+MM_CLOBBER_SGPRS = ["s16", "s17", "s18", "s19", "s20"] + MM_SGPR_P
+
+
+def build_montmul(p):
+    """out = a*b*R^-1 mod p as a value in [0, 2p) (all four moduli: 2p < 2^256); the caller canonicalises.
+    Operands %[a0..a7], %[b0..b7] (inputs) and %[o0..o7] (early-clobber outputs) are chosen by the compiler."""
+    global JUNK, S_INV, CY2
+    saved = (JUNK, S_INV, CY2)
+    JUNK, S_INV, CY2 = "s[16:17]", "s20", "s[18:19]"
+    try:
+        rg = Regs(MM_FIRST_VGPR)
+        Tz = [rg.pair() for _ in range(9)]
+        T = [t[0] for t in Tz]
+        q = [rg.pair() for _ in range(8)]
+        m = rg.one()
+        nv = rg.next
+        a = ["%%[a%d]" % i for i in range(8)]
+        b = ["%%[b%d]" % i for i in range(8)]
+        o = ["%%[o%d]" % i for i in range(8)]
+        E = Emitter()
+        E.raw("s_nop 1")
+        E.raw("s_mov_b32 %s, 0x%08x" % (S_INV, (-pow(p, -1, 1 << 32)) & M32), "smov", (S_INV, (-pow(p, -1, 1 << 32)) & M32))
+        for j in range(8):
+            E.raw("s_mov_b32 %s, 0x%08x" % (MM_SGPR_P[j], (p >> (32 * j)) & M32), "smov", (MM_SGPR_P[j], (p >> (32 * j)) & M32))
+        seq = [i_mov(t[1], 0) for t in Tz]
+        mm, _ = montmul_sum_seq(p, [(a, b)], T, Tz, q, m, MM_SGPR_P, 0, final_out=o)
+        E.schedule(seq + mm)
+        bound = ((p - 1) * (p - 1) + (R - 1) * p) // R + 1
+        assert bound < 2 * p and 2 * p < R
+        return E, dict(first=MM_FIRST_VGPR, nv=nv, a=a, b=b, o=o)
+    finally:
+        JUNK, S_INV, CY2 = saved
+
+
+def selftest_montmul(p, trials=200, seed=3):
+    rng = random.Random(seed)
+    E, mp = build_montmul(p)
+    Rinv = pow(R, -1, p)
+    edge = [0, 1, p - 1, p - 2, R % p, (p + 1) // 2, (1 << 255) % p]
+    for t in range(trials):
+        x = rng.choice(edge) if t < 30 else rng.randrange(p)
+        y = rng.choice(edge) if t < 15 else rng.randrange(p)
+        em = Emu()
+        for i in range(8):
+            em.s[mp["a"][i]] = (x >> (32 * i)) & M32
+            em.s[mp["b"][i]] = (y >> (32 * i)) & M32
+        em.run(E.order)
+        got = sum(em.v[mp["o"][i]] << (32 * i) for i in range(8))
+        assert got < 2 * p and got % p == x * y * Rinv % p, (hex(p), t)
+    return E, mp
+
+
 def selftest_finish(p, trials=40, seed=1):
     rng = random.Random(seed)
     E, mp = build_beaver_finish(p, key_names=["s%d" % (70 + i) for i in range(8)])
@@ -510,6 +570,23 @@ def emit_header(path):
             out.append("          " + ", ".join('[k%d] "s"(key.v[%d])' % (i, i) for i in range(8)))
             out.append("        : " + ", ".join(clob) + ");")
             out.append("}")
+    # single Montgomery multiplication blocks
+    for fid, (name, p) in enumerate(FIELDS):
+        selftest_montmul(p, trials=60, seed=fid)
+        E, mp = build_montmul(p)
+        nvalu = sum(1 for i in E.order if i.op in ("mov", "mad", "mul_lo", "addco", "addc", "subco", "subb", "cnd", "and"))
+        clob = ['"vcc"'] + ['"%s"' % s_ for s_ in MM_CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mp["first"], mp["nv"])]
+        out.append("// %s: single Montgomery multiplication, %d VALU, %d H1 wait states; result in [0, 2p)" % (name, nvalu, E.nops))
+        out.append("template <> __device__ __forceinline__ Fe fe_mont_mul_asm<%d>(const Fe& a, const Fe& b) {" % fid)
+        out.append("    Fe o;")
+        out.append("    asm(")
+        out.append(c_string(E.lines))
+        out.append("        : " + ", ".join('[o%d] "=&v"(o.v[%d])' % (i, i) for i in range(8)))
+        out.append("        : " + ", ".join('[a%d] "v"(a.v[%d])' % (i, i) for i in range(8)) + ",")
+        out.append("          " + ", ".join('[b%d] "v"(b.v[%d])' % (i, i) for i in range(8)))
+        out.append("        : " + ", ".join(clob) + ");")
+        out.append("    return o;")
+        out.append("}")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
     return stats
@@ -527,6 +604,8 @@ if __name__ == "__main__":
                 print("%-14s ok: %d instrs, %d wait states, %d VGPRs" % (name, len(E.order), E.nops, mp["nv"]))
             except AssertionError as ex:
                 print("%-14s %s" % (name, ex))
+            E, mp = selftest_montmul(p)
+            print("%-14s montmul block ok: %d instrs, %d wait states, temps v%d..v%d" % (name, len(E.order), E.nops, mp["first"], mp["nv"] - 1))
         sys.exit(0)
     for s in emit_header(a.o):
         print("%-14s VALU %d  mad %d  H1 wait states %d  VGPR end %d" % s)
