@@ -67,7 +67,7 @@ __device__ __forceinline__ G1 g1_neg(const G1& a) {
     return r;
 }
 // dbl-2009-l (a = 0).  z = 0 in -> z = 0 out, so the identity needs no branch.
-__device__ __noinline__ G1 g1_double(const G1& p) {
+__device__ __noinline__ G1 g1_double(G1 p) {
     Fe A = FQ_SQR(p.x), B = FQ_SQR(p.y), C = FQ_SQR(B);
     Fe t = FQ_SQR(fe_add<FQ>(p.x, B));
     Fe D = fe_dbl<FQ>(fe_sub<FQ>(fe_sub<FQ>(t, A), C));
@@ -82,7 +82,7 @@ __device__ __noinline__ G1 g1_double(const G1& p) {
 }
 // add-2007-bl with the exceptional cases of the group law handled explicitly
 // (identity operands, P + P, P + (-P)), as ark-ec's `Projective += Projective` does.
-__device__ __noinline__ G1 g1_add(const G1& p, const G1& q) {
+__device__ __noinline__ G1 g1_add(G1 p, G1 q) {
     const bool pinf = fe_is_zero(p.z), qinf = fe_is_zero(q.z);
     Fe Z1Z1 = FQ_SQR(p.z), Z2Z2 = FQ_SQR(q.z);
     Fe U1 = FQ_MUL(p.x, Z2Z2), U2 = FQ_MUL(q.x, Z1Z1);
