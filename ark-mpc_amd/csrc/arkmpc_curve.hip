@@ -376,6 +376,35 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_to_bytes(size_t n, const u64* pts
 }
 
 // ---------------------------------------------------------------------------------------------
+// Point sums: the reduction gate of AuthenticatedPointResult::msm (authenticated_curve.rs:796-805) and
+// PointShare's Sum (curve/share.rs:85-92).  Two launches: every thread folds a strided slice of the n points, then one
+// workgroup tree-reduces the partial sums through LDS (256 x 96 B).  `lanes` independent sums are computed at once
+// (2 for PointShares: share column and MAC column), selected by blockIdx.y.
+// ---------------------------------------------------------------------------------------------
+#define SUM_TPB 256
+__global__ void __launch_bounds__(SUM_TPB) k_g1_partial_sum(size_t n, const u64* pts, u32 stride, u32 lane_off, u64* partial, u32 nthreads) {
+    const u32 lane = blockIdx.y;
+    const u32 t = blockIdx.x * SUM_TPB + threadIdx.x;
+    if (t >= nthreads) return;
+    G1 acc = g1_identity();
+    for (size_t i = t; i < n; i += nthreads) acc = g1_add(acc, g1_load(pts + (size_t)stride * i + (size_t)lane_off * lane));
+    g1_store(partial + ((size_t)lane * nthreads + t) * 12, acc);
+}
+__global__ void __launch_bounds__(SUM_TPB) k_g1_final_sum(const u64* partial, u32 nthreads, u64* out) {
+    __shared__ u64 sm[SUM_TPB * 12];
+    const u32 lane = blockIdx.y, t = threadIdx.x;
+    G1 acc = g1_identity();
+    for (u32 i = t; i < nthreads; i += SUM_TPB) acc = g1_add(acc, g1_load(partial + ((size_t)lane * nthreads + i) * 12));
+    g1_store(sm + 12 * t, acc);
+    __syncthreads();
+    for (u32 s = SUM_TPB / 2; s > 0; s >>= 1) {
+        if (t < s) g1_store(sm + 12 * t, g1_add(g1_load(sm + 12 * t), g1_load(sm + 12 * (t + s))));
+        __syncthreads();
+    }
+    if (t == 0) g1_store(out + 12 * lane, g1_load(sm));
+}
+
+// ---------------------------------------------------------------------------------------------
 // K9: per-element hash commitments to points -- HashCommitmentResult::commit on each MAC-check point
 // (authenticated_curve.rs:227 -> commitment.rs:58-89 with one value):
 //     out_i = from_be_bytes_mod_order( SHA3-256( to_bytes(P_i) || to_bytes_be(blinder_i) ) )
@@ -574,6 +603,20 @@ int arkmpc_point_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, con
                               st.out<unsigned char>(io));
     return st.finish();
 }
+static int g1_sum_impl(arkmpc_ctx* ctx, size_t n, const uint64_t* pts, u32 stride, u32 lanes, uint64_t* out) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(pts, n * stride * 8), io = st.declare_out(out, (size_t)lanes * 96);
+    const u32 nthreads = (u32)(n < 65536 ? (n ? n : 1) : 65536);
+    int iw = st.declare_scratch((size_t)lanes * nthreads * 96);
+    if (st.commit()) return st.rc;
+    hipLaunchKernelGGL(k_g1_partial_sum, dim3(blocks_for(nthreads, SUM_TPB), lanes), dim3(SUM_TPB), 0, ctx->stream, n, st.in<u64>(ip), stride, 12u,
+                       st.scratch<u64>(iw), nthreads);
+    hipLaunchKernelGGL(k_g1_final_sum, dim3(1, lanes), dim3(SUM_TPB), 0, ctx->stream, st.scratch<u64>(iw), nthreads, st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_g1_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_point) { return g1_sum_impl(ctx, n, points, 12, 1, out_point); }
+int arkmpc_pointshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share) { return g1_sum_impl(ctx, n, shares, 24, 2, out_share); }
 int arkmpc_commit_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* blinders, uint64_t* out_commitments) {
     ENTER_EC(ctx);
     Stage st(ctx);

@@ -517,6 +517,16 @@ class AuthenticatedPointBatch {
         return batch_add(de_db_G, ae_c_G);                                                         // :713
     }
 
+    // ---- multiscalar multiplication (:787-806): batch_mul, then one gate summing the PointShares ----
+    static AuthenticatedPointBatch msm(const AuthenticatedScalarBatch& scalars, const AuthenticatedPointBatch& points) {
+        if (scalars.n != points.n) throw std::invalid_argument("multiscalar_mul requires equal length vectors");
+        if (scalars.n == 0) throw std::invalid_argument("multiscalar_mul requires non-empty vectors");
+        AuthenticatedPointBatch prod = batch_mul(scalars, points);
+        AuthenticatedPointBatch r = alloc(points.fabric, 1);
+        check(c(points), arkmpc_pointshare_sum(c(points), prod.n, prod.buf.ptr(), r.buf.ptr()), "pointshare_sum");
+        return r;
+    }
+
   private:
     static arkmpc_ctx* c(const AuthenticatedPointBatch& a) { return a.fabric->ctx(); }
 };

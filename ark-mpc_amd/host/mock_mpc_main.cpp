@@ -64,29 +64,30 @@ int main(int argc, char** argv) {
                 // AuthenticatedScalarResult::batch_inverse (authenticated_scalar.rs:55-82, test :1640-1660): open(inverse(x)) == x^-1
                 auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
                 res = AuthenticatedScalarBatch::batch_inverse(a, eng.from_u64(777 + fabric->party_id()));
-            } else if (scenario == "point_mul") {
+            } else if (scenario == "point_mul" || scenario == "msm") {
                 // AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714, test :1222-1244): share x, share y,
                 // Y = [y]G, Z = batch_mul(x, Y), open_authenticated; out = compressed points of Z  (expected (x*y) G)
                 auto x = fabric->batch_share_scalar(a_m, n, PARTY0);
                 auto y = fabric->batch_share_scalar(b_m, n, PARTY1);
                 auto Y = AuthenticatedPointBatch::batch_mul_generator(y);
-                auto Z = AuthenticatedPointBatch::batch_mul(x, Y);
-                if (fabric->party_id() == PARTY0 && n && bad_mac) {          // corrupt one MAC point: make it the share point
-                    std::vector<uint64_t> h(24 * n); Z.buf.download(h.data(), n * 192);
-                    std::memcpy(&h[24 * (n / 2) + 12], &h[24 * (n / 2)], 96);
-                    Z.buf.upload(h.data(), n * 192);
+                auto Z = (scenario == "msm") ? AuthenticatedPointBatch::msm(x, Y) : AuthenticatedPointBatch::batch_mul(x, Y);
+                const size_t zn = Z.n;    // msm collapses the batch to one point
+                if (fabric->party_id() == PARTY0 && zn && bad_mac) {          // corrupt one MAC point: make it the share point
+                    std::vector<uint64_t> h(24 * zn); Z.buf.download(h.data(), zn * 192);
+                    std::memcpy(&h[24 * (zn / 2) + 12], &h[24 * (zn / 2)], 96);
+                    Z.buf.upload(h.data(), zn * 192);
                 }
-                std::vector<Scalar> bl(n);
-                for (size_t i = 0; i < n; ++i) bl[i] = eng.from_u64(1000 + 7 * i + fabric->party_id());
+                std::vector<Scalar> bl(zn);
+                for (size_t i = 0; i < zn; ++i) bl[i] = eng.from_u64(1000 + 7 * i + fabric->party_id());
                 PointOpenResult o = Z.open_authenticated_batch(bl);
                 PartyOut out;
                 out.err = 0;
-                for (size_t i = 0; i < n; ++i) if (!o.ok[i]) out.err += 1;          // number of failed MAC checks
-                out.opened.resize(n);
-                if (n) {
-                    DeviceBuf bytes(fabric->engine(), 4 * n);
-                    check(fabric->ctx(), arkmpc_g1_to_bytes(fabric->ctx(), n, o.value.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "g1_to_bytes");
-                    bytes.download(out.opened.data(), n * 32);
+                for (size_t i = 0; i < zn; ++i) if (!o.ok[i]) out.err += 1;          // number of failed MAC checks
+                out.opened.resize(zn);
+                if (zn) {
+                    DeviceBuf bytes(fabric->engine(), 4 * zn);
+                    check(fabric->ctx(), arkmpc_g1_to_bytes(fabric->ctx(), zn, o.value.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "g1_to_bytes");
+                    bytes.download(out.opened.data(), zn * 32);
                 }
                 return out;
             } else {

@@ -168,6 +168,10 @@ int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const 
 int arkmpc_scalarshare_mul_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out);      /* :754-780 */
 int arkmpc_scalarshare_mul_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, const uint64_t* points,
                                  uint64_t* out);                                                                     /* curve.rs:483-517 */
+/* sums: the reduction gate of AuthenticatedPointResult::msm (authenticated_curve.rs:796-805) / PointShare::sum
+ * (curve/share.rs:85-92).  n = 0 gives the identity.  out: ONE point (12 x u64) / ONE PointShare (24 x u64). */
+int arkmpc_g1_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_point);
+int arkmpc_pointshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share);
 /* the `.share()` projection of AuthenticatedPointResult::open_batch (:74-89): n PointShares -> n points */
 int arkmpc_pointshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points);
 /* value * mac_key - share.mac() per element (authenticated_curve.rs:215-220) */

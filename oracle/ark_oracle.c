@@ -494,6 +494,12 @@ void ora_g1_batch_scalar_mul(size_t n, const u64* pts, const u64* scalars, u64* 
 void ora_g1_batch_to_affine(size_t n, const u64* pts, u64* out_xy, unsigned char* is_inf) {
     for (size_t i = 0; i < n; ++i) is_inf[i] = (unsigned char)ora_g1_to_affine(pts + 12 * i, out_xy + 8 * i);
 }
+/* authenticated_curve.rs:796-805 / curve/share.rs:85-92: left fold of the group law */
+void ora_g1_sum(size_t n, const u64* pts, size_t stride, u64 out[12]) {
+    u64 acc[12]; ora_g1_identity(acc);
+    for (size_t i = 0; i < n; ++i) ora_g1_add(acc, pts + stride * i, acc);
+    memcpy(out, acc, 96);
+}
 /* curve/share.rs:68-105 */
 void ora_pointshare_batch_add(size_t n, const u64* a, const u64* b, u64* out) {
     for (size_t i = 0; i < n; ++i) {

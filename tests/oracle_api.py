@@ -141,6 +141,9 @@ class Oracle:
         for i in range(n):
             self.lib.ora_g1_to_bytes(self._p(pts[12 * i:12 * i + 12].copy()), ctypes.c_void_p(out.ctypes.data + 32 * i))
         return out
+    def g1_sum(self, pts, stride=12, off=0):
+        n = len(pts) // stride; out = np.zeros(12, dtype=np.uint64)
+        self.lib.ora_g1_sum(ctypes.c_size_t(n), ctypes.c_void_p(pts.ctypes.data + 8 * off), ctypes.c_size_t(stride), self._p(out)); return out
     def g1_neg(self, pts):
         n = len(pts) // 12; out = np.zeros(12 * n, dtype=np.uint64)
         for i in range(n):

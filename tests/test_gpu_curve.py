@@ -164,3 +164,20 @@ def test_glv_scalar_mul_many_scalars(hip, oracle):
     got = hip.g1_batch_scalar_mul(P, S)
     want = oracle.g1_batch_scalar_mul(P, S)
     assert affine_equal(hip, oracle, got, want)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 5000])
+def test_point_sums(hip, oracle, n):
+    """arkmpc_g1_sum / arkmpc_pointshare_sum vs the oracle's left fold (group law is associative: affine equality)."""
+    pts, P = random_points(max(n, 1), 31 + n)
+    P = np.ascontiguousarray(P[:12 * n])
+    out = np.zeros(12, dtype=np.uint64)
+    hip.eng(0).g1_sum(n, P if n else np.zeros(12, dtype=np.uint64), out)
+    want = oracle.g1_sum(P) if n else oracle.g1_identity()
+    assert affine_equal(hip, oracle, out, want)
+    if n and n % 2 == 0:
+        m = n // 2
+        out2 = np.zeros(24, dtype=np.uint64)
+        hip.eng(0).pointshare_sum(m, P, out2)
+        assert affine_equal(hip, oracle, out2[:12].copy(), oracle.g1_sum(P, stride=24, off=0))
+        assert affine_equal(hip, oracle, out2[12:].copy(), oracle.g1_sum(P, stride=24, off=12))

@@ -120,3 +120,21 @@ def test_batch_inverse_protocol(tmp_path, fid):
     res = run(tmp_path, "inverse", fid, a, a)
     want = [pow(v, -1, p) for v in a]
     assert res[0] == (0, want) and res[1] == (0, want)
+
+
+@pytest.mark.gpu
+def test_authenticated_msm(tmp_path):
+    """AuthenticatedPointResult::msm (authenticated_curve.rs:787-806): open(msm([x_i], [y_i]G)) == (sum x_i*y_i) G."""
+    fid, n = 0, 40
+    r = pyref.RORD
+    x, y = rand_values(fid, n, 61), rand_values(fid, n, 62)
+    want = pyref.g1_compress(pyref.g1_mul(pyref.G, sum(u * v for u, v in zip(x, y)) % r))
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(ints_to_limbs(x).tobytes() + ints_to_limbs(y).tobytes())
+    rr = subprocess.run([EXE, "msm", str(fid), str(n), str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stderr
+    raw = outp.read_bytes()
+    assert len(raw) == 2 * (8 + 32)
+    for party in range(2):
+        assert struct.unpack_from("<Q", raw, 40 * party)[0] == 0          # MAC check passed
+        assert raw[40 * party + 8: 40 * party + 40] == want
