@@ -170,6 +170,19 @@ __global__ void __launch_bounds__(TPB) k_share_mul_public(size_t n, const u64* a
     fe_store(out + 8 * i, fe_mul<F>(as, r));
     fe_store(out + 8 * i + 4, fe_mul<F>(am, r));
 }
+// layout converters between arkworks' AoS records and the engine-native split columns (field-independent copies)
+__global__ void __launch_bounds__(TPB) k_share_split(size_t n, const u64* aos, u64* share_col, u64* mac_col) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(share_col + 4 * i, fe_load(aos + 8 * i));
+    fe_store(mac_col + 4 * i, fe_load(aos + 8 * i + 4));
+}
+__global__ void __launch_bounds__(TPB) k_share_join(size_t n, const u64* share_col, const u64* mac_col, u64* aos) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(aos + 8 * i, fe_load(share_col + 4 * i));
+    fe_store(aos + 8 * i + 4, fe_load(mac_col + 4 * i));
+}
 template <int F>
 __global__ void __launch_bounds__(TPB) k_share_extract(size_t n, const u64* a, u64* out) {
     size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -538,6 +551,22 @@ int arkmpc_share_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out
         dim3 g(blocks_for(n, TPB)), t(TPB);
         DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_neg<F>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.out<u64>(io)));
     }
+    return st.finish();
+}
+int arkmpc_share_split(arkmpc_ctx* ctx, size_t n, const uint64_t* aos, uint64_t* out_share_col, uint64_t* out_mac_col) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(aos, n * 64), is = st.declare_out(out_share_col, n * 32), im = st.declare_out(out_mac_col, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_share_split, dim3(blocks_for(n, TPB)), dim3(TPB), 0, ctx->stream, n, st.in<u64>(ia), st.out<u64>(is), st.out<u64>(im));
+    return st.finish();
+}
+int arkmpc_share_join(arkmpc_ctx* ctx, size_t n, const uint64_t* share_col, const uint64_t* mac_col, uint64_t* out_aos) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int is = st.declare_in(share_col, n * 32), im = st.declare_in(mac_col, n * 32), io = st.declare_out(out_aos, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_share_join, dim3(blocks_for(n, TPB)), dim3(TPB), 0, ctx->stream, n, st.in<u64>(is), st.in<u64>(im), st.out<u64>(io));
     return st.finish();
 }
 int arkmpc_share_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out) {

@@ -170,6 +170,8 @@ class Engine:
     def share_add(self, n, a, b, out): self.call("share_add", ("size", n), a, b, out)
     def share_sub(self, n, a, b, out): self.call("share_sub", ("size", n), a, b, out)
     def share_neg(self, n, a, out): self.call("share_neg", ("size", n), a, out)
+    def share_split(self, n, aos, s, m): self.call("share_split", ("size", n), aos, s, m)
+    def share_join(self, n, s, m, aos): self.call("share_join", ("size", n), s, m, aos)
     def share_extract(self, n, a, out): self.call("share_extract", ("size", n), a, out)
     def share_add_public(self, n, party, key, a, pub, out): self.call("share_add_public", ("size", n), ("int", party), ("key", key), a, pub, out)
     def share_sub_public(self, n, party, key, a, pub, out): self.call("share_sub_public", ("size", n), ("int", party), ("key", key), a, pub, out)

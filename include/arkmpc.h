@@ -99,6 +99,11 @@ int arkmpc_share_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint6
                             const uint64_t* a, const uint64_t* pub, uint64_t* out);                              /* batch_sub_public :691-733 */
 int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* pub, uint64_t* out);  /* batch_mul_public :883-916 */
 
+/* layout converters: arkworks AoS ScalarShare records <-> engine-native split columns (n shares, then n MACs).
+ * Import once, run the _v entry points on the columns (no dead MAC bytes in K1, cacheable re-reads), export at the end. */
+int arkmpc_share_split(arkmpc_ctx* ctx, size_t n, const uint64_t* aos, uint64_t* out_share_col, uint64_t* out_mac_col);
+int arkmpc_share_join(arkmpc_ctx* ctx, size_t n, const uint64_t* share_col, const uint64_t* mac_col, uint64_t* out_aos);
+
 /* ---- Beaver multiplication, authenticated_scalar.rs:848-879 -------------------------------- */
 /* K1  batch_sub(a,&beaver_a), batch_sub(b,&beaver_b) + the `.share()` projection of open_batch's
  *     network op (:863-868, :141-145).  x,y,a,b: n ScalarShares.  out_de: 2n Scalars, d then e,

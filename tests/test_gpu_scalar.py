@@ -291,3 +291,14 @@ def test_batch_inverse(engines, oracle, fid, n):
     one = mont_array(fid, [1])
     for i in range(n):
         assert np.array_equal(prod[4 * i:4 * i + 4], one) or not a[4 * i:4 * i + 4].any()
+
+
+def test_layout_converters(engines):
+    n = 777
+    e = engines[0]
+    aos = np.arange(8 * n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    s, m, back = _z(n, 4), _z(n, 4), _z(n, 8)
+    e.share_split(n, aos, s, m)
+    assert np.array_equal(s.reshape(-1, 4), aos.reshape(-1, 8)[:, :4]) and np.array_equal(m.reshape(-1, 4), aos.reshape(-1, 8)[:, 4:])
+    e.share_join(n, s, m, back)
+    assert np.array_equal(back, aos)

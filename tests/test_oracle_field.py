@@ -90,3 +90,23 @@ def test_batch_inverse_vs_bigint(oracle, fid):
     vals = mixed_values(fid, 50, seed=9)            # includes 0, which must stay 0 (ark_ff::batch_inversion)
     got = from_mont_array(fid, oracle.scalar_batch_inverse(fid, mont_array(fid, vals)))
     assert got == [0 if v == 0 else pow(v, -1, p) for v in vals]
+
+
+# ark-bn254 / ark-bls12-381 `FrConfig`: TWO_ADICITY and TWO_ADIC_ROOT_OF_UNITY (published constants of the arkworks crates)
+TWO_ADIC = {
+    0: (28, 19103219067921713944291392827692070036145651957329286315305642004821462161904),
+    1: (32, 10238227357739495823651030575849232062558860180284477541189508159991286009131),
+}
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_two_adic_root_of_unity_through_oracle_mul(oracle, fid):
+    """root^(2^s) == 1 and root^(2^(s-1)) == -1, computed ONLY with the oracle's Montgomery multiplication."""
+    s, root = TWO_ADIC[fid]
+    p = pyref.P[fid]
+    x = mont_array(fid, [root])
+    for i in range(s - 1):
+        x = oracle.scalar_mul(fid, x, x)
+    assert from_mont_array(fid, x) == [p - 1]
+    x = oracle.scalar_mul(fid, x, x)
+    assert from_mont_array(fid, x) == [1]
