@@ -20,7 +20,6 @@ struct arkmpc_ctx {
     // device scratch arena for host-buffer staging and internal temporaries
     char* arena = nullptr;
     size_t arena_cap = 0;
-    size_t arena_used = 0;
     // small device word for reductions (mac_verify) + pinned mirror
     int* d_flag = nullptr;
     int* h_flag = nullptr;
@@ -72,14 +71,11 @@ static inline int arena_reserve(arkmpc_ctx* ctx, size_t bytes) {
 struct Stage {
     arkmpc_ctx* ctx;
     int rc = ARKMPC_OK;
-    struct Out { void* host; void* dev; size_t bytes; };
-    std::vector<Out> outs;
     struct In { const void* host; size_t bytes; size_t off; };
     std::vector<In> ins;
     struct OutPlan { void* host; size_t bytes; size_t off; };
     std::vector<OutPlan> oplan;
     size_t total = 0;
-    bool planned = false;
     explicit Stage(arkmpc_ctx* c) : ctx(c) {}
 
     static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -115,7 +111,6 @@ struct Stage {
         if (!ctx->host_buffers) {
             for (auto& i : ins) if (((uintptr_t)i.host & 15) != 0) return rc = ark_bad(ctx, "device pointer not 16-byte aligned");
             for (auto& o : oplan) if (((uintptr_t)o.host & 15) != 0) return rc = ark_bad(ctx, "device pointer not 16-byte aligned");
-            planned = true;
             return ARKMPC_OK;
         }
         rc = arena_reserve(ctx, total + scratch_total);
@@ -125,7 +120,6 @@ struct Stage {
             hipError_t e = hipMemcpyAsync(ctx->arena + i.off, i.host, i.bytes, hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) { ctx->err = std::string("H2D: ") + hipGetErrorString(e); return rc = ARKMPC_ERR_HIP; }
         }
-        planned = true;
         return ARKMPC_OK;
     }
     template <class T> const T* in(int idx) const {

@@ -56,6 +56,8 @@ def parse():
                     "can still be cached (256 MiB Infinity Cache) when step s+1 runs; 1 = reuse the same buffers every step")
     ap.add_argument("--event-every", type=int, default=4, help="record the per-kernel HIP events on every k-th timed step only "
                     "(each event record is an extra packet on the stream; the whole region is bracketed by one event pair regardless)")
+    ap.add_argument("--k3-order", default="01", choices=["01", "10"], help="order of the two parties' K2+K3 launches after K1(P0), K1(P1). "
+                    "The parties are independent; measured: no difference (within +-1 %).")
     ap.add_argument("--chunks", type=int, default=1, help="split each step's batch into this many gate ranges, each run K1,K1,K3,K3 "
                     "(shortens the K1->K3 reuse distance so d||e and a.s/b.s re-reads can hit the 256 MiB Infinity Cache)")
     return ap.parse_args()
@@ -121,7 +123,7 @@ def build_workload(eng, n, seed, layout):
     return parties, (x, y, key)
 
 
-def prepare_step(eng, n, parties, layout, chunks=1):
+def prepare_step(eng, n, parties, layout, chunks=1, k3_order="01"):
     """Pre-bind the launches of a step (arguments marshalled once; buffers are fixed for the whole run).
     With chunks > 1 the batch is cut into gate ranges and each range runs K1(P0), K1(P1), K3(P0), K3(P1)."""
     S = lambda v: ("size", v)
@@ -139,7 +141,8 @@ def prepare_step(eng, n, parties, layout, chunks=1):
             else:
                 calls.append(eng.prepare("beaver_mask_v", S(m), P(p.x) + o4, S(4), P(p.y) + o4, S(4), P(p.a) + o4, S(4), P(p.b) + o4, S(4),
                                          P(p.de) + de_off))
-        for p, peer in ((parties[0], parties[1]), (parties[1], parties[0])):   # the "network" = reading the peer's d||e
+        pairs = ((parties[0], parties[1]), (parties[1], parties[0]))
+        for p, peer in (pairs if k3_order == "01" else pairs[::-1]):   # the "network" = reading the peer's d||e
             if layout == "aos":
                 calls.append(eng.prepare("beaver_finish_fused", S(m), ("int", p.id), ("key", p.key), P(p.de) + de_off, P(peer.de) + de_off,
                                          P(p.a) + o8, P(p.b) + o8, P(p.c) + o8, P(p.out) + o8))
@@ -266,7 +269,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    call_sets = [prepare_step(eng, n, ps, args.layout, args.chunks) for ps, _ in sets]
+    call_sets = [prepare_step(eng, n, ps, args.layout, args.chunks, args.k3_order) for ps, _ in sets]
     for w in range(args.warmup):
         step(call_sets[w % len(call_sets)])
     barrier()

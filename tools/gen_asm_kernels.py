@@ -83,10 +83,6 @@ def regs_of(*xs):
 CY2 = "s[64:65]"      # second carry register (VOP3 encodings); VCC is the first
 
 
-def _cyfmt(cy):
-    return cy
-
-
 # ---- instruction constructors.  cy = "vcc" (VOP2 encodings) or an SGPR pair (VOP3 encodings) -------------
 def i_mov(d, s): return Ins("v_mov_b32_e32 %s, %s" % (d, src(s)), "mov", (d, s), rd=regs_of(s), wr=[d])
 def i_mad(d, a, b, c):
@@ -364,9 +360,6 @@ class Emu:
 # ------------------------------------------------------------------------------------------------
 # K2+K3 body
 # ------------------------------------------------------------------------------------------------
-KEY_S = ["%%[k%d]" % i for i in range(8)]
-
-
 def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
     global NT_BASES
     NT_BASES = NT_SPLIT if nt else NT_AOS
