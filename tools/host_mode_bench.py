@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the drop-in host-pointer mode (arkmpc_ctx_set_host_buffers): one party's K1 + K2/K3 on 2^20
+gates with every buffer in pageable host memory (what a Rust Vec is).  Never the reported `value`; DESIGN.md section 6."""
+import importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+pkg = importlib.import_module("ark-mpc_amd")
+n = 1 << int(os.environ.get("LOG2N", "20"))
+e = pkg.Engine(0, device=0, host_buffers=True)
+rng = np.random.default_rng(1)
+def shares(): return (rng.integers(0, 2**63, size=8 * n, dtype=np.int64).view(np.uint64) >> np.uint64(3))   # < 2^253: valid residues
+x, y, a, b, c = (shares() for _ in range(5))
+peer_de = rng.integers(0, 2**63, size=8 * n, dtype=np.int64).view(np.uint64) >> np.uint64(3)
+de = np.zeros(8 * n, dtype=np.uint64); out = np.zeros(8 * n, dtype=np.uint64)
+key = np.array([5, 0, 0, 0], dtype=np.uint64)
+def one():
+    e.beaver_mask(n, x, y, a, b, de)
+    e.beaver_finish_fused(n, 0, key, de, peer_de, a, b, c, out)
+one()
+t0 = time.perf_counter(); reps = 5
+for _ in range(reps): one()
+t = (time.perf_counter() - t0) / reps
+moved = n * (4 * 64 + 64 + 2 * 64 + 3 * 64 + 64)     # H2D x,y,a,b + D2H d||e + H2D d||e x2 + a,b,c + D2H out
+print(json.dumps({"mode": "host buffers (pageable), one party, 2^%d gates" % int(np.log2(n)), "ms": t * 1e3, "party_gates_per_s": n / t,
+                  "pcie_GBps": moved / t / 1e9}))
