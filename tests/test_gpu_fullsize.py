@@ -141,3 +141,31 @@ def test_config5_open_authenticated_bls12_381(pkg, log2n):
     _, _, ok = run(bad)
     assert ok is False
     e.close()
+
+
+def test_asm_path_chunk_boundary_above_2p25(pkg):
+    """The hand-scheduled K2+K3 uses 32-bit byte offsets and is launched in chunks of 2^25 gates; n = 2^25 + 5 crosses the
+    boundary.  Every word is compared with the plain C++ kernel (size_t indexing), in both layouts."""
+    n = (1 << 25) + 5
+    e = _eng(pkg, 0)
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    key = _rnd(e, 1, g).cpu().numpy().view(np.uint64).copy()
+    my_de, peer_de = _rnd(e, 2 * n, g), _rnd(e, 2 * n, g)
+    cols = {k: (_rnd(e, n, g), _rnd(e, n, g)) for k in "abc"}
+    opened = torch.empty_like(my_de); e.open_combine(2 * n, my_de, peer_de, opened)
+    aos = {k: torch.cat([s.view(n, 4), m.view(n, 4)], dim=1).contiguous().view(-1) for k, (s, m) in cols.items()}
+    ref = torch.empty(8 * n, dtype=torch.int64, device="cuda")
+    e.beaver_finish(n, 1, key, opened[:4 * n], opened[4 * n:], aos["a"], aos["b"], aos["c"], ref)          # C++ kernel
+    del opened
+    out = torch.zeros(8 * n, dtype=torch.int64, device="cuda")
+    e.beaver_finish_fused(n, 1, key, my_de, peer_de, aos["a"], aos["b"], aos["c"], out)                       # asm, AoS, 2 chunks
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    del out, aos
+    o_s = torch.zeros(4 * n, dtype=torch.int64, device="cuda"); o_m = torch.zeros_like(o_s)
+    e.beaver_finish_fused_v(n, 1, key, my_de, peer_de, cols["a"][0], cols["a"][1], 4, cols["b"][0], cols["b"][1], 4,
+                            cols["c"][0], cols["c"][1], 4, o_s, o_m, 4)                                       # asm, split, 2 chunks
+    torch.cuda.synchronize()
+    r = ref.view(n, 8)
+    assert torch.equal(o_s.view(n, 4), r[:, :4]) and torch.equal(o_m.view(n, 4), r[:, 4:])
+    e.close()
