@@ -275,6 +275,8 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // fabric.rs:578-600
     AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
     AuthenticatedScalarBatch allocate_scalar_shares(const std::vector<ScalarShare>& s);
+    // fabric.rs:622-649: share public-format points (12 x u64 Jacobian each) held by `sender`
+    template <class APB> APB batch_share_point(const std::vector<uint64_t>& points, size_t n, PartyId sender);
 
   private:
     PartyId party_;
@@ -352,6 +354,11 @@ class AuthenticatedScalarBatch {
         ScalarBatch inv; inv.n = values.n; inv.buf = DeviceBuf(f->engine(), 4 * values.n);         // step 3: ScalarResult::batch_inverse
         check(f->ctx(), arkmpc_scalar_batch_inverse(f->ctx(), values.n, opened.value.buf.ptr(), inv.buf.ptr()), "scalar_batch_inverse");
         return batch_mul_public(r, inv);                                                           // step 4: m_i^-1 * r_i = x_i^-1
+    }
+    // batch_div (:974-977): a / b = a * b^-1
+    static AuthenticatedScalarBatch batch_div(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b, const Scalar& blinder) {
+        AuthenticatedScalarBatch b_inv = batch_inverse(b, blinder);
+        return batch_mul(a, b_inv);
     }
     // ---- opening (:129-172, :278-354) -----------------------------------------------------------------------
     ScalarBatch open_batch() const {
@@ -530,6 +537,37 @@ class AuthenticatedPointBatch {
   private:
     static arkmpc_ctx* c(const AuthenticatedPointBatch& a) { return a.fabric->ctx(); }
 };
+
+// fabric.rs:622-649: the sender broadcasts val - mask*G; both sides compute mask_share*G + masked (batch_mul_generator, batch_add_public)
+template <class APB>
+inline APB MpcFabric::batch_share_point(const std::vector<uint64_t>& points, size_t n, PartyId sender) {
+    auto self = shared_from_this();
+    PointBatch masked;
+    std::vector<ScalarShare> mask_shares;
+    if (party_ == sender) {
+        auto lm = prep_->next_local_input_mask_batch(n);
+        ScalarBatch masks = allocate_scalars(lm.first);
+        PointBatch mg = APB::alloc_points(self, n), vals = APB::alloc_points(self, n);
+        vals.buf.upload(points.data(), n * 96);
+        if (n) check(ctx(), arkmpc_g1_generator_mul(ctx(), n, masks.buf.ptr(), mg.buf.ptr()), "g1_generator_mul");
+        masked = APB::alloc_points(self, n);
+        if (n) check(ctx(), arkmpc_g1_sub(ctx(), n, vals.buf.ptr(), mg.buf.ptr(), masked.buf.ptr()), "g1_sub");
+        // plaintext broadcast of the masked points (batch_share_plaintext)
+        std::vector<uint64_t> h = masked.to_host();
+        std::vector<Scalar> pay(3 * n);
+        std::memcpy(pay.data(), h.data(), h.size() * 8);
+        net_->send(NetworkOutbound{next_id_++, std::move(pay)});
+        mask_shares = std::move(lm.second);
+    } else {
+        mask_shares = prep_->next_counterparty_input_mask_batch(n);
+        NetworkOutbound got = net_->receive(); next_id_++;
+        masked = APB::alloc_points(self, n);
+        masked.buf.upload(got.payload.data(), n * 96);
+    }
+    AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
+    APB masks_g = APB::batch_mul_generator(shares);
+    return APB::batch_add_public(masks_g, masked);
+}
 
 inline AuthenticatedScalarBatch MpcFabric::allocate_scalar_shares(const std::vector<ScalarShare>& s) {
     auto r = AuthenticatedScalarBatch::alloc(shared_from_this(), s.size());

@@ -60,10 +60,37 @@ int main(int argc, char** argv) {
                 auto x = AuthenticatedScalarBatch::batch_mul_public(w, pa);
                 auto y = AuthenticatedScalarBatch::batch_add_public(x, pa);
                 res = AuthenticatedScalarBatch::batch_sub_public(y, pb);                  // -(a^2-b^2)*a + a - b
+            } else if (scenario == "div") {
+                // batch_div (authenticated_scalar.rs:974-977): open(a / b) == a * b^-1
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                auto b = fabric->batch_share_scalar(b_m, n, PARTY1);
+                res = AuthenticatedScalarBatch::batch_div(a, b, eng.from_u64(555 + fabric->party_id()));
             } else if (scenario == "inverse") {
                 // AuthenticatedScalarResult::batch_inverse (authenticated_scalar.rs:55-82, test :1640-1660): open(inverse(x)) == x^-1
                 auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
                 res = AuthenticatedScalarBatch::batch_inverse(a, eng.from_u64(777 + fabric->party_id()));
+            } else if (scenario == "share_point") {
+                // batch_share_point (fabric.rs:622-649): party 0 shares P_i = [a_i]G; open_authenticated must return P_i
+                std::vector<uint64_t> pts(12 * n);
+                {
+                    ScalarBatch sa = fabric->allocate_scalars(a_m);
+                    PointBatch pg = AuthenticatedPointBatch::alloc_points(fabric, n);
+                    if (n) check(fabric->ctx(), arkmpc_g1_generator_mul(fabric->ctx(), n, sa.buf.ptr(), pg.buf.ptr()), "g1_generator_mul");
+                    pts = pg.to_host();          // both parties can compute it here; only the sender's copy is used
+                }
+                auto Z = fabric->batch_share_point<AuthenticatedPointBatch>(pts, n, PARTY0);
+                std::vector<Scalar> bl(n);
+                for (size_t i = 0; i < n; ++i) bl[i] = eng.from_u64(31 + i + fabric->party_id());
+                PointOpenResult o = Z.open_authenticated_batch(bl);
+                PartyOut out;
+                for (size_t i = 0; i < n; ++i) if (!o.ok[i]) out.err += 1;
+                out.opened.resize(n);
+                if (n) {
+                    DeviceBuf bytes(fabric->engine(), 4 * n);
+                    check(fabric->ctx(), arkmpc_g1_to_bytes(fabric->ctx(), n, o.value.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "g1_to_bytes");
+                    bytes.download(out.opened.data(), n * 32);
+                }
+                return out;
             } else if (scenario == "point_mul" || scenario == "msm") {
                 // AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714, test :1222-1244): share x, share y,
                 // Y = [y]G, Z = batch_mul(x, Y), open_authenticated; out = compressed points of Z  (expected (x*y) G)

@@ -138,3 +138,31 @@ def test_authenticated_msm(tmp_path):
     for party in range(2):
         assert struct.unpack_from("<Q", raw, 40 * party)[0] == 0          # MAC check passed
         assert raw[40 * party + 8: 40 * party + 40] == want
+
+
+@pytest.mark.gpu
+def test_batch_div_protocol(tmp_path):
+    fid, n = 0, 33
+    p = pyref.P[fid]
+    a = rand_values(fid, n, 71)
+    b = [v for v in mixed_values(fid, n + 5, 72) if v != 0][:n]
+    res = run(tmp_path, "div", fid, a, b)
+    want = [(x * pow(y, -1, p)) % p for x, y in zip(a, b)]
+    assert res[0] == (0, want) and res[1] == (0, want)
+
+
+@pytest.mark.gpu
+def test_batch_share_point(tmp_path):
+    """fabric.rs:622-649: input sharing of curve points (sender masks with mask*G), then authenticated open returns them."""
+    fid, n = 0, 9
+    a = [0, 1, pyref.RORD - 1] + rand_values(fid, n - 3, 81)
+    want = b"".join(pyref.g1_compress(pyref.g1_mul(pyref.G, v)) for v in a)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(ints_to_limbs(a).tobytes() + ints_to_limbs(a).tobytes())
+    rr = subprocess.run([EXE, "share_point", str(fid), str(n), str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stderr
+    raw = outp.read_bytes()
+    for party in range(2):
+        off = party * (8 + 32 * n)
+        assert struct.unpack_from("<Q", raw, off)[0] == 0
+        assert raw[off + 8: off + 8 + 32 * n] == want
