@@ -1,0 +1,52 @@
+"""The driver-facing contract of bench.py: one JSON line on rank 0 with the agreed fields, for a plain launch and for a
+`python -m torch.distributed.run` launch (2 ranks; gloo backend here because the GPU box has one GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline"]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _check(line, n_gpus, steps, warmup):
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "gates/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["metric"].startswith("authenticated Beaver mul-gates/sec over BN254 Fr")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
+    assert d["value"] > 0 and d["results_check"].endswith("ok")
+    return d
+
+
+def test_single_process_default_shape():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--log2n", "16",
+                        "--cpu-log2n", "12"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _check(r.stdout.strip().splitlines()[-1], 1, 6, 2)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "gates/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_torchrun_two_ranks():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--log2n", "16", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # rank 0 only
+    d = _check(lines[0], 2, 4, 1)
+    assert "cpu_baseline" not in d               # N = 1 only
