@@ -303,10 +303,12 @@ def main():
         gates = n * world * args.steps
         value = gates / elapsed
         ach = n * ALG_BYTES_K3 / (k3_ms * 1e-3) / 1e9
-        traffic = None   # HBM bytes per K3 launch from the committed PMC passes (same workload), see profiles/
+        traffic, rocprof_ms = None, None   # from the committed rocprofv3 passes of the same workload, see profiles/
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.layout)
         if os.path.exists(tf) and args.log2n == 20 and args.chunks == 1:
-            traffic = json.load(open(tf))["k_beaver_finish_asm"]["hbm_bytes_per_launch"]
+            prof = json.load(open(tf))["k_beaver_finish_asm"]
+            traffic = prof["hbm_bytes_per_launch"]
+            rocprof_ms = prof.get("rocprof_avg_launch_ms")
         out = {
             "metric": METRIC, "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -318,7 +320,9 @@ def main():
                        "parallelism": "gate-range sharding, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_beaver_finish_asm<0,NT> (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": n * ALG_BYTES_K3, "avg_launch_ms": k3_ms},
+                         "algorithmic_bytes_per_launch": n * ALG_BYTES_K3, "avg_launch_ms": k3_ms,
+                         "avg_launch_ms_note": "in-stream HIP events: includes the dispatch gap after the previous kernel",
+                         "rocprof_avg_launch_ms": rocprof_ms},
             "pipeline": {"algorithmic_GBps": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9,
                          "frac_of_hbm_peak": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "k1_avg_launch_ms": k1_ms, "k3_avg_launch_ms": k3_ms, "device_ms_per_step": dev_ms_per_step, "steps_with_kernel_events": len(sampled),
