@@ -14,11 +14,11 @@
 #include "fp_asm.cuh"
 #include <cstdlib>
 
-// Fq multiplication used by the point formulas.  Default: the plain C++ core.  -DARKMPC_EC_ASM switches to the
-// hand-scheduled block (fe_mul_fast): bit-identical (the curve tests pass with it) but MEASURED SLOWER here -- config 4
-// 15.3 ms vs 14.2 ms -- because its 35 fixed temporaries on top of the formulas' ~10 live field elements push the
-// functions into spills and one wave per SIMD.  It pays only once a whole point operation owns its register file.
-#ifdef ARKMPC_EC_ASM
+// Fq multiplication used by the point formulas: the hand-scheduled block fe_mul_fast (298 instructions, 2 wait states;
+// tools/gen_asm_kernels.py) unless -DARKMPC_EC_CPP selects the plain C++ core.  Measured on config 4: 12.2 ms vs 13.8 ms.
+// The block's 35 fixed temporaries sit in caller-saved VGPR blocks only -- with callee-saved registers among them the
+// __noinline__ point functions had to spill/restore around every call and the block was SLOWER (15.3 ms).
+#ifndef ARKMPC_EC_CPP
 #define FQ_MUL(a, b) fe_mul_fast<F_BN254_FQ>(a, b)
 #else
 #define FQ_MUL(a, b) fe_mul<F_BN254_FQ>(a, b)

@@ -23,7 +23,8 @@ def test_emulated_stream_matches_bigint(fid):
 def test_single_montmul_block_matches_bigint(fid):
     name, p = g.FIELDS[fid]
     E, mp = g.selftest_montmul(p, trials=120, seed=fid)
-    assert E.nops <= 8 and mp["nv"] - mp["first"] == 35
+    assert E.nops <= 8 and len(mp["used"]) == 35
+    assert not any(v >= 40 and (v - 40) % 16 < 8 for v in mp["used"])      # no callee-saved VGPRs (v40-47, v56-63, ...)
 
 
 @pytest.mark.parametrize("fid", [0, 1])

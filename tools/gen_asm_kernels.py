@@ -455,12 +455,16 @@ def build_montmul(p):
     saved = (JUNK, S_INV, CY2)
     JUNK, S_INV, CY2 = "s[16:17]", "s20", "s[18:19]"
     try:
-        rg = Regs(MM_FIRST_VGPR)
-        Tz = [rg.pair() for _ in range(9)]
+        # temporaries live ONLY in caller-saved VGPR blocks of the AMDGPU calling convention (v32-39, v48-55, v64-71, v80-87,
+        # v96-103; v40-47, v56-63, v72-79, ... are callee-saved): a __noinline__ device function that clobbered callee-saved
+        # registers would have to spill and restore them around every call
+        blocks = [32, 48, 64, 80, 96]
+        pairs = [("v%d" % (b + 2 * k), "v%d" % (b + 2 * k + 1)) for b in blocks for k in range(4)]
+        Tz, q = pairs[:9], pairs[9:17]
         T = [t[0] for t in Tz]
-        q = [rg.pair() for _ in range(8)]
-        m = rg.one()
-        nv = rg.next
+        m = pairs[17][0]
+        used = sorted({int(r[1:]) for pr_ in pairs[:17] for r in pr_} | {int(m[1:])})
+        nv = None
         a = ["%%[a%d]" % i for i in range(8)]
         b = ["%%[b%d]" % i for i in range(8)]
         o = ["%%[o%d]" % i for i in range(8)]
@@ -474,7 +478,7 @@ def build_montmul(p):
         E.schedule(seq + mm)
         bound = ((p - 1) * (p - 1) + (R - 1) * p) // R + 1
         assert bound < 2 * p and 2 * p < R
-        return E, dict(first=MM_FIRST_VGPR, nv=nv, a=a, b=b, o=o)
+        return E, dict(first=MM_FIRST_VGPR, nv=nv, a=a, b=b, o=o, used=used)
     finally:
         JUNK, S_INV, CY2 = saved
 
@@ -568,7 +572,7 @@ def emit_header(path):
         selftest_montmul(p, trials=60, seed=fid)
         E, mp = build_montmul(p)
         nvalu = sum(1 for i in E.order if i.op in ("mov", "mad", "mul_lo", "addco", "addc", "subco", "subb", "cnd", "and"))
-        clob = ['"vcc"'] + ['"%s"' % s_ for s_ in MM_CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mp["first"], mp["nv"])]
+        clob = ['"vcc"'] + ['"%s"' % s_ for s_ in MM_CLOBBER_SGPRS] + ['"v%d"' % i for i in mp["used"]]
         out.append("// %s: single Montgomery multiplication, %d VALU, %d H1 wait states; result in [0, 2p)" % (name, nvalu, E.nops))
         out.append("template <> __device__ __forceinline__ Fe fe_mont_mul_asm<%d>(const Fe& a, const Fe& b) {" % fid)
         out.append("    Fe o;")
@@ -598,7 +602,7 @@ if __name__ == "__main__":
             except AssertionError as ex:
                 print("%-14s %s" % (name, ex))
             E, mp = selftest_montmul(p)
-            print("%-14s montmul block ok: %d instrs, %d wait states, temps v%d..v%d" % (name, len(E.order), E.nops, mp["first"], mp["nv"] - 1))
+            print("%-14s montmul block ok: %d instrs, %d wait states, %d fixed temporaries" % (name, len(E.order), E.nops, len(mp["used"])))
         sys.exit(0)
     for s in emit_header(a.o):
         print("%-14s VALU %d  mad %d  H1 wait states %d  VGPR end %d" % s)
