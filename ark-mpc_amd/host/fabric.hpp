@@ -325,6 +325,12 @@ class AuthenticatedScalarBatch {
         if (a.n != b.n) throw std::invalid_argument("Cannot multiply batches of different sizes");
         auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_mul_public(ctx(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_mul_public"); return r;
     }
+    // batch_mul_constant (:919-949): constants are plain Scalars broadcast by the caller -- same kernel as mul_public
+    static AuthenticatedScalarBatch batch_mul_constant(const AuthenticatedScalarBatch& a, const std::vector<Scalar>& consts) {
+        if (a.n != consts.size()) throw std::invalid_argument("Cannot multiply batches of different sizes");
+        ScalarBatch c = a.fabric->allocate_scalars(consts);
+        return batch_mul_public(a, c);
+    }
     // ---- Beaver multiplication (:848-879) -------------------------------------------------------------------
     static AuthenticatedScalarBatch batch_mul(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {
         same(a, b);
@@ -603,6 +609,15 @@ inline AuthenticatedScalarBatch MpcFabric::batch_share_scalar(const std::vector<
     }
     AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
     return AuthenticatedScalarBatch::batch_add_public(shares, masked);
+}
+
+// gadgets.rs:39-52 bit_xor_batch: xor(a, b) = a + b - 2ab
+inline AuthenticatedScalarBatch bit_xor_batch(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {
+    AuthenticatedScalarBatch a_plus_b = AuthenticatedScalarBatch::batch_add(a, b);
+    AuthenticatedScalarBatch a_times_b = AuthenticatedScalarBatch::batch_mul(a, b);
+    std::vector<Scalar> twos(a.n, a.fabric->engine()->from_u64(2));
+    AuthenticatedScalarBatch t = AuthenticatedScalarBatch::batch_mul_constant(a_times_b, twos);
+    return AuthenticatedScalarBatch::batch_sub(a_plus_b, t);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

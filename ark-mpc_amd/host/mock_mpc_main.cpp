@@ -60,6 +60,11 @@ int main(int argc, char** argv) {
                 auto x = AuthenticatedScalarBatch::batch_mul_public(w, pa);
                 auto y = AuthenticatedScalarBatch::batch_add_public(x, pa);
                 res = AuthenticatedScalarBatch::batch_sub_public(y, pb);                  // -(a^2-b^2)*a + a - b
+            } else if (scenario == "xor") {
+                // gadgets.rs bit_xor_batch / authenticated_scalar.rs test_xor_circuit (:1677-1688): a + b - 2ab on shared bits
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                auto b = fabric->batch_share_scalar(b_m, n, PARTY1);
+                res = bit_xor_batch(a, b);
             } else if (scenario == "div") {
                 // batch_div (authenticated_scalar.rs:974-977): open(a / b) == a * b^-1
                 auto a = fabric->batch_share_scalar(a_m, n, PARTY0);

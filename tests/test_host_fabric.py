@@ -166,3 +166,14 @@ def test_batch_share_point(tmp_path):
         off = party * (8 + 32 * n)
         assert struct.unpack_from("<Q", raw, off)[0] == 0
         assert raw[off + 8: off + 8 + 32 * n] == want
+
+
+@pytest.mark.gpu
+def test_xor_circuit(tmp_path):
+    """test_xor_circuit (authenticated_scalar.rs:1677-1688) / gadgets.rs bit_xor_batch on all four bit pairs, batched."""
+    fid = 0
+    a = [0, 0, 1, 1] * 16
+    b = [0, 1, 0, 1] * 16
+    res = run(tmp_path, "xor", fid, a, b)
+    want = [x ^ y for x, y in zip(a, b)]
+    assert res[0] == (0, want) and res[1] == (0, want)
