@@ -245,7 +245,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # under torch.distributed.run the collective path is used even for one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank = local_rank % torch.cuda.device_count()      # (tests may oversubscribe one GPU with the gloo backend)
