@@ -105,6 +105,19 @@ __device__ __noinline__ G1 g1_add(G1 p, G1 q) {
     out = g1_select(pinf, q, out);
     return out;
 }
+// window table T[k-1] = k*P for k = 1..15 in the HBM workspace: even entries by doubling (7 Fq-mults) the half entry read
+// back from the table, odd ones by adding P (16): 7 dbl + 7 add instead of 1 dbl + 13 add
+__device__ __forceinline__ void g1_build_table(const G1& p, u64* tab, size_t tid, size_t nthreads) {
+    g1_store(tab + ((size_t)0 * nthreads + tid) * 12, p);
+    G1 prev = p;                       // T[k-1]
+    for (int k = 2; k <= 15; ++k) {
+        G1 t;
+        if (k & 1) t = g1_add(prev, p);                                                   // odd: T[k-1] + P
+        else t = g1_double(g1_load(tab + ((size_t)(k / 2 - 1) * nthreads + tid) * 12));     // even: 2 * T[k/2]
+        g1_store(tab + ((size_t)(k - 1) * nthreads + tid) * 12, t);
+        prev = t;
+    }
+}
 // [s]P, s given in Montgomery form over Fr (curve.rs:403-409).  Fixed 4-bit windows, MSB first: per window four
 // doublings and at most one addition of a table entry k*P (k = 1..15).  The table lives in an HBM workspace
 // (15 x 96 B per thread, entry-major so a wave's accesses to one entry are contiguous): 160 KiB of LDS could only
@@ -113,16 +126,7 @@ __device__ __noinline__ G1 g1_add(G1 p, G1 q) {
 // merged per lane with a select.
 __device__ __forceinline__ G1 g1_scalar_mul_w4(const G1& p, const Fe& s_mont, u64* tab, size_t tid, size_t nthreads) {
     const Fe s = fe_to_canonical<FR>(s_mont);
-    // table: T[k-1] = k*P
-    G1 t = p;
-    g1_store(tab + ((size_t)0 * nthreads + tid) * 12, t);
-    G1 t2 = g1_double(p);
-    g1_store(tab + ((size_t)1 * nthreads + tid) * 12, t2);
-    t = t2;
-    for (int k = 3; k <= 15; ++k) {
-        t = g1_add(t, p);
-        g1_store(tab + ((size_t)(k - 1) * nthreads + tid) * 12, t);
-    }
+    g1_build_table(p, tab, tid, nthreads);
     G1 acc = g1_identity();
     for (int limb = 7; limb >= 0; --limb) {
         const u32 w = s.v[limb];
@@ -214,15 +218,7 @@ __device__ __forceinline__ G1 g1_scalar_mul_glv(const G1& p, const Fe& s_mont, u
     Fe beta;
 #pragma unroll
     for (int i = 0; i < 8; ++i) beta.v[i] = GLV_BETA_MONT[i];
-    // table: T[k-1] = k*P, k = 1..15
-    G1 t = p;
-    g1_store(tab + ((size_t)0 * nthreads + tid) * 12, t);
-    t = g1_double(p);
-    g1_store(tab + ((size_t)1 * nthreads + tid) * 12, t);
-    for (int k = 3; k <= 15; ++k) {
-        t = g1_add(t, p);
-        g1_store(tab + ((size_t)(k - 1) * nthreads + tid) * 12, t);
-    }
+    g1_build_table(p, tab, tid, nthreads);
     G1 acc = g1_identity();
     for (int w = GLV_WINDOWS - 1; w >= 0; --w) {
         acc = g1_double(acc);

@@ -24,8 +24,8 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / reps * 1e-3
 glv = os.environ.get('ARKMPC_NO_GLV', '0') != '1'
-# GLV: 33 windows x (4 dbl + 2 add + 1 beta mul) + table (1 dbl + 13 add); plain 4-bit windows: 256 dbl + 64 add + table
-FQ_MULS = (33 * (4 * 7 + 2 * 16 + 1) + 7 + 13 * 16) if glv else (256 * 7 + 64 * 16 + 7 + 13 * 16)
+# GLV: 33 windows x (4 dbl + 2 add + 1 beta mul) + table (7 dbl + 7 add); plain 4-bit windows: 256 dbl + 64 add + table
+FQ_MULS = (33 * (4 * 7 + 2 * 16 + 1) + 7 * 7 + 7 * 16) if glv else (256 * 7 + 64 * 16 + 7 * 7 + 7 * 16)
 print(json.dumps({"workload": "2^%d PointShare x Scalar = %d scalar-muls" % (int(np.log2(n)), 2 * n), "ms": t * 1e3,
                   "scalar_muls_per_s": 2 * n / t, "fq_muls_per_s": 2 * n * FQ_MULS / t,
                   "algorithm": "glv+w4" if glv else "w4", "fq_muls_per_scalar_mul": FQ_MULS, "frac_of_mad_only_peak": 2 * n * FQ_MULS / t / (31.2e12 / 136)}))
