@@ -127,6 +127,48 @@ __global__ void __launch_bounds__(TPB) k_batch_inverse(size_t n, const u64* a, u
     }
 }
 
+// Inclusive prefix product out_i = in_0 * ... * in_i (the public scan inside gadgets.rs:131-137 prefix_product, there a
+// sequential loop of ScalarResult multiplications).  Field multiplication is associative, so it is a parallel scan:
+// every thread folds SCAN_ITEMS consecutive elements, the workgroup scans the 256 thread totals through LDS
+// (Hillis-Steele, 8 steps), block totals are scanned recursively and applied.
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK (TPB * SCAN_ITEMS)
+template <int F>
+__global__ void __launch_bounds__(TPB) k_scan_block(size_t n, const u64* in, u64* out, u64* block_totals) {
+    __shared__ u64 sm[TPB * 4];
+    const size_t base = ((size_t)blockIdx.x * TPB + threadIdx.x) * SCAN_ITEMS;
+    Fe v[SCAN_ITEMS];
+    Fe run = fe_one<F>();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? fe_load(in + 4 * (base + i)) : fe_one<F>();
+        run = fe_mul<F>(run, v[i]);
+        v[i] = run;                                        // thread-local inclusive prefix
+    }
+    fe_store(sm + 4 * threadIdx.x, run);
+    __syncthreads();
+    for (int off = 1; off < TPB; off <<= 1) {              // inclusive scan of the thread totals
+        Fe mine = fe_load(sm + 4 * threadIdx.x), left = fe_one<F>();
+        const bool has = threadIdx.x >= (unsigned)off;
+        if (has) left = fe_load(sm + 4 * (threadIdx.x - off));
+        __syncthreads();
+        if (has) fe_store(sm + 4 * threadIdx.x, fe_mul<F>(left, mine));
+        __syncthreads();
+    }
+    const Fe excl = threadIdx.x ? fe_load(sm + 4 * (threadIdx.x - 1)) : fe_one<F>();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) fe_store(out + 4 * (base + i), fe_mul<F>(excl, v[i]));
+    if (threadIdx.x == TPB - 1 && block_totals) fe_store(block_totals + 4 * blockIdx.x, fe_load(sm + 4 * (TPB - 1)));
+}
+template <int F>
+__global__ void __launch_bounds__(TPB) k_scan_apply(size_t n, u64* out, const u64* scanned_totals) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const size_t blk = i / SCAN_BLOCK;
+    if (i >= n || blk == 0) return;
+    fe_store(out + 4 * i, fe_mul<F>(fe_load(scanned_totals + 4 * (blk - 1)), fe_load(out + 4 * i)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // ScalarShare kernels (share.rs:72-133)
 // ---------------------------------------------------------------------------------------------
@@ -363,6 +405,17 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                        (const u64*)nullptr, a_s, a_m, b_s, b_m, c_s, c_m, o_s, o_m);
 }
 
+template <int F>
+static void scan_level(arkmpc_ctx* ctx, size_t n, const u64* in, u64* out, u64* ws) {
+    const size_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    u64* totals = ws;                                   // nblocks elements, then the deeper levels' workspace
+    hipLaunchKernelGGL((k_scan_block<F>), dim3((unsigned)nblocks), dim3(TPB), 0, ctx->stream, n, in, out, nblocks > 1 ? totals : (u64*)nullptr);
+    if (nblocks > 1) {
+        scan_level<F>(ctx, nblocks, totals, totals, totals + 4 * nblocks);      // in-place scan of the block totals
+        hipLaunchKernelGGL((k_scan_apply<F>), dim3(blocks_for(n, TPB)), dim3(TPB), 0, ctx->stream, n, out, totals);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI: context
 // ---------------------------------------------------------------------------------------------
@@ -505,6 +558,23 @@ static int scalar_unop(arkmpc_ctx* ctx, int which, size_t n, const uint64_t* a, 
         });
     }
     return st.finish();
+}
+int arkmpc_scalar_prefix_product(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) {
+    ENTER(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 32), io = st.declare_out(out, n * 32);
+    size_t ws = 0;
+    for (size_t m = (n + SCAN_BLOCK - 1) / SCAN_BLOCK; m > 1; m = (m + SCAN_BLOCK - 1) / SCAN_BLOCK) ws += m * 32;
+    ws += 64;
+    int iw = st.declare_scratch(ws + ((n + SCAN_BLOCK - 1) / SCAN_BLOCK) * 32);
+    if (st.commit()) return st.rc;
+    if (n) DISPATCH_FIELD(ctx, scan_level<F>(ctx, n, st.in<u64>(ia), st.out<u64>(io), st.scratch<u64>(iw)));
+    return st.finish();
+}
+int arkmpc_memcpy_d2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes) {
+    ENTER(ctx);
+    ARK_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ARKMPC_OK;
 }
 int arkmpc_scalar_batch_inverse(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) {
     ENTER(ctx);

@@ -161,6 +161,7 @@ class Engine:
     def scalar_sub(self, n, a, b, out): self.call("scalar_sub", ("size", n), a, b, out)
     def scalar_mul(self, n, a, b, out): self.call("scalar_mul", ("size", n), a, b, out)
     def scalar_neg(self, n, a, out): self.call("scalar_neg", ("size", n), a, out)
+    def scalar_prefix_product(self, n, a, out): self.call("scalar_prefix_product", ("size", n), a, out)
     def scalar_batch_inverse(self, n, a, out): self.call("scalar_batch_inverse", ("size", n), a, out)
     def scalar_from_canonical(self, n, a, out): self.call("scalar_from_canonical", ("size", n), a, out)
     def scalar_to_canonical(self, n, a, out): self.call("scalar_to_canonical", ("size", n), a, out)

@@ -74,6 +74,7 @@ int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr);
 int arkmpc_free(arkmpc_ctx* ctx, void* dptr);
 int arkmpc_memcpy_h2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int arkmpc_memcpy_d2h(arkmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int arkmpc_memcpy_d2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* asynchronous on the context's stream */
 
 /* ---- Scalar<C> vectors: scalar.rs:210-267, scalar_result.rs:24-278 ------------------------- */
 int arkmpc_scalar_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
@@ -83,6 +84,9 @@ int arkmpc_scalar_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* ou
 /* Scalar::batch_inverse / ScalarResult::batch_inverse (scalar.rs:93-100, scalar_result.rs:50-61): non-zero elements are
  * replaced by their inverses, zeros stay zero (ark_ff::batch_inversion).  In-place allowed. */
 int arkmpc_scalar_batch_inverse(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
+/* inclusive prefix products out_i = a_0 * ... * a_i: the public scan inside the prefix_product gadget (gadgets.rs:131-137),
+ * there a sequential chain of ScalarResult multiplications; here a parallel scan (multiplication is associative). */
+int arkmpc_scalar_prefix_product(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
 /* canonical little-endian integers (< 2^256, reduced mod p on the way in) <-> Montgomery form */
 int arkmpc_scalar_from_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);
 int arkmpc_scalar_to_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);

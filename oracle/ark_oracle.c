@@ -175,6 +175,12 @@ void ora_scalar_batch_mul(int fid, size_t n, const u64* a, const u64* b, u64* ou
     const ora_field* f = ora_get_field(fid);
     for (size_t i = 0; i < n; ++i) ora_fp_mul(f, a + 4 * i, b + 4 * i, out + 4 * i);
 }
+/* gadgets.rs:131-137: prefix = prefix * blinded_term, sequentially */
+void ora_scalar_prefix_product(int fid, size_t n, const u64* a, u64* out) {
+    const ora_field* f = ora_get_field(fid);
+    u64 run[4]; memcpy(run, f->r, 32);
+    for (size_t i = 0; i < n; ++i) { ora_fp_mul(f, run, a + 4 * i, run); memcpy(out + 4 * i, run, 32); }
+}
 /* scalar.rs:93-100 -> ark_ff::batch_inversion: non-zero elements inverted, zeros unchanged */
 void ora_scalar_batch_inverse(int fid, size_t n, const u64* a, u64* out) {
     const ora_field* f = ora_get_field(fid);

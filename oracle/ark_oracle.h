@@ -65,6 +65,7 @@ void ora_scalar_batch_sub(int field_id, size_t n, const u64* a, const u64* b, u6
 void ora_scalar_batch_mul(int field_id, size_t n, const u64* a, const u64* b, u64* out);   /* scalar_result.rs:257-278 */
 void ora_scalar_batch_neg(int field_id, size_t n, const u64* a, u64* out);
 void ora_scalar_batch_inverse(int field_id, size_t n, const u64* a, u64* out);    /* scalar.rs:93-100 */
+void ora_scalar_prefix_product(int field_id, size_t n, const u64* a, u64* out);   /* gadgets.rs:131-137 */
 
 /* ---- ScalarShare batch ops (share.rs:72-133, authenticated_scalar.rs:457-949) ---- */
 void ora_share_batch_add(int field_id, size_t n, const u64* a, const u64* b, u64* out);          /* :457-489 */

@@ -302,3 +302,13 @@ def test_layout_converters(engines):
     assert np.array_equal(s.reshape(-1, 4), aos.reshape(-1, 8)[:, :4]) and np.array_equal(m.reshape(-1, 4), aos.reshape(-1, 8)[:, 4:])
     e.share_join(n, s, m, back)
     assert np.array_equal(back, aos)
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 70000])
+def test_prefix_product_scan(engines, oracle, fid, n):
+    """parallel inclusive scan vs the oracle's sequential chain (bit-exact: products of canonical residues are unique),
+    across the one-block, two-level and ragged cases"""
+    a = mont_array(fid, rand_values(fid, n, seed=5 * n + fid))
+    out = _z(n, 4); engines[fid].scalar_prefix_product(n, a, out)
+    assert np.array_equal(out, oracle.scalar_prefix_product(fid, a))

@@ -110,3 +110,13 @@ def test_two_adic_root_of_unity_through_oracle_mul(oracle, fid):
     assert from_mont_array(fid, x) == [p - 1]
     x = oracle.scalar_mul(fid, x, x)
     assert from_mont_array(fid, x) == [1]
+
+
+def test_prefix_product_vs_bigint(oracle):
+    fid = 0; p = pyref.P[fid]
+    vals = mixed_values(fid, 30, seed=4)[3:]
+    got = from_mont_array(fid, oracle.scalar_prefix_product(fid, mont_array(fid, vals)))
+    run, want = 1, []
+    for v in vals:
+        run = run * v % p; want.append(run)
+    assert got == want
