@@ -179,6 +179,7 @@ class PreprocessingPhase {
     virtual std::vector<ScalarShare> next_counterparty_input_mask_batch(size_t n) = 0;
     virtual void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) = 0;
     virtual std::vector<ScalarShare> next_shared_value_batch(size_t n) = 0;                       // offline_prep.rs:45-50
+    virtual void next_shared_inverse_pair_batch(size_t n, std::vector<ScalarShare>& l, std::vector<ScalarShare>& r) = 0;   // :54-60
 };
 // offline_prep.rs:88-170: a = 2, b = 3, c = 6 statically split; MAC key share = party id
 class PartyIDBeaverSource : public PreprocessingPhase {
@@ -206,6 +207,9 @@ class PartyIDBeaverSource : public PreprocessingPhase {
 
     std::vector<ScalarShare> next_shared_value_batch(size_t n) override {                       // :166-168: (party_id, party_id)
         return std::vector<ScalarShare>(n, ScalarShare{s_[party_], s_[party_]});
+    }
+    void next_shared_inverse_pair_batch(size_t n, std::vector<ScalarShare>& l, std::vector<ScalarShare>& r) override {   // :159-164: 1 * 1 = 1
+        l.assign(n, ScalarShare{s_[party_], s_[party_]}); r.assign(n, ScalarShare{s_[party_], s_[party_]});
     }
 
   private:
@@ -272,6 +276,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     }
     void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c);  // fabric.rs:894-915
     AuthenticatedScalarBatch random_shared_scalars(size_t n);                                    // fabric.rs:917-928
+    void random_inverse_pairs(size_t n, AuthenticatedScalarBatch& l, AuthenticatedScalarBatch& r);  // fabric.rs:942-958
     // fabric.rs:578-600
     AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
     AuthenticatedScalarBatch allocate_scalar_shares(const std::vector<ScalarShare>& s);
@@ -402,6 +407,18 @@ class AuthenticatedScalarBatch {
         res.err = ok ? MpcError::None : MpcError::AuthenticationError;                            // :368-385
         res.value = std::move(opened);
         return res;
+    }
+    // elements [lo, lo+cnt) as a new batch (a Rust slice &v[lo..lo+cnt])
+    AuthenticatedScalarBatch slice(size_t lo, size_t cnt) const {
+        if (lo + cnt > n) throw std::out_of_range("slice");
+        auto r = alloc(fabric, cnt);
+        if (cnt) check(fabric->ctx(), arkmpc_memcpy_d2d(fabric->ctx(), r.buf.ptr(), buf.ptr() + 8 * lo, cnt * 64), "d2d");
+        return r;
+    }
+    // iter::repeat(v[idx]).take(cnt)
+    AuthenticatedScalarBatch repeat(size_t idx, size_t cnt) const {
+        std::vector<ScalarShare> h = to_host();
+        return fabric->allocate_scalar_shares(std::vector<ScalarShare>(cnt, h.at(idx)));
     }
     // test helpers (authenticated_scalar.rs:1079-1111): overwrite the MAC / the share of element idx
     void modify_mac(size_t idx, const Scalar& v) { poke(idx, 1, v); }
@@ -587,6 +604,12 @@ inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, 
     next_id_ += 3 * n;
     a = allocate_scalar_shares(ha); b = allocate_scalar_shares(hb); c = allocate_scalar_shares(hc);
 }
+inline void MpcFabric::random_inverse_pairs(size_t n, AuthenticatedScalarBatch& l, AuthenticatedScalarBatch& r) {
+    std::vector<ScalarShare> hl, hr;
+    prep_->next_shared_inverse_pair_batch(n, hl, hr);
+    next_id_ += 2 * n;
+    l = allocate_scalar_shares(hl); r = allocate_scalar_shares(hr);
+}
 inline AuthenticatedScalarBatch MpcFabric::random_shared_scalars(size_t n) {
     std::vector<ScalarShare> v = prep_->next_shared_value_batch(n);
     next_id_ += n;
@@ -609,6 +632,22 @@ inline AuthenticatedScalarBatch MpcFabric::batch_share_scalar(const std::vector<
     }
     AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
     return AuthenticatedScalarBatch::batch_add_public(shares, masked);
+}
+
+// gadgets.rs:105-148 prefix_product: blind in a telescoping manner with inverse pairs, open, scan in public, unblind
+inline AuthenticatedScalarBatch prefix_product(const AuthenticatedScalarBatch& values, const Scalar& blinder, MpcError* err = nullptr) {
+    const size_t n = values.n;
+    auto f = values.fabric;
+    AuthenticatedScalarBatch b, b_inv;
+    f->random_inverse_pairs(n + 1, b, b_inv);                                                             // :109
+    AuthenticatedScalarBatch partial_blind = AuthenticatedScalarBatch::batch_mul(b_inv.slice(0, n), values);        // :113
+    AuthenticatedScalarBatch blinded = AuthenticatedScalarBatch::batch_mul(partial_blind, b.slice(1, n));           // :114
+    AuthenticatedOpenResult opened = blinded.open_authenticated_batch(blinder);                           // :117-120
+    if (err) *err = opened.err;
+    ScalarBatch prefixes; prefixes.n = n; prefixes.buf = DeviceBuf(f->engine(), 4 * (n ? n : 1));          // :131-137
+    check(f->ctx(), arkmpc_scalar_prefix_product(f->ctx(), n, opened.value.buf.ptr(), prefixes.buf.ptr()), "scalar_prefix_product");
+    AuthenticatedScalarBatch partial_unblind = AuthenticatedScalarBatch::batch_mul_public(b.repeat(0, n), prefixes);  // :146
+    return AuthenticatedScalarBatch::batch_mul(partial_unblind, b_inv.slice(1, n));                       // :147
 }
 
 // gadgets.rs:39-52 bit_xor_batch: xor(a, b) = a + b - 2ab

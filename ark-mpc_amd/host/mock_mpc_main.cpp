@@ -60,6 +60,10 @@ int main(int argc, char** argv) {
                 auto x = AuthenticatedScalarBatch::batch_mul_public(w, pa);
                 auto y = AuthenticatedScalarBatch::batch_add_public(x, pa);
                 res = AuthenticatedScalarBatch::batch_sub_public(y, pb);                  // -(a^2-b^2)*a + a - b
+            } else if (scenario == "prefix_product") {
+                // gadgets.rs:105-148 / test_prefix_product: open(prefix_product(x))_i == x_0 * ... * x_i
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                res = prefix_product(a, eng.from_u64(999 + fabric->party_id()));
             } else if (scenario == "xor") {
                 // gadgets.rs bit_xor_batch / authenticated_scalar.rs test_xor_circuit (:1677-1688): a + b - 2ab on shared bits
                 auto a = fabric->batch_share_scalar(a_m, n, PARTY0);

@@ -177,3 +177,16 @@ def test_xor_circuit(tmp_path):
     res = run(tmp_path, "xor", fid, a, b)
     want = [x ^ y for x, y in zip(a, b)]
     assert res[0] == (0, want) and res[1] == (0, want)
+
+
+@pytest.mark.gpu
+def test_prefix_product_gadget(tmp_path):
+    """gadgets.rs:105-148: five Beaver/open rounds + a public scan; open(prefix_product(x))_i == x_0 * ... * x_i."""
+    fid, n = 0, 300
+    p = pyref.P[fid]
+    a = [v for v in rand_values(fid, n, 91)]
+    res = run(tmp_path, "prefix_product", fid, a, a)
+    run_, want = 1, []
+    for v in a:
+        run_ = run_ * v % p; want.append(run_)
+    assert res[0] == (0, want) and res[1] == (0, want)
