@@ -312,3 +312,34 @@ def test_prefix_product_scan(engines, oracle, fid, n):
     a = mont_array(fid, rand_values(fid, n, seed=5 * n + fid))
     out = _z(n, 4); engines[fid].scalar_prefix_product(n, a, out)
     assert np.array_equal(out, oracle.scalar_prefix_product(fid, a))
+
+
+def test_thread_safety_same_and_separate_contexts(pkg, oracle):
+    """include/arkmpc.h THREADING: calls on one context are serialised internally; different contexts are independent
+    (gates may run on rayon workers concurrently, multi_threaded/executor.rs:208-217)."""
+    import threading
+    fid, n = 0, 5000
+    shared = pkg.Engine(fid, device=0, host_buffers=True)
+    own = [pkg.Engine(fid, device=0, host_buffers=True) for _ in range(2)]
+    a = [mont_array(fid, rand_values(fid, n, 100 + t)) for t in range(2)]
+    b = [mont_array(fid, rand_values(fid, n, 200 + t)) for t in range(2)]
+    want = [oracle.scalar_mul(fid, a[t], b[t]) for t in range(2)]
+    errors = []
+
+    def work(t):
+        try:
+            for it in range(40):
+                for eng in (shared, own[t]):
+                    out = _z(n, 4)
+                    eng.scalar_mul(n, a[t], b[t], out)
+                    if not np.array_equal(out, want[t]):
+                        errors.append((t, it))
+        except Exception as ex:      # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    assert errors == []
+    for e in [shared] + own:
+        e.close()
