@@ -20,8 +20,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
-ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "sha3_host.hip"]
-ENGINE_DEPS = ["fp.cuh", "field_consts.inc", "asm_kernels.inc", "fp_asm.cuh", "glv_consts.inc", "arkmpc_internal.hpp", os.path.join("..", "..", "include", "arkmpc.h")]
+ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "arkmpc_edwards.hip", "sha3_host.hip"]
+ENGINE_DEPS = ["fp.cuh", "field_consts.inc", "asm_kernels.inc", "fp_asm.cuh", "glv_consts.inc", "ed25519_consts.inc", "arkmpc_internal.hpp", os.path.join("..", "..", "include", "arkmpc.h")]
 
 
 def _newer(target, deps):

@@ -1,0 +1,273 @@
+// arkmpc_edwards.hip -- HIP kernels + C ABI for Curve25519 points: the curve group of
+// ark_curve25519::EdwardsProjective, which the reference's README example instantiates MpcFabric with (README.md:24).
+// Same CurvePoint / PointShare semantics as the BN254 side (online-phase/src/algebra/curve/{curve,share}.rs); only the
+// group law differs.
+//
+// Points cross the ABI as ark-ec twisted-Edwards `Projective{x, y, t, z}` = extended coordinates over Fq = 2^255 - 19 in
+// Montgomery form (16 x u64), identity (0, 1, 0, 1); PointShare = 32 x u64.  Results are compared with the oracle on
+// affine coordinates.  Curve: -x^2 + y^2 = 1 + d x^2 y^2 (a = -1).  add-2008-hwcd-3 is complete on this curve (a = -1 is
+// a square, d is not), so addition needs no exceptional cases at all; doubling is dbl-2008-hwcd.
+// Scalars are Curve25519 Fr elements: the context's field must be ARKMPC_CURVE25519_FR.
+#include "arkmpc_internal.hpp"
+#include <cstdlib>
+
+#define TPB_ED 128
+constexpr int EQ = F_CURVE25519_FQ;
+constexpr int ER = F_CURVE25519_FR;
+#include "ed25519_consts.inc"
+
+struct Ed {
+    Fe x, y, t, z;
+};
+__device__ __forceinline__ Fe ed_const(const u32 (&c)[8]) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = c[i];
+    return r;
+}
+__device__ __forceinline__ Ed ed_load(const u64* p) {
+    Ed r;
+    r.x = fe_load(p); r.y = fe_load(p + 4); r.t = fe_load(p + 8); r.z = fe_load(p + 12);
+    return r;
+}
+__device__ __forceinline__ void ed_store(u64* p, const Ed& a) {
+    fe_store(p, a.x); fe_store(p + 4, a.y); fe_store(p + 8, a.t); fe_store(p + 12, a.z);
+}
+__device__ __forceinline__ Ed ed_identity() {
+    Ed r;
+    r.x = fe_zero<EQ>(); r.y = fe_one<EQ>(); r.t = fe_zero<EQ>(); r.z = fe_one<EQ>();
+    return r;
+}
+__device__ __forceinline__ Ed ed_generator() {
+    Ed r;
+    r.x = ed_const(ED_GX_MONT); r.y = ed_const(ED_GY_MONT); r.t = ed_const(ED_GT_MONT); r.z = fe_one<EQ>();
+    return r;
+}
+__device__ __forceinline__ Ed ed_select(bool c, const Ed& a, const Ed& b) {
+    Ed r;
+    r.x = fe_select(c, a.x, b.x); r.y = fe_select(c, a.y, b.y); r.t = fe_select(c, a.t, b.t); r.z = fe_select(c, a.z, b.z);
+    return r;
+}
+__device__ __forceinline__ Ed ed_neg(const Ed& a) {
+    Ed r = a;
+    r.x = fe_neg<EQ>(a.x); r.t = fe_neg<EQ>(a.t);
+    return r;
+}
+// add-2008-hwcd-3 (a = -1), strongly unified and complete on this curve: 8M + 1 multiplication by 2d
+__device__ __noinline__ Ed ed_add(Ed p, Ed q) {
+    Fe A = fe_mul<EQ>(fe_sub<EQ>(p.y, p.x), fe_sub<EQ>(q.y, q.x));
+    Fe B = fe_mul<EQ>(fe_add<EQ>(p.y, p.x), fe_add<EQ>(q.y, q.x));
+    Fe C = fe_mul<EQ>(fe_mul<EQ>(p.t, ed_const(ED_D2_MONT)), q.t);
+    Fe D = fe_dbl<EQ>(fe_mul<EQ>(p.z, q.z));
+    Fe E = fe_sub<EQ>(B, A), F = fe_sub<EQ>(D, C), G = fe_add<EQ>(D, C), H = fe_add<EQ>(B, A);
+    Ed r;
+    r.x = fe_mul<EQ>(E, F); r.y = fe_mul<EQ>(G, H); r.t = fe_mul<EQ>(E, H); r.z = fe_mul<EQ>(F, G);
+    return r;
+}
+// dbl-2008-hwcd (a = -1): 4M + 4S
+__device__ __noinline__ Ed ed_double(Ed p) {
+    Fe A = fe_sqr<EQ>(p.x), B = fe_sqr<EQ>(p.y), C = fe_dbl<EQ>(fe_sqr<EQ>(p.z));
+    Fe D = fe_neg<EQ>(A);
+    Fe E = fe_sub<EQ>(fe_sub<EQ>(fe_sqr<EQ>(fe_add<EQ>(p.x, p.y)), A), B);
+    Fe G = fe_add<EQ>(D, B), F = fe_sub<EQ>(G, C), H = fe_sub<EQ>(D, B);
+    Ed r;
+    r.x = fe_mul<EQ>(E, F); r.y = fe_mul<EQ>(G, H); r.t = fe_mul<EQ>(E, H); r.z = fe_mul<EQ>(F, G);
+    return r;
+}
+// [s]P with 4-bit fixed windows, table k*P (k = 1..15) in the HBM workspace (entry-major), wave-uniform control flow
+__device__ __forceinline__ Ed ed_scalar_mul_w4(const Ed& p, const Fe& s_mont, u64* tab, size_t tid, size_t nthreads) {
+    const Fe s = fe_to_canonical<ER>(s_mont);
+    ed_store(tab + ((size_t)0 * nthreads + tid) * 16, p);
+    Ed prev = p;
+    for (int k = 2; k <= 15; ++k) {
+        Ed t = (k & 1) ? ed_add(prev, p) : ed_double(ed_load(tab + ((size_t)(k / 2 - 1) * nthreads + tid) * 16));
+        ed_store(tab + ((size_t)(k - 1) * nthreads + tid) * 16, t);
+        prev = t;
+    }
+    Ed acc = ed_identity();
+    for (int limb = 7; limb >= 0; --limb) {
+        const u32 w = s.v[limb];
+        for (int nib = 7; nib >= 0; --nib) {
+            acc = ed_double(ed_double(ed_double(ed_double(acc))));
+            const u32 d = (w >> (4 * nib)) & 15u;
+            if (__any(d != 0)) {
+                Ed q = ed_load(tab + ((size_t)(d ? d - 1 : 0) * nthreads + tid) * 16);
+                Ed sum = ed_add(acc, q);
+                acc = ed_select(d != 0, sum, acc);
+            }
+        }
+    }
+    return acc;
+}
+// uniform-scalar multiplication without a table (MAC key times a public point)
+__device__ __forceinline__ Ed ed_scalar_mul_plain(const Ed& p, const Fe& s_mont) {
+    const Fe s = fe_to_canonical<ER>(s_mont);
+    Ed acc = ed_identity();
+    for (int limb = 7; limb >= 0; --limb) {
+        const u32 w = s.v[limb];
+        for (int bit = 31; bit >= 0; --bit) {
+            acc = ed_double(acc);
+            const bool take = (w >> bit) & 1u;
+            if (__any(take)) acc = ed_select(take, ed_add(acc, p), acc);
+        }
+    }
+    return acc;
+}
+
+template <bool NEGB>
+__global__ void __launch_bounds__(TPB_ED) k_ed_add(size_t n, const u64* a, const u64* b, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed q = ed_load(b + 16 * i);
+    if (NEGB) q = ed_neg(q);
+    ed_store(out + 16 * i, ed_add(ed_load(a + 16 * i), q));
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_neg(size_t n, const u64* a, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    ed_store(out + 16 * i, ed_neg(ed_load(a + 16 * i)));
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_scalar_mul(size_t n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride,
+                                                           u32 s_div, u64* out, u64* table_ws) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed p = points ? ed_load(points + (size_t)p_stride * (i / p_div)) : ed_generator();
+    Fe s = fe_load(scalars + (size_t)s_stride * (i / s_div));
+    ed_store(out + 16 * i, ed_scalar_mul_w4(p, s, table_ws, i, n));
+}
+// PointShare::add_public (curve/share.rs:57-60)
+__global__ void __launch_bounds__(TPB_ED) k_edshare_add_public(size_t n, int party, Fe key, const u64* shares, const u64* pub, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed rhs = ed_load(pub + 16 * i), sh = ed_load(shares + 32 * i), mac = ed_load(shares + 32 * i + 16);
+    if (party == 0) sh = ed_add(sh, rhs);
+    mac = ed_add(mac, ed_scalar_mul_plain(rhs, key));
+    ed_store(out + 32 * i, sh);
+    ed_store(out + 32 * i + 16, mac);
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_to_affine(size_t n, const u64* pts, u64* out_xy) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed p = ed_load(pts + 16 * i);
+    Fe zi = fe_inv_fermat<EQ>(p.z);
+    fe_store(out_xy + 8 * i, fe_mul<EQ>(p.x, zi));
+    fe_store(out_xy + 8 * i + 4, fe_mul<EQ>(p.y, zi));
+}
+// ark-serialize compressed twisted-Edwards encoding (CurvePoint::to_bytes, curve.rs:103-108): y little-endian, bit 7 of
+// the last byte set iff x > -x (as integers)
+__global__ void __launch_bounds__(TPB_ED) k_ed_to_bytes(size_t n, const u64* pts, unsigned char* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed p = ed_load(pts + 16 * i);
+    Fe zi = fe_inv_fermat<EQ>(p.z);
+    Fe x = fe_mul<EQ>(p.x, zi), y = fe_mul<EQ>(p.y, zi);
+    Fe xc = fe_to_canonical<EQ>(x), nxc = fe_to_canonical<EQ>(fe_neg<EQ>(x)), yc = fe_to_canonical<EQ>(y);
+    u32 br = 0, bo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nxc.v[k], xc.v[k], br, &bo); br = bo; }   // borrow <=> x > -x
+    u32 top = yc.v[7];
+    if (br) top |= 0x80000000u;
+    uint4* q = reinterpret_cast<uint4*>(out + 32 * i);
+    q[0] = make_uint4(yc.v[0], yc.v[1], yc.v[2], yc.v[3]);
+    q[1] = make_uint4(yc.v[4], yc.v[5], yc.v[6], top);
+}
+
+#define ENTER_ED(ctx)                                                                           \
+    if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
+    CtxGuard guard__(ctx);                                                                      \
+    if (guard__.rc) return guard__.rc;                                                          \
+    if ((ctx)->field_id != ARKMPC_CURVE25519_FR) { (ctx)->err = "Curve25519 point ops need a CURVE25519_FR context"; return ARKMPC_ERR_UNSUPPORTED; }
+
+extern "C" {
+
+static int ed_addsub(arkmpc_ctx* ctx, bool sub, size_t m, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, m * 128), ib = st.declare_in(b, m * 128), io = st.declare_out(out, m * 128);
+    if (st.commit()) return st.rc;
+    if (m) {
+        dim3 g(blocks_for(m, TPB_ED)), t(TPB_ED);
+        if (sub) hipLaunchKernelGGL((k_ed_add<true>), g, t, 0, ctx->stream, m, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+        else hipLaunchKernelGGL((k_ed_add<false>), g, t, 0, ctx->stream, m, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+    }
+    return st.finish();
+}
+int arkmpc_ed_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return ed_addsub(ctx, false, n, a, b, out); }
+int arkmpc_ed_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return ed_addsub(ctx, true, n, a, b, out); }
+int arkmpc_edshare_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return ed_addsub(ctx, false, 2 * n, a, b, out); }
+int arkmpc_edshare_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) { return ed_addsub(ctx, true, 2 * n, a, b, out); }
+
+static int ed_neg_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* a, uint64_t* out) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, m * 128), io = st.declare_out(out, m * 128);
+    if (st.commit()) return st.rc;
+    if (m) hipLaunchKernelGGL(k_ed_neg, dim3(blocks_for(m, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, m, st.in<u64>(ia), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_ed_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return ed_neg_impl(ctx, n, a, out); }
+int arkmpc_edshare_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return ed_neg_impl(ctx, 2 * n, a, out); }
+
+static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n_points, u32 p_stride, u32 p_div, const uint64_t* scalars,
+                        size_t scalar_bytes, u32 s_stride, u32 s_div, uint64_t* out) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ip = points ? st.declare_in(points, n_points * 128) : -1;
+    int is = st.declare_in(scalars, scalar_bytes), io = st.declare_out(out, m * 128);
+    const size_t CH = (size_t)1 << 20;
+    const size_t chunk = m < CH ? m : CH;
+    int iw = st.declare_scratch(chunk * 15 * 128);
+    if (st.commit()) return st.rc;
+    for (size_t lo = 0; lo < m; lo += chunk) {
+        const size_t cnt = (m - lo < chunk) ? (m - lo) : chunk;
+        const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
+        const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
+        hipLaunchKernelGGL(k_ed_scalar_mul, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, cnt, pp, p_stride, p_div, sp, s_stride,
+                           s_div, st.out<u64>(io) + 16 * lo, st.scratch<u64>(iw));
+    }
+    return st.finish();
+}
+int arkmpc_ed_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out) {
+    if (n && !points) return ctx ? ark_bad(ctx, "null points") : ARKMPC_ERR_BAD_ARG;
+    return ed_smul_impl(ctx, n, points, n, 16, 1, scalars, n * 32, 4, 1, out);
+}
+int arkmpc_ed_generator_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* scalars, uint64_t* out) {
+    return ed_smul_impl(ctx, n, nullptr, 0, 0, 1, scalars, n * 32, 4, 1, out);
+}
+int arkmpc_edshare_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, const uint64_t* scalars, uint64_t* out) {
+    if (n && !shares) return ctx ? ark_bad(ctx, "null shares") : ARKMPC_ERR_BAD_ARG;
+    return ed_smul_impl(ctx, 2 * n, shares, 2 * n, 16, 1, scalars, n * 32, 4, 2, out);
+}
+int arkmpc_scalarshare_mul_ed_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out) {
+    return ed_smul_impl(ctx, 2 * n, nullptr, 0, 0, 1, scalar_shares, n * 64, 4, 1, out);
+}
+int arkmpc_edshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                              const uint64_t* pub_points, uint64_t* out) {
+    ENTER_ED(ctx);
+    if (party_id != 0 && party_id != 1) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int is = st.declare_in(shares, n * 256), ip = st.declare_in(pub_points, n * 128), io = st.declare_out(out, n * 256);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_edshare_add_public, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, party_id, fe_from_host(mac_key),
+                              st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_ed_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(points, n * 128), io = st.declare_out(out_xy, n * 64);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_ed_to_affine, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_ed_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(points, n * 128), io = st.declare_out(out_bytes, n * 32);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_ed_to_bytes, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.out<unsigned char>(io));
+    return st.finish();
+}
+
+}  // extern "C"

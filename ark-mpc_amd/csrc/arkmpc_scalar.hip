@@ -73,27 +73,6 @@ __global__ void __launch_bounds__(TPB) k_to_bytes_be(size_t n, const u64* a, uns
 // inverse, zeros stay zero.  Each thread inverts INV_K consecutive elements with Montgomery's trick around ONE
 // Fermat exponentiation (a^(p-2)): ~3 multiplications per element + 380/INV_K, instead of 380.
 #define INV_K 8
-template <int F> __device__ __forceinline__ Fe fe_inv_fermat(const Fe& a) {
-    using P = FieldParams<F>;
-    Fe acc = fe_one<F>();
-    for (int limb = 7; limb >= 0; --limb) {
-        // limb of p - 2 with the borrow propagated (BLS12-381 Fr ends in ...00000001)
-        u32 w = P::P(limb);
-        bool borrow = true;   // subtracting 2 from limb 0
-        u32 sub = 2u;
-        for (int l = 0; l <= limb; ++l) {
-            const u32 pl = P::P(l);
-            const u32 s = (l == 0) ? sub : (borrow ? 1u : 0u);
-            if (l == limb) w = pl - s;
-            borrow = pl < s;
-        }
-        for (int bit = 31; bit >= 0; --bit) {
-            acc = fe_sqr<F>(acc);
-            if ((w >> bit) & 1u) acc = fe_mul<F>(acc, a);
-        }
-    }
-    return acc;
-}
 template <int F>
 __global__ void __launch_bounds__(TPB) k_batch_inverse(size_t n, const u64* a, u64* out) {
     const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -339,6 +318,7 @@ __global__ void __launch_bounds__(TPB) k_mac_verify(size_t n, const u64* mine, c
         case 1: { constexpr int F = 1; EXPR_F; } break;                                         \
         case 2: { constexpr int F = 2; EXPR_F; } break;                                         \
         case 3: { constexpr int F = 3; EXPR_F; } break;                                         \
+        case 4: { constexpr int F = 4; EXPR_F; } break;                                         \
         default: return ark_bad(ctx, "bad field id");                                           \
     }
 

@@ -20,7 +20,7 @@ typedef uint64_t u64;
 template <int FID> struct FieldParams;
 #include "field_consts.inc"
 
-enum { F_BN254_FR = 0, F_BLS12_381_FR = 1, F_CURVE25519_FR = 2, F_BN254_FQ = 3, F_NFIELDS = 4 };
+enum { F_BN254_FR = 0, F_BLS12_381_FR = 1, F_CURVE25519_FR = 2, F_BN254_FQ = 3, F_CURVE25519_FQ = 4, F_NFIELDS = 5 };
 
 struct Fe {
     u32 v[8];
@@ -189,4 +189,27 @@ template <int F> __host__ __device__ __forceinline__ Fe fe_reduce_once_loop(Fe a
         for (int i = 0; i < 8; ++i) a.v[i] = d[i];
     }
     return a;
+}
+
+// a^(p-2) (Fermat); 0 -> 0.  The exponent limbs are derived from P with the borrow propagated.
+template <int F> __device__ __forceinline__ Fe fe_inv_fermat(const Fe& a) {
+    using P = FieldParams<F>;
+    Fe acc = fe_one<F>();
+    for (int limb = 7; limb >= 0; --limb) {
+        // limb of p - 2 with the borrow propagated (BLS12-381 Fr ends in ...00000001)
+        u32 w = P::P(limb);
+        bool borrow = true;   // subtracting 2 from limb 0
+        u32 sub = 2u;
+        for (int l = 0; l <= limb; ++l) {
+            const u32 pl = P::P(l);
+            const u32 s = (l == 0) ? sub : (borrow ? 1u : 0u);
+            if (l == limb) w = pl - s;
+            borrow = pl < s;
+        }
+        for (int bit = 31; bit >= 0; --bit) {
+            acc = fe_sqr<F>(acc);
+            if ((w >> bit) & 1u) acc = fe_mul<F>(acc, a);
+        }
+    }
+    return acc;
 }

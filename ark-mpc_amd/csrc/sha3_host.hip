@@ -105,7 +105,8 @@ void host_to_bytes_be(int field_id, const uint64_t mont[4], unsigned char out[32
         case 0: to_be_t<0>(mont, out); break;
         case 1: to_be_t<1>(mont, out); break;
         case 2: to_be_t<2>(mont, out); break;
-        default: to_be_t<3>(mont, out); break;
+        case 3: to_be_t<3>(mont, out); break;
+        default: to_be_t<4>(mont, out); break;
     }
 }
 void host_from_be_bytes_mod_order(int field_id, const unsigned char be[32], uint64_t out_mont[4]) {
@@ -113,6 +114,7 @@ void host_from_be_bytes_mod_order(int field_id, const unsigned char be[32], uint
         case 0: from_be_t<0>(be, out_mont); break;
         case 1: from_be_t<1>(be, out_mont); break;
         case 2: from_be_t<2>(be, out_mont); break;
-        default: from_be_t<3>(be, out_mont); break;
+        case 3: from_be_t<3>(be, out_mont); break;
+        default: from_be_t<4>(be, out_mont); break;
     }
 }

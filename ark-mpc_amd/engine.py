@@ -8,12 +8,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-FIELD_IDS = {"bn254_fr": 0, "bls12_381_fr": 1, "curve25519_fr": 2, "bn254_fq": 3}
+FIELD_IDS = {"bn254_fr": 0, "bls12_381_fr": 1, "curve25519_fr": 2, "bn254_fq": 3, "curve25519_fq": 4}
 FIELD_MODULI = {
     0: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001,
     1: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
     2: 2**252 + 27742317777372353535851937790883648493,
     3: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+    4: 2**255 - 19,
 }
 
 
@@ -225,6 +226,21 @@ class Engine:
     def pointshare_sum(self, n, shares, out): self.call("pointshare_sum", ("size", n), shares, out)
     def commit_points_sha3(self, n, pts, blinders, out): self.call("commit_points_sha3", ("size", n), pts, blinders, out)
     def point_mac_verify(self, n, mine, peer, out_ok): self.call("point_mac_verify", ("size", n), mine, peer, out_ok)
+
+    # ---- Curve25519 (Edwards) points
+    def ed_add(self, n, a, b, out): self.call("ed_add", ("size", n), a, b, out)
+    def ed_sub(self, n, a, b, out): self.call("ed_sub", ("size", n), a, b, out)
+    def ed_neg(self, n, a, out): self.call("ed_neg", ("size", n), a, out)
+    def ed_scalar_mul(self, n, pts, sc, out): self.call("ed_scalar_mul", ("size", n), pts, sc, out)
+    def ed_generator_mul(self, n, sc, out): self.call("ed_generator_mul", ("size", n), sc, out)
+    def ed_to_affine(self, n, pts, out): self.call("ed_to_affine", ("size", n), pts, out)
+    def ed_to_bytes(self, n, pts, out): self.call("ed_to_bytes", ("size", n), pts, out)
+    def edshare_add(self, n, a, b, out): self.call("edshare_add", ("size", n), a, b, out)
+    def edshare_sub(self, n, a, b, out): self.call("edshare_sub", ("size", n), a, b, out)
+    def edshare_neg(self, n, a, out): self.call("edshare_neg", ("size", n), a, out)
+    def edshare_mul_public(self, n, sh, sc, out): self.call("edshare_mul_public", ("size", n), sh, sc, out)
+    def edshare_add_public(self, n, party, key, sh, pub, out): self.call("edshare_add_public", ("size", n), ("int", party), ("key", key), sh, pub, out)
+    def scalarshare_mul_ed_generator(self, n, ss, out): self.call("scalarshare_mul_ed_generator", ("size", n), ss, out)
 
 
 def sha3_256(data: bytes) -> bytes:

@@ -54,7 +54,8 @@ typedef enum {
     ARKMPC_BN254_FR = 0,       /* scalar field of BN254 (ark-bn254, the reference's TestCurve: lib.rs:78) */
     ARKMPC_BLS12_381_FR = 1,   /* scalar field of BLS12-381 */
     ARKMPC_CURVE25519_FR = 2,  /* ed25519 group order (README.md:24 uses ark-curve25519) */
-    ARKMPC_BN254_FQ = 3        /* base field of BN254 (coordinates of G1 points) */
+    ARKMPC_BN254_FQ = 3,       /* base field of BN254 (coordinates of G1 points) */
+    ARKMPC_CURVE25519_FQ = 4   /* 2^255 - 19 (coordinates of Curve25519 / ed25519 points) */
 } arkmpc_field;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -193,6 +194,25 @@ int arkmpc_commit_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points,
                               uint64_t* out_commitments);
 /* all(mine_i + peer_i == identity) (authenticated_curve.rs:127-131), per element: out_ok[i] in {0,1} (host or device per mode) */
 int arkmpc_point_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok);
+
+/* ---- Curve25519 points (context field must be ARKMPC_CURVE25519_FR) -------------------------------------------------
+ * ark_curve25519::EdwardsProjective (README.md:24): twisted-Edwards extended coordinates { x[4], y[4], t[4], z[4] } over
+ * 2^255 - 19 in Montgomery form = 16 x u64, identity (0, 1, 0, 1); PointShare = 32 x u64.  Same CurvePoint / PointShare
+ * semantics as the BN254 entry points above (curve.rs:203-409, curve/share.rs:55-114). */
+int arkmpc_ed_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
+int arkmpc_ed_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
+int arkmpc_ed_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
+int arkmpc_ed_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out);
+int arkmpc_ed_generator_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* scalars, uint64_t* out);
+int arkmpc_ed_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy);        /* n x { x[4], y[4] } */
+int arkmpc_ed_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes);         /* y LE, bit 7 = x > -x */
+int arkmpc_edshare_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
+int arkmpc_edshare_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
+int arkmpc_edshare_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
+int arkmpc_edshare_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, const uint64_t* scalars, uint64_t* out);
+int arkmpc_edshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                              const uint64_t* pub_points, uint64_t* out);
+int arkmpc_scalarshare_mul_ed_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out);
 
 #ifdef __cplusplus
 }

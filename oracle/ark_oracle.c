@@ -28,6 +28,8 @@ static const u64 MODULI[ORA_NFIELDS][4] = {
     {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0x0000000000000000ULL, 0x1000000000000000ULL},
     /* BN254 Fq  0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47 */
     {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    /* Curve25519 Fq  2^255 - 19 */
+    {0xffffffffffffffedULL, 0xffffffffffffffffULL, 0xffffffffffffffffULL, 0x7fffffffffffffffULL},
 };
 
 static ora_field FIELDS[ORA_NFIELDS];
@@ -633,4 +635,84 @@ int ora_batch_mul_9pass_mt(int fid, size_t n, int party, const u64 key[4], const
     }
     free(th); free(jobs);
     return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Curve25519 in twisted-Edwards form (ark_curve25519::EdwardsProjective): -x^2 + y^2 = 1 + d x^2 y^2 over 2^255 - 19,
+ * extended coordinates {x, y, t, z}, identity (0, 1, 0, 1).  curve.rs:194-409 delegates to ark-ec; the published
+ * formulas are add-2008-hwcd-3 (complete for a = -1) and the affine group law it implements.
+ * ---------------------------------------------------------------------------------------- */
+#define EQF (ora_get_field(ORA_CURVE25519_FQ))
+#define ERF (ora_get_field(ORA_CURVE25519_FR))
+static void ed_d2(u64 out[4]) {   /* 2*d, d = -121665/121666 */
+    const ora_field* q = EQF;
+    u64 a[4] = {121665, 0, 0, 0}, b[4] = {121666, 0, 0, 0}, am[4], bm[4], bi[4], d[4];
+    ora_fp_from_canonical(q, a, am); ora_fp_from_canonical(q, b, bm);
+    ora_fp_inv(q, bm, bi); ora_fp_mul(q, am, bi, d); ora_fp_neg(q, d, d);
+    ora_fp_add(q, d, d, out);
+}
+void ora_ed_identity(u64 out[16]) {
+    const ora_field* q = EQF; memset(out, 0, 128); memcpy(out + 4, q->r, 32); memcpy(out + 12, q->r, 32);
+}
+/* RFC 8032 base point: y = 4/5, x the even root */
+void ora_ed_generator(u64 out[16]) {
+    const ora_field* q = EQF;
+    static const u64 GX[4] = {0xc9562d608f25d51aULL, 0x692cc7609525a7b2ULL, 0xc0a4e231fdd6dc5cULL, 0x216936d3cd6e53feULL};
+    static const u64 GY[4] = {0x6666666666666658ULL, 0x6666666666666666ULL, 0x6666666666666666ULL, 0x6666666666666666ULL};
+    ora_fp_from_canonical(q, GX, out); ora_fp_from_canonical(q, GY, out + 4);
+    ora_fp_mul(q, out, out + 4, out + 8); memcpy(out + 12, q->r, 32);
+}
+void ora_ed_neg(const u64 a[16], u64 out[16]) {
+    const ora_field* q = EQF; u64 nx[4], nt[4];
+    ora_fp_neg(q, a, nx); ora_fp_neg(q, a + 8, nt);
+    memcpy(out, nx, 32); memmove(out + 4, a + 4, 32); memcpy(out + 8, nt, 32); memmove(out + 12, a + 12, 32);
+}
+void ora_ed_add(const u64 p[16], const u64 r[16], u64 out[16]) {
+    const ora_field* q = EQF;
+    u64 A[4], B[4], C[4], D[4], E[4], F[4], G[4], H[4], t1[4], t2[4], k[4], res[16];
+    ed_d2(k);
+    ora_fp_sub(q, p + 4, p, t1); ora_fp_sub(q, r + 4, r, t2); ora_fp_mul(q, t1, t2, A);
+    ora_fp_add(q, p + 4, p, t1); ora_fp_add(q, r + 4, r, t2); ora_fp_mul(q, t1, t2, B);
+    ora_fp_mul(q, p + 8, k, C); ora_fp_mul(q, C, r + 8, C);
+    ora_fp_mul(q, p + 12, r + 12, D); ora_fp_add(q, D, D, D);
+    ora_fp_sub(q, B, A, E); ora_fp_sub(q, D, C, F); ora_fp_add(q, D, C, G); ora_fp_add(q, B, A, H);
+    ora_fp_mul(q, E, F, res); ora_fp_mul(q, G, H, res + 4); ora_fp_mul(q, E, H, res + 8); ora_fp_mul(q, F, G, res + 12);
+    memcpy(out, res, 128);
+}
+/* curve.rs:403-409: [s]P, MSB-first double-and-add through the complete addition law */
+void ora_ed_scalar_mul(const u64 pt[16], const u64 scalar_mont[4], u64 out[16]) {
+    u64 s[4]; ora_fp_to_canonical(ERF, scalar_mont, s);
+    u64 acc[16]; ora_ed_identity(acc);
+    for (int i = 255; i >= 0; --i) {
+        ora_ed_add(acc, acc, acc);
+        if ((s[i / 64] >> (i % 64)) & 1) ora_ed_add(acc, pt, acc);
+    }
+    memcpy(out, acc, 128);
+}
+void ora_ed_to_affine(const u64 a[16], u64 out_xy[8]) {
+    const ora_field* q = EQF; u64 zi[4];
+    ora_fp_inv(q, a + 12, zi); ora_fp_mul(q, a, zi, out_xy); ora_fp_mul(q, a + 4, zi, out_xy + 4);
+}
+/* ark-serialize compressed TE encoding: y little-endian, bit 7 of the last byte = x > -x */
+void ora_ed_to_bytes(const u64 a[16], unsigned char out[32]) {
+    const ora_field* q = EQF; u64 xy[8], xc[4], nx[4], nxc[4], yc[4];
+    ora_ed_to_affine(a, xy);
+    ora_fp_to_canonical(q, xy, xc); ora_fp_neg(q, xy, nx); ora_fp_to_canonical(q, nx, nxc); ora_fp_to_canonical(q, xy + 4, yc);
+    for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) out[8 * i + b] = (unsigned char)(yc[i] >> (8 * b));
+    if (geq(xc, nxc) && memcmp(xc, nxc, 32) != 0) out[31] |= 0x80;
+}
+void ora_ed_batch_add(size_t n, const u64* a, const u64* b, u64* out) { for (size_t i = 0; i < n; ++i) ora_ed_add(a + 16 * i, b + 16 * i, out + 16 * i); }
+void ora_ed_batch_neg(size_t n, const u64* a, u64* out) { for (size_t i = 0; i < n; ++i) ora_ed_neg(a + 16 * i, out + 16 * i); }
+void ora_ed_batch_scalar_mul(size_t n, const u64* pts, size_t p_div, const u64* scalars, size_t s_div, u64* out) {
+    for (size_t i = 0; i < n; ++i) ora_ed_scalar_mul(pts + 16 * (i / p_div), scalars + 4 * (i / s_div), out + 16 * i);
+}
+void ora_ed_batch_to_affine(size_t n, const u64* pts, u64* out_xy) { for (size_t i = 0; i < n; ++i) ora_ed_to_affine(pts + 16 * i, out_xy + 8 * i); }
+/* curve/share.rs:57-60 */
+void ora_edshare_batch_add_public(size_t n, int party, const u64 key[4], const u64* shares, const u64* pub, u64* out) {
+    for (size_t i = 0; i < n; ++i) {
+        u64 kp[16];
+        ora_ed_scalar_mul(pub + 16 * i, key, kp);
+        if (party == 0) ora_ed_add(shares + 32 * i, pub + 16 * i, out + 32 * i); else memmove(out + 32 * i, shares + 32 * i, 128);
+        ora_ed_add(shares + 32 * i + 16, kp, out + 32 * i + 16);
+    }
 }

@@ -36,7 +36,7 @@ extern "C" {
 
 typedef uint64_t u64;
 
-enum { ORA_BN254_FR = 0, ORA_BLS12_381_FR = 1, ORA_CURVE25519_FR = 2, ORA_BN254_FQ = 3, ORA_NFIELDS = 4 };
+enum { ORA_BN254_FR = 0, ORA_BLS12_381_FR = 1, ORA_CURVE25519_FR = 2, ORA_BN254_FQ = 3, ORA_CURVE25519_FQ = 4, ORA_NFIELDS = 5 };
 
 typedef struct {
     u64 p[4];   /* modulus */
@@ -132,6 +132,20 @@ void ora_pointshare_batch_add_public(size_t n, int party_id, const u64 mac_key[4
 void ora_scalarshare_batch_mul_generator(size_t n, const u64* scalar_shares, u64* out);            /* :754-780 */
 void ora_scalarshare_batch_mul_point(size_t n, const u64* scalar_shares, const u64* points, u64* out); /* curve.rs:483-517 */
 void ora_g1_batch_to_affine(size_t n, const u64* pts, u64* out_xy, unsigned char* is_inf);
+
+/* ---- Curve25519, twisted Edwards extended coordinates {x,y,t,z} = 16 x u64 (ark_curve25519::EdwardsProjective) ---- */
+void ora_ed_identity(u64 out[16]);
+void ora_ed_generator(u64 out[16]);
+void ora_ed_add(const u64 a[16], const u64 b[16], u64 out[16]);
+void ora_ed_neg(const u64 a[16], u64 out[16]);
+void ora_ed_scalar_mul(const u64 pt[16], const u64 scalar_mont[4], u64 out[16]);
+void ora_ed_to_affine(const u64 a[16], u64 out_xy[8]);
+void ora_ed_to_bytes(const u64 a[16], unsigned char out[32]);
+void ora_ed_batch_add(size_t n, const u64* a, const u64* b, u64* out);
+void ora_ed_batch_neg(size_t n, const u64* a, u64* out);
+void ora_ed_batch_scalar_mul(size_t n, const u64* pts, size_t p_div, const u64* scalars, size_t s_div, u64* out);
+void ora_ed_batch_to_affine(size_t n, const u64* pts, u64* out_xy);
+void ora_edshare_batch_add_public(size_t n, int party_id, const u64 mac_key[4], const u64* shares, const u64* pub, u64* out);
 
 /* ---- PartyIDBeaverSource (offline_prep.rs:88-170) ---- */
 void ora_dummy_mac_key_share(int field_id, int party_id, u64 out[4]);

@@ -165,6 +165,29 @@ class Oracle:
     def scalarshare_mul_point(self, ss, pts):
         n = len(ss) // 8; out = np.zeros(24 * n, dtype=np.uint64); self._call("ora_scalarshare_batch_mul_point", n, ss, pts, out); return out
 
+    # -- Curve25519 (Edwards)
+    def ed_generator(self):
+        out = np.zeros(16, dtype=np.uint64); self.lib.ora_ed_generator(self._p(out)); return out
+    def ed_identity(self):
+        out = np.zeros(16, dtype=np.uint64); self.lib.ora_ed_identity(self._p(out)); return out
+    def ed_batch_add(self, a, b):
+        n = len(a) // 16; out = np.zeros(16 * n, dtype=np.uint64); self._call("ora_ed_batch_add", n, a, b, out); return out
+    def ed_batch_neg(self, a):
+        n = len(a) // 16; out = np.zeros(16 * n, dtype=np.uint64); self._call("ora_ed_batch_neg", n, a, out); return out
+    def ed_batch_scalar_mul(self, pts, scalars, n=None, p_div=1, s_div=1):
+        n = n if n is not None else len(pts) // 16
+        out = np.zeros(16 * n, dtype=np.uint64); self._call("ora_ed_batch_scalar_mul", n, pts, p_div, scalars, s_div, out); return out
+    def ed_batch_to_affine(self, pts):
+        n = len(pts) // 16; out = np.zeros(8 * n, dtype=np.uint64); self._call("ora_ed_batch_to_affine", n, pts, out); return out
+    def ed_to_bytes(self, pts):
+        n = len(pts) // 16; out = np.zeros(32 * n, dtype=np.uint8)
+        for i in range(n):
+            self.lib.ora_ed_to_bytes(self._p(pts[16 * i:16 * i + 16].copy()), ctypes.c_void_p(out.ctypes.data + 32 * i))
+        return out
+    def edshare_add_public(self, party, key, shares, pub):
+        n = len(shares) // 32; out = np.zeros(32 * n, dtype=np.uint64)
+        self._call("ora_edshare_batch_add_public", n, party, key, shares, pub, out); return out
+
     # -- PartyIDBeaverSource
     def dummy_mac_key_share(self, fid, party):
         out = np.zeros(4, dtype=np.uint64); self._call("ora_dummy_mac_key_share", fid, party, out); return out

@@ -11,6 +11,7 @@ P = {
     1: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,  # BLS12-381 Fr
     2: 2**252 + 27742317777372353535851937790883648493,                       # Curve25519 Fr
     3: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,  # BN254 Fq
+    4: 2**255 - 19,                                                          # Curve25519 Fq
 }
 R = 1 << 256
 # arkworks' published constants (ark-bn254 / ark-bls12-381 / ark-curve25519 `FrConfig`)
@@ -109,3 +110,50 @@ def g1_jacobian_mont(a, z=1):
         return limbs(to_mont(3, 1)) + limbs(to_mont(3, 1)) + [0, 0, 0, 0]
     x, y = a
     return limbs(to_mont(3, x * z * z)) + limbs(to_mont(3, y * z * z * z)) + limbs(to_mont(3, z))
+
+
+# ---- Curve25519 in twisted-Edwards form (-x^2 + y^2 = 1 + d x^2 y^2 over 2^255 - 19), affine points, identity (0, 1)
+EQ = P[4]
+EL = P[2]
+ED_D = (-121665 * pow(121666, -1, EQ)) % EQ
+ED_B = (15112221349535400772501151409588531511454012693041857206046113283949847762202,
+        46316835694926478169428394003475163141307993866256225615783033603165251855960)
+
+
+def ed_add(a, b):
+    x1, y1 = a
+    x2, y2 = b
+    k = ED_D * x1 * x2 * y1 * y2 % EQ
+    x3 = (x1 * y2 + x2 * y1) * pow(1 + k, -1, EQ) % EQ
+    y3 = (y1 * y2 + x1 * x2) * pow(1 - k, -1, EQ) % EQ
+    return (x3, y3)
+
+
+def ed_neg(a):
+    return ((-a[0]) % EQ, a[1])
+
+
+def ed_mul(a, k):
+    k %= EL
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = ed_add(acc, a)
+        a = ed_add(a, a)
+        k >>= 1
+    return acc
+
+
+def ed_compress(a):
+    """ark-serialize compressed twisted-Edwards encoding: y little-endian, bit 7 of the last byte set iff x > -x."""
+    x, y = a
+    b = bytearray(y.to_bytes(32, "little"))
+    if x > (EQ - x) % EQ:
+        b[31] |= 0x80
+    return bytes(b)
+
+
+def ed_extended_mont(a, z=1):
+    """extended coordinates (X, Y, T, Z) = (x z, y z, x y z, z) as Montgomery limbs"""
+    x, y = a
+    return limbs(to_mont(4, x * z)) + limbs(to_mont(4, y * z)) + limbs(to_mont(4, x * y * z)) + limbs(to_mont(4, z))

@@ -9,8 +9,8 @@ from helpers import (mont_array, from_mont_array, mixed_values, rand_values, lim
 
 pytestmark = pytest.mark.gpu
 
-FIDS = [0, 1, 2, 3]
-NAMES = {0: "bn254_fr", 1: "bls12_381_fr", 2: "curve25519_fr", 3: "bn254_fq"}
+FIDS = [0, 1, 2, 3, 4]
+NAMES = {0: "bn254_fr", 1: "bls12_381_fr", 2: "curve25519_fr", 3: "bn254_fq", 4: "curve25519_fq"}
 SIZES = [1, 63, 257, 1000]
 
 

@@ -29,7 +29,7 @@ def test_montgomery_constants_match_published(oracle, fid):
     assert f.bits == p.bit_length()
 
 
-@pytest.mark.parametrize("fid", FIDS)
+@pytest.mark.parametrize("fid", FIDS + [4])
 def test_field_ops_vs_bigint(oracle, fid):
     p = pyref.P[fid]
     a = mixed_values(fid, 200, seed=100 + fid)
