@@ -1,6 +1,7 @@
 // arkmpc_internal.hpp -- context, error plumbing and host-buffer staging shared by the C-ABI TUs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,6 +28,10 @@ struct arkmpc_ctx {
     unsigned char* h_pin[2] = {nullptr, nullptr};
     size_t h_pin_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // kernel timer: event pairs bound to the dispatch of the NEXT K1 / K3 launch (hipExtLaunchKernelGGL)
+    static constexpr int kTimerSlots = 64;
+    hipEvent_t tev[2 * kTimerSlots] = {};
+    int timer_slot = -1;
 };
 
 #define ARK_HIP(ctx, call)                                                                      \
@@ -144,6 +149,18 @@ struct Stage {
         return ARKMPC_OK;
     }
 };
+
+// launch on the context's stream; if a kernel-timer slot is armed, bind its start/stop events to this dispatch
+template <class K, class... A>
+static inline void launch_k(arkmpc_ctx* ctx, K kernel, dim3 grid, dim3 block, A... args) {
+    if (ctx->timer_slot >= 0) {
+        const int s = ctx->timer_slot;
+        ctx->timer_slot = -1;
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->tev[2 * s], ctx->tev[2 * s + 1], 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
+    }
+}
 
 static inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
 

@@ -340,13 +340,13 @@ static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u
     const bool split = x.stride == 4 && y.stride == 4 && a.stride == 4 && b.stride == 4;
     static const int aos_mode = getenv("ARKMPC_K1_NT_AOS") ? atoi(getenv("ARKMPC_K1_NT_AOS")) & 7 : 0;
     switch (split ? k1_nt_mode() : aos_mode) {
-        case 1: hipLaunchKernelGGL((k_beaver_mask<F, 1>), g, t, 0, ctx->stream, n, x, y, a, b, out); break;
-        case 2: hipLaunchKernelGGL((k_beaver_mask<F, 2>), g, t, 0, ctx->stream, n, x, y, a, b, out); break;
-        case 3: hipLaunchKernelGGL((k_beaver_mask<F, 3>), g, t, 0, ctx->stream, n, x, y, a, b, out); break;
-        case 4: hipLaunchKernelGGL((k_beaver_mask<F, 4>), g, t, 0, ctx->stream, n, x, y, a, b, out); break;
-        case 5: hipLaunchKernelGGL((k_beaver_mask<F, 5>), g, t, 0, ctx->stream, n, x, y, a, b, out); break;
-        case 7: hipLaunchKernelGGL((k_beaver_mask<F, 7>), g, t, 0, ctx->stream, n, x, y, a, b, out); break;
-        default: hipLaunchKernelGGL((k_beaver_mask<F, 0>), g, t, 0, ctx->stream, n, x, y, a, b, out); break;
+        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out); break;
+        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out); break;
+        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out); break;
+        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out); break;
+        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out); break;
+        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out); break;
+        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out); break;
     }
 }
 
@@ -370,19 +370,19 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                 const size_t cs = (size_t)a_s.stride * lo, os = (size_t)o_s.stride * lo;
                 // split-column layout (stride 4): once-streamed data carries non-temporal hints; AoS: none (halves share lines)
                 if (a_s.stride == 4 && o_s.stride == 4)
-                    hipLaunchKernelGGL((k_beaver_finish_asm<F, 1>), dim3(blocks_for(cnt, TPB)), dim3(TPB), 0, ctx->stream, (u32)cnt, mask, k,
+                    launch_k(ctx, k_beaver_finish_asm<F, 1>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k,
                                        my_de + 4 * lo, my_de + 4 * (n + lo), peer_de + 4 * lo, peer_de + 4 * (n + lo), a_s.p + cs, a_m.p + cs,
                                        b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u, o_s.stride * 8u);
                 else
-                    hipLaunchKernelGGL((k_beaver_finish_asm<F, 0>), dim3(blocks_for(cnt, TPB)), dim3(TPB), 0, ctx->stream, (u32)cnt, mask, k,
+                    launch_k(ctx, k_beaver_finish_asm<F, 0>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k,
                                        my_de + 4 * lo, my_de + 4 * (n + lo), peer_de + 4 * lo, peer_de + 4 * (n + lo), a_s.p + cs, a_m.p + cs,
                                        b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u, o_s.stride * 8u);
             }
             return;
         }
     }
-    hipLaunchKernelGGL((k_beaver_finish<F, true>), dim3(blocks_for(n, TPB)), dim3(TPB), 0, ctx->stream, n, party, k, my_de, peer_de,
-                       (const u64*)nullptr, a_s, a_m, b_s, b_m, c_s, c_m, o_s, o_m);
+    launch_k(ctx, k_beaver_finish<F, true>, dim3(blocks_for(n, TPB)), dim3(TPB), n, party, k, my_de, peer_de, (const u64*)nullptr, a_s, a_m,
+             b_s, b_m, c_s, c_m, o_s, o_m);
 }
 
 template <int F>
@@ -443,6 +443,7 @@ int arkmpc_ctx_destroy(arkmpc_ctx* ctx) {
             if (ctx->h_pin[i]) (void)hipHostFree(ctx->h_pin[i]);
             if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
         }
+        for (auto& e : ctx->tev) if (e) (void)hipEventDestroy(e);
         if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -467,6 +468,22 @@ int arkmpc_ctx_set_host_buffers(arkmpc_ctx* ctx, int enabled) {
 int arkmpc_sync(arkmpc_ctx* ctx) {
     ENTER(ctx);
     ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ARKMPC_OK;
+}
+
+int arkmpc_kernel_timer_arm(arkmpc_ctx* ctx, int slot) {
+    ENTER(ctx);
+    if (slot < 0 || slot >= arkmpc_ctx::kTimerSlots) return ark_bad(ctx, "timer slot out of range");
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->tev[2 * slot + i]) ARK_HIP(ctx, hipEventCreate(&ctx->tev[2 * slot + i]));
+    ctx->timer_slot = slot;
+    return ARKMPC_OK;
+}
+int arkmpc_kernel_timer_ms(arkmpc_ctx* ctx, int slot, float* out_ms) {
+    ENTER(ctx);
+    if (slot < 0 || slot >= arkmpc_ctx::kTimerSlots || !out_ms || !ctx->tev[2 * slot]) return ark_bad(ctx, "timer slot not armed");
+    ARK_HIP(ctx, hipEventSynchronize(ctx->tev[2 * slot + 1]));
+    ARK_HIP(ctx, hipEventElapsedTime(out_ms, ctx->tev[2 * slot], ctx->tev[2 * slot + 1]));
     return ARKMPC_OK;
 }
 

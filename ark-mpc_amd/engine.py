@@ -111,6 +111,14 @@ class Engine:
     def set_stream(self, stream_ptr):
         self._ck(self.lib.arkmpc_ctx_set_stream(self.h, ctypes.c_void_p(int(stream_ptr))))
 
+    def kernel_timer_arm(self, slot):
+        self._ck(self.lib.arkmpc_kernel_timer_arm(self.h, ctypes.c_int(int(slot))))
+
+    def kernel_timer_ms(self, slot):
+        ms = ctypes.c_float(0.0)
+        self._ck(self.lib.arkmpc_kernel_timer_ms(self.h, ctypes.c_int(int(slot)), ctypes.byref(ms)))
+        return float(ms.value)
+
     def sync(self):
         self._ck(self.lib.arkmpc_sync(self.h))
 

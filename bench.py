@@ -54,8 +54,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for launch-path tests)")
     ap.add_argument("--sets", type=int, default=2, help="independent workload sets rotated step by step, so that no input line of step s "
                     "can still be cached (256 MiB Infinity Cache) when step s+1 runs; 1 = reuse the same buffers every step")
-    ap.add_argument("--event-every", type=int, default=4, help="record the per-kernel HIP events on every k-th timed step only "
-                    "(each event record is an extra packet on the stream; the whole region is bracketed by one event pair regardless)")
+    ap.add_argument("--event-every", type=int, default=4, help="time the four kernels of every k-th timed step with dispatch-bound HIP events (at most 16 steps); "
+                    "the whole region is bracketed by one event pair regardless")
     ap.add_argument("--k3-order", default="01", choices=["01", "10"], help="order of the two parties' K2+K3 launches after K1(P0), K1(P1). "
                     "The parties are independent; measured: no difference (within +-1 %).")
     ap.add_argument("--chunks", type=int, default=1, help="split each step's batch into this many gate ranges, each run K1,K1,K3,K3 "
@@ -154,17 +154,16 @@ def prepare_step(eng, n, parties, layout, chunks=1, k3_order="01"):
     return calls
 
 
-def step(calls, evs=None):
-    if evs is None or len(calls) != 4:
-        if evs is not None: evs[0].record()
+def step(calls, eng=None, slot_base=None):
+    """One step = the pre-bound launches in order.  With slot_base set, each launch gets a kernel-timer slot: HIP events bound
+    to the kernel's own dispatch (hipExtLaunchKernelGGL), so its duration excludes the dispatch gap."""
+    if slot_base is None:
         for c in calls:
             c()
-        if evs is not None: evs[4].record()
         return
-    evs[0].record()
-    for i, c in enumerate(calls):
+    for j, c in enumerate(calls):
+        eng.kernel_timer_arm(slot_base + j)
         c()
-        evs[i + 1].record()
 
 
 def check_results(eng, n, parties, truth, layout):
@@ -273,13 +272,15 @@ def main():
     for w in range(args.warmup):
         step(call_sets[w % len(call_sets)])
     barrier()
-    sampled = [s for s in range(args.steps) if s % max(1, args.event_every) == 0]
-    evs = {s: [torch.cuda.Event(enable_timing=True) for _ in range(5)] for s in sampled}
+    # per-kernel durations: on sampled steps each of the four launches carries a dispatch-bound HIP event pair (64 slots)
+    every = max(1, args.event_every, -(-args.steps // 16))
+    sampled = [s for s in range(args.steps) if s % every == 0][:16] if args.chunks == 1 else []
+    slot_of = {s: 4 * i for i, s in enumerate(sampled)}
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev_begin.record()
     for s in range(args.steps):
-        step(call_sets[s % len(call_sets)], evs.get(s))
+        step(call_sets[s % len(call_sets)], eng, slot_of.get(s))
     ev_end.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -287,9 +288,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # per-kernel durations from the in-stream HIP events of the sampled steps of the timed region
-    if args.chunks == 1:
-        seg = np.array([[evs[s][i].elapsed_time(evs[s][i + 1]) for i in range(4)] for s in sampled])  # ms
+    if sampled:
+        seg = np.array([[eng.kernel_timer_ms(slot_of[s] + j) for j in range(4)] for s in sampled])  # ms
         k1_ms = float(seg[:, :2].mean())
         k3_ms = float(seg[:, 2:].mean())
     else:
@@ -321,7 +321,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_beaver_finish_asm<0,NT> (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": n * ALG_BYTES_K3, "avg_launch_ms": k3_ms,
-                         "avg_launch_ms_note": "in-stream HIP events: includes the dispatch gap after the previous kernel",
+                         "avg_launch_ms_note": "HIP events bound to the kernel dispatch (hipExtLaunchKernelGGL) on sampled steps of the timed region",
                          "rocprof_avg_launch_ms": rocprof_ms},
             "pipeline": {"algorithmic_GBps": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9,
                          "frac_of_hbm_peak": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,

@@ -68,6 +68,11 @@ int arkmpc_ctx_set_stream(arkmpc_ctx* ctx, void* hip_stream);
 int arkmpc_ctx_set_host_buffers(arkmpc_ctx* ctx, int enabled);
 int arkmpc_sync(arkmpc_ctx* ctx);
 const char* arkmpc_last_error(arkmpc_ctx* ctx);
+/* Kernel timer: arm slot s (0..63) and the NEXT Beaver kernel launch (K1 or K2+K3) on this context gets HIP events bound to
+ * its dispatch (hipExtLaunchKernelGGL start/stop events): arkmpc_kernel_timer_ms then returns that kernel's own duration
+ * (it blocks until the kernel has finished).  Unlike marker events recorded between launches this excludes the dispatch gap. */
+int arkmpc_kernel_timer_arm(arkmpc_ctx* ctx, int slot);
+int arkmpc_kernel_timer_ms(arkmpc_ctx* ctx, int slot, float* out_ms);
 const char* arkmpc_version(void);
 int arkmpc_device_count(void);
 /* device memory helpers for callers without their own allocator (Rust shim, tests) */
