@@ -9,10 +9,14 @@
 // a square, d is not), so addition needs no exceptional cases at all; doubling is dbl-2008-hwcd.
 // Scalars are Curve25519 Fr elements: the context's field must be ARKMPC_CURVE25519_FR.
 #include "arkmpc_internal.hpp"
+#include "fp_asm.cuh"
 #include <cstdlib>
 
 #define TPB_ED 128
 constexpr int EQ = F_CURVE25519_FQ;
+// coordinate multiplications use the hand-scheduled block (tools/gen_asm_kernels.py), as the BN254 point kernels do
+#define EQ_MUL(a, b) fe_mul_fast<F_CURVE25519_FQ>(a, b)
+#define EQ_SQR(a) EQ_MUL(a, a)
 constexpr int ER = F_CURVE25519_FR;
 #include "ed25519_consts.inc"
 
@@ -55,23 +59,23 @@ __device__ __forceinline__ Ed ed_neg(const Ed& a) {
 }
 // add-2008-hwcd-3 (a = -1), strongly unified and complete on this curve: 8M + 1 multiplication by 2d
 __device__ __noinline__ Ed ed_add(Ed p, Ed q) {
-    Fe A = fe_mul<EQ>(fe_sub<EQ>(p.y, p.x), fe_sub<EQ>(q.y, q.x));
-    Fe B = fe_mul<EQ>(fe_add<EQ>(p.y, p.x), fe_add<EQ>(q.y, q.x));
-    Fe C = fe_mul<EQ>(fe_mul<EQ>(p.t, ed_const(ED_D2_MONT)), q.t);
-    Fe D = fe_dbl<EQ>(fe_mul<EQ>(p.z, q.z));
+    Fe A = EQ_MUL(fe_sub<EQ>(p.y, p.x), fe_sub<EQ>(q.y, q.x));
+    Fe B = EQ_MUL(fe_add<EQ>(p.y, p.x), fe_add<EQ>(q.y, q.x));
+    Fe C = EQ_MUL(EQ_MUL(p.t, ed_const(ED_D2_MONT)), q.t);
+    Fe D = fe_dbl<EQ>(EQ_MUL(p.z, q.z));
     Fe E = fe_sub<EQ>(B, A), F = fe_sub<EQ>(D, C), G = fe_add<EQ>(D, C), H = fe_add<EQ>(B, A);
     Ed r;
-    r.x = fe_mul<EQ>(E, F); r.y = fe_mul<EQ>(G, H); r.t = fe_mul<EQ>(E, H); r.z = fe_mul<EQ>(F, G);
+    r.x = EQ_MUL(E, F); r.y = EQ_MUL(G, H); r.t = EQ_MUL(E, H); r.z = EQ_MUL(F, G);
     return r;
 }
 // dbl-2008-hwcd (a = -1): 4M + 4S
 __device__ __noinline__ Ed ed_double(Ed p) {
-    Fe A = fe_sqr<EQ>(p.x), B = fe_sqr<EQ>(p.y), C = fe_dbl<EQ>(fe_sqr<EQ>(p.z));
+    Fe A = EQ_SQR(p.x), B = EQ_SQR(p.y), C = fe_dbl<EQ>(EQ_SQR(p.z));
     Fe D = fe_neg<EQ>(A);
-    Fe E = fe_sub<EQ>(fe_sub<EQ>(fe_sqr<EQ>(fe_add<EQ>(p.x, p.y)), A), B);
+    Fe E = fe_sub<EQ>(fe_sub<EQ>(EQ_SQR(fe_add<EQ>(p.x, p.y)), A), B);
     Fe G = fe_add<EQ>(D, B), F = fe_sub<EQ>(G, C), H = fe_sub<EQ>(D, B);
     Ed r;
-    r.x = fe_mul<EQ>(E, F); r.y = fe_mul<EQ>(G, H); r.t = fe_mul<EQ>(E, H); r.z = fe_mul<EQ>(F, G);
+    r.x = EQ_MUL(E, F); r.y = EQ_MUL(G, H); r.t = EQ_MUL(E, H); r.z = EQ_MUL(F, G);
     return r;
 }
 // [s]P with 4-bit fixed windows, table k*P (k = 1..15) in the HBM workspace (entry-major), wave-uniform control flow
@@ -150,8 +154,8 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_to_affine(size_t n, const u64* pt
     if (i >= n) return;
     Ed p = ed_load(pts + 16 * i);
     Fe zi = fe_inv_fermat<EQ>(p.z);
-    fe_store(out_xy + 8 * i, fe_mul<EQ>(p.x, zi));
-    fe_store(out_xy + 8 * i + 4, fe_mul<EQ>(p.y, zi));
+    fe_store(out_xy + 8 * i, EQ_MUL(p.x, zi));
+    fe_store(out_xy + 8 * i + 4, EQ_MUL(p.y, zi));
 }
 // ark-serialize compressed twisted-Edwards encoding (CurvePoint::to_bytes, curve.rs:103-108): y little-endian, bit 7 of
 // the last byte set iff x > -x (as integers)
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_to_bytes(size_t n, const u64* pts
     if (i >= n) return;
     Ed p = ed_load(pts + 16 * i);
     Fe zi = fe_inv_fermat<EQ>(p.z);
-    Fe x = fe_mul<EQ>(p.x, zi), y = fe_mul<EQ>(p.y, zi);
+    Fe x = EQ_MUL(p.x, zi), y = EQ_MUL(p.y, zi);
     Fe xc = fe_to_canonical<EQ>(x), nxc = fe_to_canonical<EQ>(fe_neg<EQ>(x)), yc = fe_to_canonical<EQ>(y);
     u32 br = 0, bo;
 #pragma unroll

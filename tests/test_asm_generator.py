@@ -19,7 +19,7 @@ def test_emulated_stream_matches_bigint(fid):
     assert mp["nv"] <= 128                                        # 4 waves/SIMD budget
 
 
-@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("fid", [0, 1, 2, 3, 4])
 def test_single_montmul_block_matches_bigint(fid):
     name, p = g.FIELDS[fid]
     E, mp = g.selftest_montmul(p, trials=120, seed=fid)

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Curve25519 (Edwards) scalar-mul throughput: 2^18 PointShare x Scalar = 2^19 scalar-muls."""
+import importlib, json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+pkg = importlib.import_module("ark-mpc_amd")
+e = pkg.Engine("curve25519_fr", device=0, stream=torch.cuda.current_stream().cuda_stream)
+n = 1 << int(os.environ.get("LOG2N", "18"))
+g = torch.Generator(device="cuda"); g.manual_seed(7)
+def rnd(cnt):
+    raw = torch.randint(-(2**63), 2**63 - 1, (4 * cnt,), dtype=torch.int64, device="cuda", generator=g)
+    out = torch.empty_like(raw); e.scalar_from_canonical(cnt, raw, out); return out
+shares = torch.empty(32 * n, dtype=torch.int64, device="cuda")
+e.scalarshare_mul_ed_generator(n, rnd(2 * n), shares)
+sc = rnd(n); out = torch.empty_like(shares)
+e.edshare_mul_public(n, shares, sc, out); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3): e.edshare_mul_public(n, shares, sc, out)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 3 * 1e-3
+print(json.dumps({"workload": "2^%d EdPointShare x Scalar = %d scalar-muls" % (int(np.log2(n)), 2 * n), "ms": t * 1e3, "scalar_muls_per_s": 2 * n / t}))
