@@ -640,3 +640,6 @@ int arkmpc_g1_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_
 }
 
 }  // extern "C"
+
+// variable-base MSM (bucket method): CurvePoint::msm / msm_authenticated
+#include "arkmpc_msm.inc"

@@ -28,6 +28,8 @@ struct arkmpc_ctx {
     unsigned char* h_pin[2] = {nullptr, nullptr};
     size_t h_pin_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // small pinned buffer (64 KiB): window sums of the MSM for the host-side Horner fold
+    unsigned char* h_small = nullptr;
     // kernel timer: event pairs bound to the dispatch of the NEXT K1 / K3 launch (hipExtLaunchKernelGGL)
     static constexpr int kTimerSlots = 64;
     hipEvent_t tev[2 * kTimerSlots] = {};

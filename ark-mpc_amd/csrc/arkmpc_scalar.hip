@@ -439,6 +439,7 @@ int arkmpc_ctx_destroy(arkmpc_ctx* ctx) {
         if (ctx->arena) (void)hipFree(ctx->arena);
         if (ctx->d_flag) (void)hipFree(ctx->d_flag);
         if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+        if (ctx->h_small) (void)hipHostFree(ctx->h_small);
         for (int i = 0; i < 2; ++i) {
             if (ctx->h_pin[i]) (void)hipHostFree(ctx->h_pin[i]);
             if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);

@@ -232,6 +232,8 @@ class Engine:
     def point_mac_check_shares(self, n, key, opened, shares, out): self.call("point_mac_check_shares", ("size", n), ("key", key), opened, shares, out)
     def g1_sum(self, n, pts, out): self.call("g1_sum", ("size", n), pts, out)
     def pointshare_sum(self, n, shares, out): self.call("pointshare_sum", ("size", n), shares, out)
+    def g1_msm(self, n, pts, scalars, out): self.call("g1_msm", ("size", n), pts, scalars, out)
+    def g1_msm_authenticated(self, n, pts, scalar_shares, out): self.call("g1_msm_authenticated", ("size", n), pts, scalar_shares, out)
     def commit_points_sha3(self, n, pts, blinders, out): self.call("commit_points_sha3", ("size", n), pts, blinders, out)
     def point_mac_verify(self, n, mine, peer, out_ok): self.call("point_mac_verify", ("size", n), mine, peer, out_ok)
 

@@ -187,6 +187,17 @@ int arkmpc_scalarshare_mul_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scal
  * (curve/share.rs:85-92).  n = 0 gives the identity.  out: ONE point (12 x u64) / ONE PointShare (24 x u64). */
 int arkmpc_g1_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_point);
 int arkmpc_pointshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share);
+/* Variable-base multi-scalar multiplication, sum_i scalars[i] * points[i]  (CurvePoint::msm, curve.rs:549-560, which
+ * batch-normalises to affine and calls ark-ec's VariableBaseMSM; also the gate body of msm_results, :588-603 / :661-684).
+ * points: n Jacobian points (12 x u64), any representative, identities allowed; scalars: n x 4 u64 Montgomery.
+ * out: ONE point.  n = 0 gives the identity.  Bucket (Pippenger) method on the device; the summation order is fixed, so
+ * the output representative is deterministic. */
+int arkmpc_g1_msm(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out_point);
+/* CurvePointResult::msm_authenticated (curve.rs:618-642 / :701-731): authenticated scalars x public points ->
+ * PointShare(msm(shares, points), msm(macs, points)).  scalar_shares: n ScalarShares (8 x u64); out: ONE PointShare
+ * (24 x u64).  Both columns go through one sort / one set of launches over the shared affine points. */
+int arkmpc_g1_msm_authenticated(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalar_shares,
+                                uint64_t* out_share);
 /* the `.share()` projection of AuthenticatedPointResult::open_batch (:74-89): n PointShares -> n points */
 int arkmpc_pointshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points);
 /* value * mac_key - share.mac() per element (authenticated_curve.rs:215-220) */

@@ -508,6 +508,19 @@ void ora_g1_sum(size_t n, const u64* pts, size_t stride, u64 out[12]) {
     for (size_t i = 0; i < n; ++i) ora_g1_add(acc, pts + stride * i, acc);
     memcpy(out, acc, 96);
 }
+/* CurvePoint::msm (curve.rs:549-560): sum_i scalars[i] * points[i].  The reference hands affine points and big-integer
+ * scalars to ark-ec's VariableBaseMSM (a Pippenger bucket method); the group element is defined by the plain sum, which is
+ * what this restates (scalar stride in u64 lets it read one column of a ScalarShare array). */
+void ora_g1_msm(size_t n, const u64* pts, const u64* scalars, size_t scalar_stride, u64 out[12]) {
+    u64 acc[12], t[12]; ora_g1_identity(acc);
+    for (size_t i = 0; i < n; ++i) { ora_g1_scalar_mul(pts + 12 * i, scalars + scalar_stride * i, t); ora_g1_add(acc, t, acc); }
+    memcpy(out, acc, 96);
+}
+/* CurvePoint::msm_authenticated (curve.rs:618-642): PointShare(msm(shares, points), msm(macs, points)) */
+void ora_g1_msm_authenticated(size_t n, const u64* pts, const u64* scalar_shares, u64 out[24]) {
+    ora_g1_msm(n, pts, scalar_shares, 8, out);
+    ora_g1_msm(n, pts, scalar_shares + 4, 8, out + 12);
+}
 /* curve/share.rs:68-105 */
 void ora_pointshare_batch_add(size_t n, const u64* a, const u64* b, u64* out) {
     for (size_t i = 0; i < n; ++i) {

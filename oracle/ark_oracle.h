@@ -122,6 +122,8 @@ void ora_g1_to_bytes(const u64 a[12], unsigned char out[32]);
 void ora_g1_batch_add(size_t n, const u64* a, const u64* b, u64* out);
 void ora_g1_batch_scalar_mul(size_t n, const u64* pts, const u64* scalars, u64* out);
 void ora_g1_sum(size_t n, const u64* pts, size_t stride_u64, u64 out[12]);   /* authenticated_curve.rs:796-805 */
+void ora_g1_msm(size_t n, const u64* pts, const u64* scalars, size_t scalar_stride_u64, u64 out[12]);   /* curve.rs:549-560 */
+void ora_g1_msm_authenticated(size_t n, const u64* pts, const u64* scalar_shares, u64 out[24]);         /* curve.rs:618-642 */
 /* PointShare ops (curve/share.rs:55-114) */
 void ora_pointshare_batch_add(size_t n, const u64* a, const u64* b, u64* out);
 void ora_pointshare_batch_sub(size_t n, const u64* a, const u64* b, u64* out);

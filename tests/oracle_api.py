@@ -145,6 +145,11 @@ class Oracle:
     def g1_sum(self, pts, stride=12, off=0):
         n = len(pts) // stride; out = np.zeros(12, dtype=np.uint64)
         self.lib.ora_g1_sum(ctypes.c_size_t(n), ctypes.c_void_p(pts.ctypes.data + 8 * off), ctypes.c_size_t(stride), self._p(out)); return out
+    def g1_msm(self, pts, scalars, stride=4, off=0):
+        n = len(pts) // 12; out = np.zeros(12, dtype=np.uint64)
+        self.lib.ora_g1_msm(ctypes.c_size_t(n), self._p(pts), ctypes.c_void_p(scalars.ctypes.data + 8 * off), ctypes.c_size_t(stride), self._p(out)); return out
+    def g1_msm_authenticated(self, pts, scalar_shares):
+        n = len(pts) // 12; out = np.zeros(24, dtype=np.uint64); self._call("ora_g1_msm_authenticated", n, pts, scalar_shares, out); return out
     def g1_neg(self, pts):
         n = len(pts) // 12; out = np.zeros(12 * n, dtype=np.uint64)
         for i in range(n):

@@ -58,3 +58,25 @@ def test_add_and_scalar_mul_vs_python(oracle):
     # compressed encoding
     assert oracle.g1_to_bytes(P).tobytes() == b"".join(pyref.g1_compress(p) for p in pts)
     assert oracle.g1_to_bytes(oracle.g1_identity()).tobytes() == pyref.g1_compress(None)
+
+
+def test_msm_vs_python(oracle):
+    """CurvePoint::msm / msm_authenticated (curve.rs:549-560, 618-642) against the Python affine group law."""
+    n = 12
+    ks = [0, 1, pyref.RORD - 1] + rand_values(0, n - 3, 77)
+    macs = rand_values(0, n, 78)
+    base_k = rand_values(0, n, 79)
+    pts = [pyref.g1_mul(pyref.G, k) for k in base_k]
+    pts[4] = None                                                         # identity among the bases
+    pts[6] = pts[5]                                                       # repeated base
+    P = jac([p if p else (1, 1) for p in pts], [0 if p is None else 1 + 31 * i for i, p in enumerate(pts)])
+    def ref(scalars):
+        acc = None
+        for k, p in zip(scalars, pts):
+            acc = pyref.g1_add(acc, pyref.g1_mul(p, k) if p else None)
+        return acc
+    assert affine_of(oracle, oracle.g1_msm(P, mont_array(0, ks))) == [ref(ks)]
+    shares = mont_array(0, [v for pair in zip(ks, macs) for v in pair])
+    got = oracle.g1_msm_authenticated(P, shares)
+    assert affine_of(oracle, got) == [ref(ks), ref(macs)]
+    assert affine_of(oracle, oracle.g1_msm(P[:0], mont_array(0, []))) == [None]     # empty -> identity
