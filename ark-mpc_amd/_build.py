@@ -21,7 +21,8 @@ ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "arkmpc_edwards.hip", "sha3_host.hip"]
-ENGINE_DEPS = ["fp.cuh", "field_consts.inc", "asm_kernels.inc", "fp_asm.cuh", "glv_consts.inc", "ed25519_consts.inc", "arkmpc_internal.hpp", os.path.join("..", "..", "include", "arkmpc.h")]
+# every header / include fragment in csrc (a stale .so after editing an .inc is the failure this guards against)
+ENGINE_DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".inc", ".hpp"))) + [os.path.join("..", "..", "include", "arkmpc.h")]
 
 
 def _newer(target, deps):
