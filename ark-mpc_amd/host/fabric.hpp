@@ -556,6 +556,22 @@ class AuthenticatedPointBatch {
         check(c(points), arkmpc_pointshare_sum(c(points), prod.n, prod.buf.ptr(), r.buf.ptr()), "pointshare_sum");
         return r;
     }
+    // CurvePoint::msm / CurvePointResult::msm_results (curve.rs:549-560, :588-603): public scalars x public points -> one point
+    static PointBatch point_msm(const std::shared_ptr<MpcFabric>& f, const ScalarBatch& scalars, const PointBatch& points) {
+        if (scalars.n != points.n) throw std::invalid_argument("msm cannot compute on vectors of unequal length");
+        auto r = alloc_points(f, 1);
+        check(f->ctx(), arkmpc_g1_msm(f->ctx(), points.n, points.buf.ptr(), scalars.buf.ptr(), r.buf.ptr()), "g1_msm");
+        return r;
+    }
+    // CurvePointResult::msm_authenticated (curve.rs:618-642 / :701-731): authenticated scalars x public points; a local
+    // gate -- PointShare(msm(shares, P), msm(macs, P)) -- both columns in one bucket-method pass on the GPU
+    static AuthenticatedPointBatch msm_authenticated(const AuthenticatedScalarBatch& scalars, const PointBatch& points) {
+        if (scalars.n != points.n) throw std::invalid_argument("msm cannot compute on vectors of unequal length");
+        auto r = alloc(scalars.fabric, 1);
+        check(scalars.fabric->ctx(),
+              arkmpc_g1_msm_authenticated(scalars.fabric->ctx(), points.n, points.buf.ptr(), scalars.buf.ptr(), r.buf.ptr()), "g1_msm_authenticated");
+        return r;
+    }
 
   private:
     static arkmpc_ctx* c(const AuthenticatedPointBatch& a) { return a.fabric->ctx(); }

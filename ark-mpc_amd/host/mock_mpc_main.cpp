@@ -100,13 +100,22 @@ int main(int argc, char** argv) {
                     bytes.download(out.opened.data(), n * 32);
                 }
                 return out;
-            } else if (scenario == "point_mul" || scenario == "msm") {
+            } else if (scenario == "point_mul" || scenario == "msm" || scenario == "msm_public_points") {
                 // AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714, test :1222-1244): share x, share y,
                 // Y = [y]G, Z = batch_mul(x, Y), open_authenticated; out = compressed points of Z  (expected (x*y) G)
                 auto x = fabric->batch_share_scalar(a_m, n, PARTY0);
                 auto y = fabric->batch_share_scalar(b_m, n, PARTY1);
                 auto Y = AuthenticatedPointBatch::batch_mul_generator(y);
-                auto Z = (scenario == "msm") ? AuthenticatedPointBatch::msm(x, Y) : AuthenticatedPointBatch::batch_mul(x, Y);
+                AuthenticatedPointBatch Z;
+                if (scenario == "msm_public_points") {
+                    // msm_authenticated (curve.rs:618-642): x authenticated, bases P_i = [b_i]G public (both parties hold b)
+                    ScalarBatch pub_b = fabric->allocate_scalars(b_m);
+                    PointBatch P = AuthenticatedPointBatch::alloc_points(fabric, n);
+                    if (n) check(fabric->ctx(), arkmpc_g1_generator_mul(fabric->ctx(), n, pub_b.buf.ptr(), P.buf.ptr()), "g1_generator_mul");
+                    Z = AuthenticatedPointBatch::msm_authenticated(x, P);
+                } else {
+                    Z = (scenario == "msm") ? AuthenticatedPointBatch::msm(x, Y) : AuthenticatedPointBatch::batch_mul(x, Y);
+                }
                 const size_t zn = Z.n;    // msm collapses the batch to one point
                 if (fabric->party_id() == PARTY0 && zn && bad_mac) {          // corrupt one MAC point: make it the share point
                     std::vector<uint64_t> h(24 * zn); Z.buf.download(h.data(), zn * 192);

@@ -169,3 +169,48 @@ def test_asm_path_chunk_boundary_above_2p25(pkg):
     r = ref.view(n, 8)
     assert torch.equal(o_s.view(n, 4), r[:, :4]) and torch.equal(o_m.view(n, 4), r[:, 4:])
     e.close()
+
+
+def _affine(e, pt):
+    xy = torch.empty(8, dtype=torch.int64, device="cuda"); inf = torch.empty(16, dtype=torch.uint8, device="cuda")
+    e.g1_to_affine(1, pt, xy, inf); torch.cuda.synchronize()
+    return None if int(inf[0]) else tuple(int(v) for v in xy.cpu().numpy().view(np.uint64))
+
+
+def test_msm_above_chunk_size(pkg):
+    """Bucket-method MSM at n = 2^22 + 1000 (two passes of the 2^22-point chunking) with bases k_i * G:
+    (a) closed form: the result is (sum s_i * k_i mod r) * G with the sum taken in Python integers;
+    (b) a skewed scalar vector (three distinct values and zeros: every window has a handful of very long bucket runs)
+        against the per-element path arkmpc_g1_scalar_mul + arkmpc_g1_sum;
+    (c) the authenticated form returns the same share-column point and the MAC-column point of a second MSM."""
+    n = (1 << 22) + 1000
+    r = pyref.RORD
+    e = _eng(pkg, 0)
+    g = torch.Generator(device="cuda"); g.manual_seed(0xA11CE006)
+    k = _rnd(e, n, g); s = _rnd(e, n, g); m = _rnd(e, n, g)
+    P = torch.empty(12 * n, dtype=torch.int64, device="cuda"); e.g1_generator_mul(n, k, P)
+    out = torch.empty(12, dtype=torch.int64, device="cuda"); e.g1_msm(n, P, s, out)
+    def ints(t):
+        c = torch.empty_like(t); e.scalar_to_canonical(n, t, c); torch.cuda.synchronize()
+        b = c.cpu().numpy().view(np.uint64).reshape(n, 4)
+        return [int(w[0]) | int(w[1]) << 64 | int(w[2]) << 128 | int(w[3]) << 192 for w in b.tolist()]
+    ki, si = ints(k), ints(s)
+    want = pyref.g1_mul(pyref.G, sum(a * b for a, b in zip(si, ki)) % r)
+    got = _affine(e, out)
+    x, y = got[:4], got[4:]
+    as_int = lambda w: pyref.from_mont(3, w[0] | w[1] << 64 | w[2] << 128 | w[3] << 192)
+    assert (as_int(x), as_int(y)) == want
+    # (c) authenticated form
+    aos = torch.cat([s.view(n, 4), m.view(n, 4)], dim=1).contiguous().view(-1)
+    out2 = torch.empty(24, dtype=torch.int64, device="cuda"); e.g1_msm_authenticated(n, P, aos, out2)
+    outm = torch.empty(12, dtype=torch.int64, device="cuda"); e.g1_msm(n, P, m, outm)
+    assert torch.equal(out2[:12], out) and torch.equal(out2[12:], outm)
+    # (b) skewed scalars vs the per-element path
+    vals = _rnd(e, 3, g).view(3, 4)
+    pick = torch.randint(0, 4, (n,), device="cuda", generator=g)
+    table = torch.cat([vals, torch.zeros(1, 4, dtype=torch.int64, device="cuda")])
+    sk = table[pick].contiguous().view(-1)
+    e.g1_msm(n, P, sk, out)
+    tmp = torch.empty(12 * n, dtype=torch.int64, device="cuda"); e.g1_scalar_mul(n, P, sk, tmp)
+    ref = torch.empty(12, dtype=torch.int64, device="cuda"); e.g1_sum(n, tmp, ref)
+    assert _affine(e, out) == _affine(e, ref)

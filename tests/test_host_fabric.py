@@ -141,6 +141,26 @@ def test_authenticated_msm(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 300])
+def test_msm_authenticated_public_points(tmp_path, n):
+    """CurvePointResult::msm_authenticated (curve.rs:618-642): authenticated scalars x public bases [b_i]G through the
+    bucket-method MSM; the authenticated open must give (sum x_i*b_i) G with the MAC check passing on both parties."""
+    fid = 0
+    r = pyref.RORD
+    x, b = rand_values(fid, n, 63), rand_values(fid, n, 64)
+    want = pyref.g1_compress(pyref.g1_mul(pyref.G, sum(u * v for u, v in zip(x, b)) % r))
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(ints_to_limbs(x).tobytes() + ints_to_limbs(b).tobytes())
+    rr = subprocess.run([EXE, "msm_public_points", str(fid), str(n), str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stderr
+    raw = outp.read_bytes()
+    assert len(raw) == 2 * (8 + 32)
+    for party in range(2):
+        assert struct.unpack_from("<Q", raw, 40 * party)[0] == 0
+        assert raw[40 * party + 8: 40 * party + 40] == want
+
+
+@pytest.mark.gpu
 def test_batch_div_protocol(tmp_path):
     fid, n = 0, 33
     p = pyref.P[fid]

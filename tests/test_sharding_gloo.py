@@ -97,3 +97,42 @@ def test_sharded_equals_unsharded(oracle, n, corrupt):
     chk0 = oracle.mac_check_shares(fid, keys[0], np.array(full_val, dtype=np.uint64), res0)
     want = oracle.commit_scalars(fid, chk0, mont_array(fid, [12345]))
     assert comm == want.tolist()
+
+
+def _msm_worker(rank, world, port, n, q):
+    """MSM shards by index range: every rank folds its slice to ONE point, the world_size points are gathered in rank
+    order (96 B each) and summed -- the only cross-GPU traffic of the authenticated MSM."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_api
+    from helpers import mont_array, rand_values
+    sharding = importlib.import_module("ark-mpc_amd.sharding")
+    ora = oracle_api.load()
+    G = ora.g1_generator()
+    P = ora.g1_batch_scalar_mul(np.tile(G, n), mont_array(0, rand_values(0, n, 21)))
+    S = mont_array(0, rand_values(0, n, 22))
+    lo, hi = sharding.shard_range(n, world, rank)
+    part = ora.g1_msm(np.ascontiguousarray(P[12 * lo:12 * hi]), np.ascontiguousarray(S[4 * lo:4 * hi]))
+    allp = sharding.gather_ordered(torch.from_numpy(part.view(np.int64).copy()), world, 12).numpy().view(np.uint64)
+    if rank == 0:
+        total = ora.g1_sum(np.ascontiguousarray(allp))
+        want = ora.g1_msm(P, S)
+        xy_a, inf_a = ora.g1_batch_to_affine(total)
+        xy_b, inf_b = ora.g1_batch_to_affine(want)
+        q.put((bool(np.array_equal(xy_a, xy_b) and np.array_equal(inf_a, inf_b)), int(hi - lo)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_msm_equals_unsharded(oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n = 37
+    procs = [ctx.Process(target=_msm_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for pr in procs: pr.start()
+    same, m0 = q.get(timeout=120)
+    for pr in procs: pr.join(timeout=60)
+    assert all(pr.exitcode == 0 for pr in procs)
+    assert same and m0 in (18, 19)
