@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
-ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "arkmpc_edwards.hip", "sha3_host.hip"]
+ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "arkmpc_edwards.hip", "arkmpc_wire.hip", "sha3_host.hip"]
 # every header / include fragment in csrc (a stale .so after editing an .inc is the failure this guards against)
 ENGINE_DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".inc", ".hpp"))) + [os.path.join("..", "..", "include", "arkmpc.h")]
 

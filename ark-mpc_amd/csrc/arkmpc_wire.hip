@@ -1,0 +1,418 @@
+// arkmpc_wire.hip -- the wire format on either side of the hot path (first half):
+// what QuicTwoPartyNet puts on the stream for the batches the engine produces and consumes.
+//
+// Reference: a message is NetworkOutbound{result_id: usize, payload: NetworkPayload} (online-phase/src/network.rs:33-60)
+// written as  u64 little-endian length || serde_json::to_vec(&msg)  (network/quic.rs:303-306, read back at :226-251).
+// serde_json's compact writer emits no whitespace, struct fields in declaration order and externally tagged enum
+// variants, so a ScalarBatch message is exactly
+//     {"result_id":<decimal>,"payload":{"ScalarBatch":[[b0,b1,...,b31],[...],...]}}
+// where each element is the scalar's `serialize_uncompressed` bytes -- 32 bytes, canonical, little-endian
+// (algebra/scalar/scalar.rs:186-192) -- written as a JSON array of decimal numbers (serde_json serialize_bytes).
+// CurvePoint serialises the same way from `to_bytes()` = serialize_compressed (curve.rs:50-55, :103-108), variant
+// "PointBatch".  The survey names this serde_json pass as where an opening's time goes on the QUIC path (section 8a row a5):
+// ~115 text bytes per 32-byte value.
+//
+// Encoding (HBM-bound byte work): lengths per record -> exclusive scan -> each workgroup renders its 256 records into
+// LDS and copies the contiguous text out with coalesced stores.  Decoding: count '[' per 4 KiB block -> scan -> scatter
+// element start positions -> one thread per element parses and validates its <= 131 characters.  Scalars are then
+// checked against the modulus (deserialize_uncompressed validates, scalar.rs:195-201) and converted to Montgomery form.
+#include "arkmpc_internal.hpp"
+#include <hipcub/hipcub.hpp>
+#include <cstdio>
+#include <cstring>
+
+#define WIRE_TPB 256
+#define WIRE_MAX_REC 131u   // ",[" + 32 x "255" + 31 x "," + "]"
+
+namespace {
+
+__device__ __forceinline__ u32 ndigits(u32 b) { return 1u + (b >= 10u) + (b >= 100u); }
+
+// text length of record i (with its leading separator when i > 0)
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_lengths(size_t n, const unsigned char* recs, u64* lens) {
+    const size_t i = (size_t)blockIdx.x * WIRE_TPB + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { lens[i] = 0; return; }
+    const uint4* q = reinterpret_cast<const uint4*>(recs + 32 * i);
+    const uint4 a = q[0], b = q[1];
+    const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u32 len = 2u + 31u + (i ? 1u : 0u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int s = 0; s < 32; s += 8) len += ndigits((w[k] >> s) & 255u);
+    lens[i] = len;
+}
+
+struct WireHeader {
+    unsigned char text[80];
+    u32 len;
+};
+
+// One workgroup renders records [blk*256, blk*256+256) into LDS, then streams the contiguous text to `out`.
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_render(size_t n, const unsigned char* recs, const u64* off, WireHeader hdr, unsigned char* out) {
+    __shared__ unsigned char sm[WIRE_TPB * WIRE_MAX_REC + 16];
+    const size_t first = (size_t)blockIdx.x * WIRE_TPB;
+    const size_t i = first + threadIdx.x;
+    const size_t last = (first + WIRE_TPB < n) ? first + WIRE_TPB : n;
+    const u64 base = off[first], end = off[last];
+    if (i < n) {
+        unsigned char* p = sm + (off[i] - base);
+        const uint4* q = reinterpret_cast<const uint4*>(recs + 32 * i);
+        const uint4 a = q[0], b = q[1];
+        const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (i) *p++ = ',';
+        *p++ = '[';
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int s = 0; s < 32; s += 8) {
+                const u32 v = (w[k] >> s) & 255u;
+                if (k | s) *p++ = ',';
+                if (v >= 100u) *p++ = (unsigned char)('0' + v / 100u);
+                if (v >= 10u) *p++ = (unsigned char)('0' + (v / 10u) % 10u);
+                *p++ = (unsigned char)('0' + v % 10u);
+            }
+        }
+        *p++ = ']';
+    }
+    __syncthreads();
+    unsigned char* dst = out + 8 + hdr.len + base;
+    const u32 total = (u32)(end - base);
+    // head bytes up to 16-byte alignment of dst, then 16-byte vector stores, then the tail
+    const u32 mis = (u32)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    const u32 head = mis < total ? mis : total;
+    if (threadIdx.x < head) dst[threadIdx.x] = sm[threadIdx.x];
+    const u32 nvec = (total - head) / 16u;
+    for (u32 v = threadIdx.x; v < nvec; v += WIRE_TPB) {
+        const unsigned char* s = sm + head + 16u * v;     // LDS side is byte-addressed: assemble the vector
+        u32 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = (u32)s[4 * k] | ((u32)s[4 * k + 1] << 8) | ((u32)s[4 * k + 2] << 16) | ((u32)s[4 * k + 3] << 24);
+        *reinterpret_cast<uint4*>(dst + head + 16u * v) = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    const u32 done = head + 16u * nvec;
+    if (threadIdx.x < total - done) dst[done + threadIdx.x] = sm[done + threadIdx.x];
+    if (blockIdx.x == 0) {
+        // frame prefix, JSON header and trailer
+        const u64 body = off[n];
+        const u64 json_len = hdr.len + body + 3;
+        if (threadIdx.x < 8) out[threadIdx.x] = (unsigned char)(json_len >> (8 * threadIdx.x));
+        if (threadIdx.x < hdr.len) out[8 + threadIdx.x] = hdr.text[threadIdx.x];
+        if (threadIdx.x < 3) out[8 + hdr.len + body + threadIdx.x] = (unsigned char)("]}}"[threadIdx.x]);
+    }
+}
+
+// ---- decode ------------------------------------------------------------------------------------------------------
+// The body is frame[lo, hi).  `frame` is 16-byte aligned, so every thread examines one aligned 16-byte vector and masks
+// the bytes outside the body; positions are frame-relative.
+__device__ __forceinline__ u32 bracket_mask(const unsigned char* frame, size_t v, size_t lo, size_t hi) {
+    if (16 * v + 16 <= lo || 16 * v >= hi) return 0;
+    const uint4 q = *reinterpret_cast<const uint4*>(frame + 16 * v);
+    const u32 w[4] = {q.x, q.y, q.z, q.w};
+    u32 mask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const size_t at = 16 * v + k;
+        if (((w[k >> 2] >> (8 * (k & 3))) & 255u) == (u32)'[' && at >= lo && at < hi) mask |= 1u << k;
+    }
+    return mask;
+}
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_count(const unsigned char* frame, size_t v0, size_t lo, size_t hi, u32* blk_cnt, u32 nblocks) {
+    __shared__ u32 wsum[WIRE_TPB / 64];
+    u32 c = __popc(bracket_mask(frame, v0 + (size_t)blockIdx.x * WIRE_TPB + threadIdx.x, lo, hi));
+    for (int s = 32; s > 0; s >>= 1) c += __shfl_down(c, s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (blockIdx.x == 0) blk_cnt[nblocks] = 0;
+    }
+}
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_positions(const unsigned char* frame, size_t v0, size_t lo, size_t hi, const u32* blk_off, u64* pos,
+                                                             size_t max_n) {
+    __shared__ u32 cnt[WIRE_TPB];
+    const size_t v = v0 + (size_t)blockIdx.x * WIRE_TPB + threadIdx.x;
+    const u32 mask = bracket_mask(frame, v, lo, hi);
+    const u32 c = __popc(mask);
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (u32 s = 1; s < WIRE_TPB; s <<= 1) {       // inclusive Hillis-Steele scan over 256 counts
+        const u32 t = threadIdx.x >= s ? cnt[threadIdx.x - s] : 0;
+        __syncthreads();
+        cnt[threadIdx.x] += t;
+        __syncthreads();
+    }
+    size_t idx = (size_t)blk_off[blockIdx.x] + cnt[threadIdx.x] - c;
+    for (u32 k = 0; k < 16; ++k)
+        if (mask & (1u << k)) { if (idx < max_n) pos[idx] = 16 * v + k; ++idx; }
+}
+// error bits
+#define WIRE_E_SYNTAX 1
+#define WIRE_E_RANGE 2
+// One workgroup stages the text of its 256 elements in LDS (coalesced 16-byte loads), then one thread per element
+// parses  '[' number (',' number){31} ']'  followed by ',' + the next element, or by the end of the body.
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_parse(size_t n, size_t lo, size_t hi, const unsigned char* frame, const u64* pos, unsigned char* recs,
+                                                         int* err) {
+    __shared__ uint4 smv[(WIRE_TPB * WIRE_MAX_REC + 48) / 16 + 1];
+    unsigned char* sm = reinterpret_cast<unsigned char*>(smv);
+    const size_t first = (size_t)blockIdx.x * WIRE_TPB;
+    const size_t i = first + threadIdx.x;
+    const size_t last = (first + WIRE_TPB < n) ? first + WIRE_TPB : n;
+    const size_t span_lo = pos[first], span_hi = (last < n) ? pos[last] : hi;
+    const size_t al = span_lo & ~(size_t)15;
+    // an element longer than the grammar allows makes the span exceed the staging buffer: syntax error, no parse
+    const bool fits = span_hi - al <= (size_t)WIRE_TPB * WIRE_MAX_REC + 16;
+    if (!fits) { if (threadIdx.x == 0) atomicOr(err, WIRE_E_SYNTAX); return; }
+    const u32 nvec = (u32)((span_hi - al + 15) / 16);
+    for (u32 v = threadIdx.x; v < nvec; v += WIRE_TPB) smv[v] = *reinterpret_cast<const uint4*>(frame + al + 16 * (size_t)v);   // reads < 16 B past hi: the trailer
+    __syncthreads();
+    if (i >= n) return;
+    const size_t end = span_hi - al;                  // LDS-relative end of this workgroup's text
+    size_t p = pos[i] - al;
+    int bad = 0;
+    if (i == 0 && pos[0] != lo) bad |= WIRE_E_SYNTAX;
+    ++p;                                              // past '['
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int s = 0; s < 32; s += 8) {
+            u32 v = 0, nd = 0;
+            unsigned char lead = 0;
+            while (p < end && nd < 4) {
+                const unsigned char ch = sm[p];
+                if (ch < '0' || ch > '9') break;
+                if (nd == 0) lead = ch;
+                v = v * 10u + (u32)(ch - '0');
+                ++nd; ++p;
+            }
+            if (nd == 0 || nd > 3 || (nd > 1 && lead == '0')) bad |= WIRE_E_SYNTAX;
+            else if (v > 255u) bad |= WIRE_E_RANGE;
+            w[k] |= (v & 255u) << s;
+            const unsigned char sep = (k == 7 && s == 24) ? ']' : ',';
+            if (p >= end || sm[p] != sep) bad |= WIRE_E_SYNTAX;
+            ++p;
+        }
+    }
+    if (i + 1 < n) {
+        // ',' then the next element's '[' immediately (its position is known from pos[])
+        if (pos[i + 1] - al != p + 1 || (p < end ? sm[p] != ',' : frame[al + p] != ',')) bad |= WIRE_E_SYNTAX;
+    } else if (al + p != hi) {
+        bad |= WIRE_E_SYNTAX;
+    }
+    uint4* q = reinterpret_cast<uint4*>(recs + 32 * i);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    if (bad) atomicOr(err, bad);
+}
+// canonical little-endian -> Montgomery, rejecting values >= p (deserialize_uncompressed validates)
+template <int F>
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_scalars(size_t n, const unsigned char* recs, u64* out, int* err) {
+    const size_t i = (size_t)blockIdx.x * WIRE_TPB + threadIdx.x;
+    if (i >= n) return;
+    using P = FieldParams<F>;
+    const Fe v = fe_load(reinterpret_cast<const u64*>(recs + 32 * i));
+    u32 br = 0, bo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { (void)__builtin_subc(v.v[k], P::P(k), br, &bo); br = bo; }
+    if (!br) { atomicOr(err, WIRE_E_RANGE); return; }          // v - p did not borrow: v >= p
+    fe_store(out + 4 * i, fe_from_canonical<F>(v));
+}
+template <int F>
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_to_canonical(size_t n, const u64* in, unsigned char* recs) {
+    const size_t i = (size_t)blockIdx.x * WIRE_TPB + threadIdx.x;
+    if (i >= n) return;
+    fe_store(reinterpret_cast<u64*>(recs + 32 * i), fe_to_canonical<F>(fe_load(in + 4 * i)));
+}
+
+const char* kind_name(int kind) { return kind == ARKMPC_WIRE_SCALAR_BATCH ? "ScalarBatch" : (kind == ARKMPC_WIRE_POINT_BATCH ? "PointBatch" : nullptr); }
+
+WireHeader make_header(int kind, uint64_t result_id) {
+    WireHeader h;
+    int len = snprintf((char*)h.text, sizeof(h.text), "{\"result_id\":%llu,\"payload\":{\"%s\":[", (unsigned long long)result_id, kind_name(kind));
+    h.len = (u32)len;
+    return h;
+}
+
+#define DISPATCH_F(ctx, EXPR_F)                                                                 \
+    switch ((ctx)->field_id) {                                                                  \
+        case 0: { constexpr int F = 0; EXPR_F; } break;                                         \
+        case 1: { constexpr int F = 1; EXPR_F; } break;                                         \
+        case 2: { constexpr int F = 2; EXPR_F; } break;                                         \
+        case 3: { constexpr int F = 3; EXPR_F; } break;                                         \
+        case 4: { constexpr int F = 4; EXPR_F; } break;                                         \
+        default: return ark_bad(ctx, "bad field id");                                           \
+    }
+
+// shared encoder: records are either given (recs32 != nullptr, caller layout mode) or produced from Montgomery scalars
+int encode_impl(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const unsigned char* recs32, const uint64_t* scalars, uint8_t* out_frame,
+                size_t out_cap, size_t* out_len) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    CtxGuard guard(ctx);
+    if (guard.rc) return guard.rc;
+    if (!kind_name(kind)) return ark_bad(ctx, "unknown payload kind");
+    if (!out_len) return ark_bad(ctx, "null out_len");
+    const WireHeader hdr = make_header(kind, result_id);
+    const size_t bound = 8 + hdr.len + n * (size_t)WIRE_MAX_REC + 3;
+    if (out_cap < bound) return ark_bad(ctx, "frame buffer smaller than arkmpc_wire_frame_bound(n)");
+    Stage st(ctx);
+    int ir = recs32 ? st.declare_in(recs32, n * 32) : -1, is = scalars ? st.declare_in(scalars, n * 32) : -1;
+    int io = st.declare_out(out_frame, bound);
+    size_t scan_bytes = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const u64*)nullptr, (u64*)nullptr, n + 1, ctx->stream);
+    if (e != hipSuccess) { ctx->err = std::string("scan sizing: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    int il = st.declare_scratch((n + 1) * 8), iof = st.declare_scratch((n + 1) * 8), it = st.declare_scratch(scan_bytes + 64),
+        ic = st.declare_scratch(n * 32 + 32);
+    if (st.commit()) return st.rc;
+    hipStream_t s = ctx->stream;
+    const unsigned char* recs = recs32 ? st.in<unsigned char>(ir) : st.scratch<unsigned char>(ic);
+    if (!recs32 && n) DISPATCH_F(ctx, hipLaunchKernelGGL((k_wire_to_canonical<F>), dim3(blocks_for(n, WIRE_TPB)), dim3(WIRE_TPB), 0, s, n, st.in<u64>(is),
+                                                         st.scratch<unsigned char>(ic)));
+    hipLaunchKernelGGL(k_wire_lengths, dim3(blocks_for(n + 1, WIRE_TPB)), dim3(WIRE_TPB), 0, s, n, recs, st.scratch<u64>(il));
+    e = hipcub::DeviceScan::ExclusiveSum(st.scratch<void>(it), scan_bytes, st.scratch<u64>(il), st.scratch<u64>(iof), n + 1, s);
+    if (e != hipSuccess) { ctx->err = std::string("scan: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    hipLaunchKernelGGL(k_wire_render, dim3(n ? blocks_for(n, WIRE_TPB) : 1), dim3(WIRE_TPB), 0, s, n, recs, st.scratch<u64>(iof), hdr, st.out<unsigned char>(io));
+    // the frame length is data dependent: read the scan total back
+    u64* h_total = (u64*)ctx->h_flag;
+    ARK_HIP(ctx, hipMemcpyAsync(h_total, st.scratch<u64>(iof) + n, 8, hipMemcpyDeviceToHost, s));
+    ARK_HIP(ctx, hipStreamSynchronize(s));
+    const size_t frame_len = 8 + hdr.len + (size_t)*h_total + 3;
+    *out_len = frame_len;
+    // host-buffer mode: only the bytes of the frame travel back
+    if (ctx->host_buffers) st.oplan[io].bytes = frame_len;
+    return st.finish();
+}
+
+}  // namespace
+
+extern "C" {
+
+int arkmpc_wire_frame_bound(size_t n, size_t* out_bytes) {
+    if (!out_bytes) return ARKMPC_ERR_BAD_ARG;
+    *out_bytes = 8 + 80 + n * (size_t)WIRE_MAX_REC + 3;
+    return ARKMPC_OK;
+}
+
+int arkmpc_wire_encode_scalar_batch(arkmpc_ctx* ctx, uint64_t result_id, size_t n, const uint64_t* scalars, uint8_t* out_frame, size_t out_cap,
+                                    size_t* out_len) {
+    if (ctx && n && !scalars) return ark_bad(ctx, "null scalars");
+    return encode_impl(ctx, ARKMPC_WIRE_SCALAR_BATCH, result_id, n, nullptr, n ? scalars : nullptr, out_frame, out_cap, out_len);
+}
+
+int arkmpc_wire_encode_bytes32(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const uint8_t* records, uint8_t* out_frame, size_t out_cap,
+                               size_t* out_len) {
+    if (ctx && n && !records) return ark_bad(ctx, "null records");
+    return encode_impl(ctx, kind, result_id, n, n ? records : nullptr, nullptr, out_frame, out_cap, out_len);
+}
+
+// Parses the frame header on the host (it is < 100 bytes), the body on the device.
+static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
+                       size_t* out_n, uint64_t* out_result_id, int* out_kind) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    CtxGuard guard(ctx);
+    if (guard.rc) return guard.rc;
+    if (!frame || !out_n) return ark_bad(ctx, "null frame / out_n");
+    if (frame_len < 8 + 30) return ark_bad(ctx, "frame too short");
+    // header bytes to the host
+    unsigned char head[112];
+    const size_t hl = frame_len < sizeof(head) ? frame_len : sizeof(head);
+    unsigned char tail[3];
+    if (ctx->host_buffers) {
+        memcpy(head, frame, hl);
+        memcpy(tail, frame + frame_len - 3, 3);
+    } else {
+        ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag, frame, hl < 48 ? hl : 48, hipMemcpyDeviceToHost, ctx->stream));   // h_flag is 64 bytes
+        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(head, ctx->h_flag, hl < 48 ? hl : 48);
+        if (hl > 48) {
+            ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag, frame + 48, hl - 48, hipMemcpyDeviceToHost, ctx->stream));
+            ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            memcpy(head + 48, ctx->h_flag, hl - 48);
+        }
+        ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag, frame + frame_len - 3, 3, hipMemcpyDeviceToHost, ctx->stream));
+        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(tail, ctx->h_flag, 3);
+    }
+    u64 declared = 0;
+    for (int k = 0; k < 8; ++k) declared |= (u64)head[k] << (8 * k);
+    if (declared != frame_len - 8) return ark_bad(ctx, "length prefix does not match the frame");
+    size_t p = 8;
+    auto expect = [&](const char* lit) -> bool {
+        const size_t l = strlen(lit);
+        if (p + l > hl || memcmp(head + p, lit, l) != 0) return false;
+        p += l;
+        return true;
+    };
+    if (!expect("{\"result_id\":")) return ark_bad(ctx, "malformed message: result_id");
+    u64 rid = 0;
+    size_t nd = 0;
+    while (p < hl && head[p] >= '0' && head[p] <= '9' && nd < 20) { rid = rid * 10 + (u64)(head[p] - '0'); ++p; ++nd; }
+    if (nd == 0 || (nd > 1 && head[p - nd] == '0')) return ark_bad(ctx, "malformed message: result_id");
+    if (!expect(",\"payload\":{\"")) return ark_bad(ctx, "malformed message: payload");
+    int kind = -1;
+    if (expect("ScalarBatch\":[")) kind = ARKMPC_WIRE_SCALAR_BATCH;
+    else if (expect("PointBatch\":[")) kind = ARKMPC_WIRE_POINT_BATCH;
+    else return ark_bad(ctx, "unsupported payload variant");
+    if (want_kind >= 0 && kind != want_kind) return ark_bad(ctx, "payload variant differs from the expected one");
+    if (memcmp(tail, "]}}", 3) != 0 || frame_len < p + 3) return ark_bad(ctx, "malformed message: trailer");
+    const size_t body_off = p, body_len = frame_len - 3 - p;
+    if (out_result_id) *out_result_id = rid;
+    if (out_kind) *out_kind = kind;
+
+    Stage st(ctx);
+    int ifr = st.declare_in(frame, frame_len);
+    int ior = out_records ? st.declare_out(out_records, max_n * 32) : -1, ios = out_scalars ? st.declare_out(out_scalars, max_n * 32) : -1;
+    const size_t v0 = body_off / 16, v1 = (body_off + body_len + 15) / 16;      // aligned 16-byte vectors covering the body
+    const u32 nblocks = (u32)((v1 - v0 + WIRE_TPB - 1) / WIRE_TPB);
+    size_t scan_bytes = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const u32*)nullptr, (u32*)nullptr, nblocks + 1, ctx->stream);
+    if (e != hipSuccess) { ctx->err = std::string("scan sizing: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    int ic = st.declare_scratch(((size_t)nblocks + 1) * 4), io = st.declare_scratch(((size_t)nblocks + 1) * 4), it = st.declare_scratch(scan_bytes + 64),
+        ip = st.declare_scratch((max_n + 1) * 8), irc = st.declare_scratch(max_n * 32 + 32);
+    if (st.commit()) return st.rc;
+    hipStream_t s = ctx->stream;
+    const unsigned char* fr = st.in<unsigned char>(ifr);
+    const size_t lo = body_off, hi = body_off + body_len;
+    size_t n = 0;
+    if (body_len) {
+        hipLaunchKernelGGL(k_wire_count, dim3(nblocks), dim3(WIRE_TPB), 0, s, fr, v0, lo, hi, st.scratch<u32>(ic), nblocks);
+        e = hipcub::DeviceScan::ExclusiveSum(st.scratch<void>(it), scan_bytes, st.scratch<u32>(ic), st.scratch<u32>(io), nblocks + 1, s);
+        if (e != hipSuccess) { ctx->err = std::string("scan: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+        ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag, st.scratch<u32>(io) + nblocks, 4, hipMemcpyDeviceToHost, s));
+        ARK_HIP(ctx, hipStreamSynchronize(s));
+        n = (size_t)*(u32*)ctx->h_flag;
+        if (n == 0) return ark_bad(ctx, "malformed message: body");
+        if (n > max_n) { *out_n = n; return ark_bad(ctx, "more elements than the output buffer holds"); }
+        ARK_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_wire_positions, dim3(nblocks), dim3(WIRE_TPB), 0, s, fr, v0, lo, hi, st.scratch<u32>(io), st.scratch<u64>(ip), max_n);
+        unsigned char* recs = out_records ? st.out<unsigned char>(ior) : st.scratch<unsigned char>(irc);
+        hipLaunchKernelGGL(k_wire_parse, dim3(blocks_for(n, WIRE_TPB)), dim3(WIRE_TPB), 0, s, n, lo, hi, fr, st.scratch<u64>(ip), recs, ctx->d_flag);
+        if (out_scalars) DISPATCH_F(ctx, hipLaunchKernelGGL((k_wire_scalars<F>), dim3(blocks_for(n, WIRE_TPB)), dim3(WIRE_TPB), 0, s, n, recs,
+                                                            st.out<u64>(ios), ctx->d_flag));
+        ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        ARK_HIP(ctx, hipStreamSynchronize(s));
+        const int err = *ctx->h_flag;
+        if (err & WIRE_E_SYNTAX) return ark_bad(ctx, "malformed message: element syntax");
+        if (err & WIRE_E_RANGE) return ark_bad(ctx, "element out of range (byte > 255 or scalar >= modulus)");
+    }
+    *out_n = n;
+    if (ctx->host_buffers) {
+        if (ior >= 0) st.oplan[ior].bytes = n * 32;
+        if (ios >= 0) st.oplan[ios].bytes = n * 32;
+    }
+    return st.finish();
+}
+
+int arkmpc_wire_decode_scalar_batch(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, uint64_t* out_scalars, size_t* out_n,
+                                    uint64_t* out_result_id) {
+    if (ctx && max_n && !out_scalars) return ark_bad(ctx, "null output");
+    return decode_impl(ctx, frame, frame_len, max_n, ARKMPC_WIRE_SCALAR_BATCH, nullptr, out_scalars, out_n, out_result_id, nullptr);
+}
+int arkmpc_wire_decode_bytes32(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, uint8_t* out_records, size_t* out_n,
+                               uint64_t* out_result_id, int* out_kind) {
+    if (ctx && max_n && !out_records) return ark_bad(ctx, "null output");
+    return decode_impl(ctx, frame, frame_len, max_n, -1, out_records, nullptr, out_n, out_result_id, out_kind);
+}
+
+}  // extern "C"

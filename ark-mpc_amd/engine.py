@@ -237,6 +237,30 @@ class Engine:
     def commit_points_sha3(self, n, pts, blinders, out): self.call("commit_points_sha3", ("size", n), pts, blinders, out)
     def point_mac_verify(self, n, mine, peer, out_ok): self.call("point_mac_verify", ("size", n), mine, peer, out_ok)
 
+    # ---- wire format (QuicTwoPartyNet frames: u64 length + serde_json text)
+    def wire_frame_bound(self, n):
+        out = ctypes.c_size_t(0); self.lib.arkmpc_wire_frame_bound(ctypes.c_size_t(int(n)), ctypes.byref(out)); return int(out.value)
+    def wire_encode_scalar_batch(self, result_id, n, scalars, out_frame, out_cap):
+        ln = ctypes.c_size_t(0)
+        self._ck(self.lib.arkmpc_wire_encode_scalar_batch(self.h, ctypes.c_uint64(int(result_id)), ctypes.c_size_t(int(n)), _ptr(scalars), _ptr(out_frame),
+                                                          ctypes.c_size_t(int(out_cap)), ctypes.byref(ln)))
+        return int(ln.value)
+    def wire_encode_bytes32(self, kind, result_id, n, records, out_frame, out_cap):
+        ln = ctypes.c_size_t(0)
+        self._ck(self.lib.arkmpc_wire_encode_bytes32(self.h, ctypes.c_int(int(kind)), ctypes.c_uint64(int(result_id)), ctypes.c_size_t(int(n)), _ptr(records),
+                                                     _ptr(out_frame), ctypes.c_size_t(int(out_cap)), ctypes.byref(ln)))
+        return int(ln.value)
+    def wire_decode_scalar_batch(self, frame, frame_len, max_n, out_scalars):
+        n = ctypes.c_size_t(0); rid = ctypes.c_uint64(0)
+        self._ck(self.lib.arkmpc_wire_decode_scalar_batch(self.h, _ptr(frame), ctypes.c_size_t(int(frame_len)), ctypes.c_size_t(int(max_n)), _ptr(out_scalars),
+                                                          ctypes.byref(n), ctypes.byref(rid)))
+        return int(n.value), int(rid.value)
+    def wire_decode_bytes32(self, frame, frame_len, max_n, out_records):
+        n = ctypes.c_size_t(0); rid = ctypes.c_uint64(0); kind = ctypes.c_int(-1)
+        self._ck(self.lib.arkmpc_wire_decode_bytes32(self.h, _ptr(frame), ctypes.c_size_t(int(frame_len)), ctypes.c_size_t(int(max_n)), _ptr(out_records),
+                                                     ctypes.byref(n), ctypes.byref(rid), ctypes.byref(kind)))
+        return int(n.value), int(rid.value), int(kind.value)
+
     # ---- Curve25519 (Edwards) points
     def ed_add(self, n, a, b, out): self.call("ed_add", ("size", n), a, b, out)
     def ed_sub(self, n, a, b, out): self.call("ed_sub", ("size", n), a, b, out)

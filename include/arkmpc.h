@@ -230,6 +230,35 @@ int arkmpc_edshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uin
                               const uint64_t* pub_points, uint64_t* out);
 int arkmpc_scalarshare_mul_ed_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Wire format of the batches that cross the party-to-party link (csrc/arkmpc_wire.hip).
+ * A frame is what QuicTwoPartyNet writes (network/quic.rs:303-306): u64 little-endian length, then
+ * serde_json::to_vec(&NetworkOutbound{result_id, payload}) (network.rs:33-60), i.e. the compact text
+ *   {"result_id":<id>,"payload":{"ScalarBatch":[[b0,...,b31],...]}}
+ * with every Scalar as its 32 canonical little-endian bytes (scalar.rs:186-192) and every CurvePoint as its 32
+ * compressed bytes (curve.rs:50-55, :103-108; variant "PointBatch"), each byte a decimal number.
+ * Frame pointers follow the context's buffer mode like every other buffer.  Encoders and decoders block (the frame
+ * length / element count is data dependent).  Decoders validate the whole grammar: any deviation from the compact form
+ * above, a byte > 255 or a scalar >= the modulus returns ARKMPC_ERR_BAD_ARG (serde_json / deserialize_uncompressed
+ * would return an error to the caller, scalar.rs:195-201). */
+#define ARKMPC_WIRE_SCALAR_BATCH 0
+#define ARKMPC_WIRE_POINT_BATCH 1
+/* capacity (bytes) an encode call needs for n elements: 8 + 80 + 131 n + 3 */
+int arkmpc_wire_frame_bound(size_t n, size_t* out_bytes);
+/* NetworkPayload::ScalarBatch of n Montgomery scalars (what open_batch / the Beaver d||e exchange send,
+ * authenticated_scalar.rs:141-145).  *out_len = bytes written (length prefix included). */
+int arkmpc_wire_encode_scalar_batch(arkmpc_ctx* ctx, uint64_t result_id, size_t n, const uint64_t* scalars, uint8_t* out_frame,
+                                    size_t out_cap, size_t* out_len);
+/* n ready-made 32-byte records under the given variant (PointBatch: the output of arkmpc_g1_to_bytes / arkmpc_ed_to_bytes) */
+int arkmpc_wire_encode_bytes32(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const uint8_t* records, uint8_t* out_frame,
+                               size_t out_cap, size_t* out_len);
+/* Parse a received ScalarBatch frame into Montgomery scalars.  max_n = capacity of out_scalars (elements); *out_n = count. */
+int arkmpc_wire_decode_scalar_batch(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, uint64_t* out_scalars,
+                                    size_t* out_n, uint64_t* out_result_id);
+/* Parse a ScalarBatch / PointBatch frame into raw 32-byte records; *out_kind = ARKMPC_WIRE_* */
+int arkmpc_wire_decode_bytes32(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, uint8_t* out_records, size_t* out_n,
+                               uint64_t* out_result_id, int* out_kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,3 +157,19 @@ def ed_extended_mont(a, z=1):
     """extended coordinates (X, Y, T, Z) = (x z, y z, x y z, z) as Montgomery limbs"""
     x, y = a
     return limbs(to_mont(4, x * z)) + limbs(to_mont(4, y * z)) + limbs(to_mont(4, x * y * z)) + limbs(to_mont(4, z))
+
+
+# ---- wire format: QuicTwoPartyNet frames (network/quic.rs:303-306) ------------------------------------------------
+def wire_frame(kind, result_id, records):
+    """u64 LE length || serde_json::to_vec(NetworkOutbound{result_id, payload: kind(records)}) for 32-byte records.
+    serde_json's compact writer = json.dumps with separators (",", ":"): no whitespace, fields in declaration order
+    (result_id, payload; network.rs:36-42), externally tagged enum variant, byte strings as arrays of integers."""
+    import json
+    import struct
+    body = json.dumps({"result_id": int(result_id), "payload": {kind: [list(r) for r in records]}}, separators=(",", ":")).encode()
+    return struct.pack("<Q", len(body)) + body
+
+
+def wire_scalar_records(fid, values):
+    """Scalar::serialize = serialize_uncompressed: 32 canonical little-endian bytes (scalar.rs:186-192)"""
+    return [int(v % P[fid]).to_bytes(32, "little") for v in values]

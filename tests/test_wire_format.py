@@ -1,0 +1,142 @@
+"""Wire format of the batches on the party-to-party link: the Python model used as the checker (pyref.wire_frame)
+against a hand-written known answer, and -- on the GPU -- the HIP encoder / decoder against that model.
+Reference: network.rs:33-60 (NetworkOutbound / NetworkPayload), network/quic.rs:303-306 (u64 LE length + serde_json),
+scalar.rs:186-201 (Scalar <-> 32 canonical LE bytes, validated on read), curve.rs:50-63 (CurvePoint <-> compressed bytes)."""
+import struct
+
+import numpy as np
+import pytest
+
+import pyref
+from helpers import mont_array, rand_values, EngineAdapter
+
+
+def test_model_known_answer():
+    """One-scalar ScalarBatch, value 1 + 255*256 + 2^248*10: the literal serde_json text."""
+    v = 1 + 255 * 256 + (10 << 248)
+    want = b'{"result_id":7,"payload":{"ScalarBatch":[[1,255' + b",0" * 29 + b",10]]}}"
+    got = pyref.wire_frame("ScalarBatch", 7, pyref.wire_scalar_records(0, [v]))
+    assert got == struct.pack("<Q", len(want)) + want
+    assert pyref.wire_frame("PointBatch", 0, []) == struct.pack("<Q", 43) + b'{"result_id":0,"payload":{"PointBatch":[]}}'
+
+
+@pytest.fixture(scope="module")
+def hip(pkg):
+    return EngineAdapter(pkg)
+
+
+def encode(eng, rid, values_mont, n):
+    cap = eng.wire_frame_bound(n)
+    buf = np.zeros(cap, dtype=np.uint8)
+    ln = eng.wire_encode_scalar_batch(rid, n, values_mont if n else np.zeros(4, dtype=np.uint64), buf, cap)
+    return buf[:ln].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fid", [0, 1, 2])
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 3000])
+def test_encode_scalar_batch_matches_model(hip, fid, n):
+    p = pyref.P[fid]
+    vals = ([0, 1, p - 1, 255, 256, 10 ** 20, (1 << 248) - 1] + rand_values(fid, max(n, 7), 500 + n))[:n]
+    rid = [0, 9, 10, 12345678901234567890][n % 4]
+    got = encode(hip.eng(fid), rid, mont_array(fid, vals), n)
+    assert got == pyref.wire_frame("ScalarBatch", rid, pyref.wire_scalar_records(fid, vals))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 31, 256, 3000])
+def test_decode_scalar_batch(hip, n):
+    fid = 0
+    vals = ([0, pyref.P[fid] - 1, 1] + rand_values(fid, max(n, 3), 600 + n))[:n]
+    frame = np.frombuffer(pyref.wire_frame("ScalarBatch", 42 + n, pyref.wire_scalar_records(fid, vals)), dtype=np.uint8).copy()
+    out = np.zeros(4 * max(n, 1), dtype=np.uint64)
+    cnt, rid = hip.eng(fid).wire_decode_scalar_batch(frame, len(frame), max(n, 1), out)
+    assert (cnt, rid) == (n, 42 + n)
+    assert np.array_equal(out[:4 * n], mont_array(fid, vals))
+
+
+@pytest.mark.gpu
+def test_point_batch_round_trip(hip, oracle):
+    """PointBatch: compressed points from arkmpc_g1_to_bytes -> frame == model(frame of oracle bytes) -> records back."""
+    from test_gpu_curve import random_points
+    n = 50
+    pts, P = random_points(n, 700)
+    recs = hip.g1_to_bytes(P)
+    eng = hip.eng(0)
+    cap = eng.wire_frame_bound(n)
+    buf = np.zeros(cap, dtype=np.uint8)
+    ln = eng.wire_encode_bytes32(1, 77, n, recs, buf, cap)
+    want = pyref.wire_frame("PointBatch", 77, [pyref.g1_compress(p) for p in pts])
+    assert buf[:ln].tobytes() == want
+    back = np.zeros(32 * n, dtype=np.uint8)
+    cnt, rid, kind = eng.wire_decode_bytes32(buf[:ln].copy(), ln, n, back)
+    assert (cnt, rid, kind) == (n, 77, 1) and np.array_equal(back, recs)
+
+
+def _mutations(good):
+    body = good[8:]
+    def fr(b): return struct.pack("<Q", len(b)) + b
+    yield "length prefix", struct.pack("<Q", len(body) + 1) + body
+    yield "whitespace", fr(body.replace(b"[[", b"[ [", 1))
+    yield "byte > 255", fr(body.replace(b"[[", b"[[256,", 1).replace(b",0]", b"]", 1))
+    yield "leading zero", fr(body.replace(b",255,", b",0255,", 1))
+    yield "31 numbers", fr(body.replace(b",255,", b",", 1))
+    yield "33 numbers", fr(body.replace(b",255,", b",255,255,", 1))
+    yield "missing separator", fr(body.replace(b"],[", b"][", 1))
+    yield "trailing garbage in body", fr(body.replace(b"]]}}", b"],]}}", 1))
+    yield "other variant", fr(body.replace(b"ScalarBatch", b"ScalarShare", 1))
+    yield "trailer", fr(body[:-1])
+    yield "negative", fr(body.replace(b",255,", b",-25,", 1))
+
+
+@pytest.mark.gpu
+def test_decode_rejects_malformed_frames(hip, pkg):
+    fid = 0
+    vals = [255 * 256 + 7, 5, (255 << 8) | (255 << 40)] + rand_values(fid, 300, 801)
+    good = pyref.wire_frame("ScalarBatch", 3, pyref.wire_scalar_records(fid, vals))
+    eng = hip.eng(fid)
+    out = np.zeros(4 * len(vals), dtype=np.uint64)
+    assert eng.wire_decode_scalar_batch(np.frombuffer(good, dtype=np.uint8).copy(), len(good), len(vals), out)[0] == len(vals)
+    seen = 0
+    for name, bad in _mutations(good):
+        assert bad != good, name
+        arr = np.frombuffer(bad, dtype=np.uint8).copy()
+        with pytest.raises(pkg.ArkMpcError):
+            eng.wire_decode_scalar_batch(arr, len(arr), len(vals), out)
+        seen += 1
+    assert seen == 11
+    # scalar >= modulus: deserialize_uncompressed rejects it (scalar.rs:195-201)
+    p = pyref.P[fid]
+    over = pyref.wire_frame("ScalarBatch", 3, [int(p).to_bytes(32, "little")])
+    arr = np.frombuffer(over, dtype=np.uint8).copy()
+    with pytest.raises(pkg.ArkMpcError):
+        eng.wire_decode_scalar_batch(arr, len(arr), 4, out)
+    # output capacity too small
+    with pytest.raises(pkg.ArkMpcError):
+        eng.wire_decode_scalar_batch(np.frombuffer(good, dtype=np.uint8).copy(), len(good), 10, out)
+
+
+@pytest.mark.gpu
+def test_large_round_trip_device_buffers(pkg):
+    """2^21 scalars (the d||e exchange of a 2^20-gate batch) on device buffers: decode(encode(x)) == x, the text checked
+    against the model on a prefix and through its total length."""
+    torch = pytest.importorskip("torch")
+    n = 1 << 21
+    e = pkg.Engine(0, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    raw = torch.randint(-(2**63), 2**63 - 1, (4 * n,), dtype=torch.int64, device="cuda", generator=g)
+    x = torch.empty_like(raw); e.scalar_from_canonical(n, raw, x)
+    cap = e.wire_frame_bound(n)
+    frame = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    ln = e.wire_encode_scalar_batch(99, n, x, frame, cap)
+    canon = torch.empty_like(x); e.scalar_to_canonical(n, x, canon); torch.cuda.synchronize()
+    cb = canon.cpu().numpy().view(np.uint8).reshape(n, 32)
+    digits = np.where(cb >= 100, 3, np.where(cb >= 10, 2, 1)).sum()
+    assert ln == 8 + len(b'{"result_id":99,"payload":{"ScalarBatch":[') + int(digits) + 31 * n + 2 * n + (n - 1) + 3
+    k = 2000
+    model = pyref.wire_frame("ScalarBatch", 99, [bytes(r) for r in cb[:k]])
+    head = frame[:len(model) - 3].cpu().numpy().tobytes()
+    assert head[8:] == model[8:-3]
+    back = torch.empty_like(x)
+    cnt, rid = e.wire_decode_scalar_batch(frame, ln, n, back)
+    assert (cnt, rid) == (n, 99) and torch.equal(back, x)
