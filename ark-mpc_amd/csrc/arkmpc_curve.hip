@@ -371,6 +371,55 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_to_bytes(size_t n, const u64* pts
     q[1] = make_uint4(xc.v[4], xc.v[5], xc.v[6], top);
 }
 
+// CurvePoint::from_bytes (curve.rs:110-114) = deserialize_compressed with validation, the inverse of k_g1_to_bytes:
+// x must be canonical (< q) and at most one flag bit set; bit 6 -> identity; otherwise y = (x^3 + 3)^((q+1)/4) (q = 3 mod 4)
+// must square back to x^3 + 3, and bit 7 selects the larger root.  ok[i] = 0 (and the identity) for a non-encoding.
+__global__ void __launch_bounds__(TPB_EC) k_g1_from_bytes(size_t n, const unsigned char* in, u64* out, unsigned char* ok) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    using P = FieldParams<FQ>;
+    const uint4* q = reinterpret_cast<const uint4*>(in + 32 * i);
+    const uint4 a = q[0], b = q[1];
+    Fe xc;
+    xc.v[0] = a.x; xc.v[1] = a.y; xc.v[2] = a.z; xc.v[3] = a.w; xc.v[4] = b.x; xc.v[5] = b.y; xc.v[6] = b.z; xc.v[7] = b.w & 0x3fffffffu;
+    const bool neg = (b.w >> 31) & 1u, inf = (b.w >> 30) & 1u;
+    u32 br = 0, bo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { (void)__builtin_subc(xc.v[k], P::P(k), br, &bo); br = bo; }
+    bool valid = br && !(neg && inf);                 // x - q borrows <=> x < q
+    G1 r = g1_identity();
+    if (valid && !inf) {
+        const Fe x = fe_from_canonical<FQ>(xc);
+        const Fe three = fe_add<FQ>(fe_dbl<FQ>(fe_one<FQ>()), fe_one<FQ>());
+        const Fe rhs = fe_add<FQ>(FQ_MUL(FQ_SQR(x), x), three);
+        u32 e[8], cy = 1;                             // e = (q + 1) / 4
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const u64 t = (u64)P::P(k) + cy; e[k] = (u32)t; cy = (u32)(t >> 32); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = (e[k] >> 2) | (k < 7 ? e[k + 1] << 30 : 0u);
+        Fe y = fe_one<FQ>();
+        for (int limb = 7; limb >= 0; --limb) {
+            u32 w = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w = (limb == k) ? e[k] : w;
+            for (int bit = 31; bit >= 0; --bit) {
+                y = FQ_SQR(y);
+                if ((w >> bit) & 1u) y = FQ_MUL(y, rhs);
+            }
+        }
+        valid = fe_eq(FQ_SQR(y), rhs);
+        const Fe ny = fe_neg<FQ>(y);
+        const Fe yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(ny);
+        u32 b2 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nyc.v[k], yc.v[k], b2, &bo); b2 = bo; }   // borrows <=> y > -y
+        const bool y_is_larger = b2 != 0;
+        if (valid) { r.x = x; r.y = (y_is_larger == neg) ? y : ny; r.z = fe_one<FQ>(); }
+    }
+    g1_store(out + 12 * i, r);
+    ok[i] = valid ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Point sums: the reduction gate of AuthenticatedPointResult::msm (authenticated_curve.rs:796-805) and
 // PointShare's Sum (curve/share.rs:85-92).  Two launches: every thread folds a strided slice of the n points, then one
@@ -636,6 +685,16 @@ int arkmpc_g1_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_
     int ip = st.declare_in(points, n * 96), io = st.declare_out(out_bytes, n * 32);
     if (st.commit()) return st.rc;
     if (n) hipLaunchKernelGGL(k_g1_to_bytes, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.out<unsigned char>(io));
+    return st.finish();
+}
+
+int arkmpc_g1_from_bytes(arkmpc_ctx* ctx, size_t n, const uint8_t* bytes, uint64_t* out_points, uint8_t* out_ok) {
+    ENTER_EC(ctx);
+    Stage st(ctx);
+    int ib = st.declare_in(bytes, n * 32), io = st.declare_out(out_points, n * 96), ik = st.declare_out(out_ok, n);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_g1_from_bytes, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<unsigned char>(ib), st.out<u64>(io),
+                              st.out<unsigned char>(ik));
     return st.finish();
 }
 

@@ -230,6 +230,7 @@ class Engine:
     def scalarshare_mul_point(self, n, ss, pts, out): self.call("scalarshare_mul_point", ("size", n), ss, pts, out)
     def pointshare_extract(self, n, shares, out): self.call("pointshare_extract", ("size", n), shares, out)
     def point_mac_check_shares(self, n, key, opened, shares, out): self.call("point_mac_check_shares", ("size", n), ("key", key), opened, shares, out)
+    def g1_from_bytes(self, n, data, out, out_ok): self.call("g1_from_bytes", ("size", n), data, out, out_ok)
     def g1_sum(self, n, pts, out): self.call("g1_sum", ("size", n), pts, out)
     def pointshare_sum(self, n, shares, out): self.call("pointshare_sum", ("size", n), shares, out)
     def g1_msm(self, n, pts, scalars, out): self.call("g1_msm", ("size", n), pts, scalars, out)

@@ -16,8 +16,10 @@
 // What is NOT mirrored (out of scope): the DAG executor and ResultHandle futures -- operations
 // here run eagerly on the GPU stream, and a "network op" is a blocking send/receive of the batch payload.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -126,6 +128,9 @@ class DeviceBuf {
 struct NetworkOutbound {
     uint64_t result_id;            // ids are allocated in lock-step by both parties (fabric.rs:282-295)
     std::vector<Scalar> payload;
+    // wire mode (MpcFabric::set_wire_frames): the message as QuicTwoPartyNet would put it on the stream -- u64 LE length +
+    // serde_json text (network/quic.rs:303-306), produced and parsed by the engine's codec (csrc/arkmpc_wire.hip)
+    std::vector<uint8_t> frame;
 };
 class MpcNetwork {
   public:
@@ -250,9 +255,41 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         ScalarBatch b; b.n = mont.size(); b.buf = DeviceBuf(eng_, 4 * (mont.size() ? mont.size() : 1)); b.buf.upload(mont.data(), mont.size() * 32);
         return b;
     }
+    // Wire mode: every batch crosses the mock link as the serde_json frame the QUIC transport would carry, so the
+    // protocol-level scenarios exercise the GPU encoder / validating decoder end to end (env ARKMPC_MOCK_WIRE=1 in
+    // execute_mock_mpc).  Off: payloads are handed over as host vectors (network/mock.rs).
+    void set_wire_frames(bool on) { wire_ = on; }
+    bool wire_frames() const { return wire_; }
+    static std::atomic<uint64_t>& frames_sent() { static std::atomic<uint64_t> c{0}; return c; }   // process-wide, for the tests
     // send / receive / exchange of a scalar batch (fabric.rs:720-814): party 0 sends first then receives
-    void send_values(const ScalarBatch& v) { net_->send(NetworkOutbound{next_id_++, v.to_host()}); }
-    ScalarBatch receive_values() { NetworkOutbound m = net_->receive(); next_id_++; return allocate_scalars(m.payload); }
+    void send_values(const ScalarBatch& v) {
+        if (!wire_) { net_->send(NetworkOutbound{next_id_++, v.to_host(), {}}); return; }
+        const uint64_t id = next_id_++;
+        size_t cap = 0, len = 0;
+        arkmpc_wire_frame_bound(v.n, &cap);
+        DeviceBuf fr(eng_, cap / 8 + 1);
+        check(ctx(), arkmpc_wire_encode_scalar_batch(ctx(), id, v.n, v.buf.ptr(), reinterpret_cast<uint8_t*>(fr.ptr()), cap, &len), "wire_encode_scalar_batch");
+        NetworkOutbound m{id, {}, std::vector<uint8_t>(len)};
+        fr.download(m.frame.data(), len);
+        frames_sent()++;
+        net_->send(std::move(m));
+    }
+    ScalarBatch receive_values() {
+        NetworkOutbound m = net_->receive();
+        const uint64_t id = next_id_++;
+        if (!wire_) return allocate_scalars(m.payload);
+        // the element count is only known after parsing: a scalar's text is at least 66 bytes ("[0,0,...,0]," )
+        const size_t max_n = m.frame.size() / 66 + 1;
+        DeviceBuf fr(eng_, m.frame.size() / 8 + 2);
+        fr.upload(m.frame.data(), m.frame.size());
+        ScalarBatch b; b.buf = DeviceBuf(eng_, 4 * max_n);
+        size_t n = 0; uint64_t rid = 0;
+        check(ctx(), arkmpc_wire_decode_scalar_batch(ctx(), reinterpret_cast<const uint8_t*>(fr.ptr()), m.frame.size(), max_n, b.buf.ptr(), &n, &rid),
+              "wire_decode_scalar_batch");
+        if (rid != id) throw std::runtime_error("MpcNetworkError: result id mismatch on a received frame");
+        b.n = n;
+        return b;
+    }
     ScalarBatch exchange_values(const ScalarBatch& mine) {
         if (party_ == PARTY0) { send_values(mine); return receive_values(); }
         ScalarBatch peer = receive_values(); send_values(mine); return peer;
@@ -262,17 +299,54 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         if (party_ == sender) { ScalarBatch b = allocate_scalars(mont); send_values(b); return b; }
         (void)n; return receive_values();
     }
-    // point payloads travel as 12 x u64 per point packed into the scalar-vector payload (NetworkPayload::PointBatch, network.rs:45-60)
-    template <class PB> PB exchange_points(const PB& mine) {
-        std::vector<uint64_t> h = mine.to_host();
-        std::vector<Scalar> pay(3 * mine.n);
-        std::memcpy(pay.data(), h.data(), h.size() * 8);
-        NetworkOutbound got;
-        if (party_ == PARTY0) { net_->send(NetworkOutbound{next_id_++, std::move(pay)}); got = net_->receive(); next_id_++; }
-        else { got = net_->receive(); next_id_++; net_->send(NetworkOutbound{next_id_++, std::move(pay)}); }
-        PB r; r.n = mine.n; r.buf = DeviceBuf(eng_, 12 * (mine.n ? mine.n : 1));
-        r.buf.upload(got.payload.data(), mine.n * 96);
+    // Point batches (NetworkPayload::PointBatch, network.rs:45-60).  Mock mode: 12 x u64 Jacobian limbs per point packed
+    // into the payload vector.  Wire mode: compressed points (CurvePoint::to_bytes, curve.rs:50-55) as serde_json text; the
+    // receiver decompresses with validation (CurvePoint::from_bytes, :57-63).
+    template <class PB> void send_points(const PB& mine) {
+        const size_t n = mine.n;
+        const uint64_t id = next_id_++;
+        if (!wire_) {
+            std::vector<uint64_t> h = mine.to_host();
+            std::vector<Scalar> pay(3 * n);
+            std::memcpy(pay.data(), h.data(), h.size() * 8);
+            net_->send(NetworkOutbound{id, std::move(pay), {}});
+            return;
+        }
+        DeviceBuf bytes(eng_, 4 * (n ? n : 1));
+        if (n) check(ctx(), arkmpc_g1_to_bytes(ctx(), n, mine.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "g1_to_bytes");
+        size_t cap = 0, len = 0;
+        arkmpc_wire_frame_bound(n, &cap);
+        DeviceBuf fr(eng_, cap / 8 + 1);
+        check(ctx(), arkmpc_wire_encode_bytes32(ctx(), ARKMPC_WIRE_POINT_BATCH, id, n, reinterpret_cast<const uint8_t*>(bytes.ptr()),
+                                                reinterpret_cast<uint8_t*>(fr.ptr()), cap, &len), "wire_encode_bytes32");
+        NetworkOutbound m{id, {}, std::vector<uint8_t>(len)};
+        fr.download(m.frame.data(), len);
+        frames_sent()++;
+        net_->send(std::move(m));
+    }
+    template <class PB> PB receive_points(size_t n) {
+        NetworkOutbound m = net_->receive();
+        const uint64_t id = next_id_++;
+        PB r; r.n = n; r.buf = DeviceBuf(eng_, 12 * (n ? n : 1));
+        if (!wire_) { r.buf.upload(m.payload.data(), n * 96); return r; }
+        DeviceBuf fr(eng_, m.frame.size() / 8 + 2);
+        fr.upload(m.frame.data(), m.frame.size());
+        DeviceBuf bytes(eng_, 4 * (n ? n : 1));
+        size_t cnt = 0; uint64_t rid = 0; int kind = -1;
+        check(ctx(), arkmpc_wire_decode_bytes32(ctx(), reinterpret_cast<const uint8_t*>(fr.ptr()), m.frame.size(), n ? n : 1,
+                                                reinterpret_cast<uint8_t*>(bytes.ptr()), &cnt, &rid, &kind), "wire_decode_bytes32");
+        if (rid != id || cnt != n || kind != ARKMPC_WIRE_POINT_BATCH) throw std::runtime_error("MpcNetworkError: unexpected point frame");
+        DeviceBuf okd(eng_, (n + 7) / 8 + 1);
+        if (n) check(ctx(), arkmpc_g1_from_bytes(ctx(), n, reinterpret_cast<const uint8_t*>(bytes.ptr()), r.buf.ptr(), reinterpret_cast<uint8_t*>(okd.ptr())),
+                     "g1_from_bytes");
+        std::vector<uint8_t> ok(n);
+        okd.download(ok.data(), n);
+        for (auto b : ok) if (!b) throw std::runtime_error("MpcNetworkError::SerializationError: invalid point encoding");
         return r;
+    }
+    template <class PB> PB exchange_points(const PB& mine) {
+        if (party_ == PARTY0) { send_points(mine); return receive_points<PB>(mine.n); }
+        PB r = receive_points<PB>(mine.n); send_points(mine); return r;
     }
     void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c);  // fabric.rs:894-915
     AuthenticatedScalarBatch random_shared_scalars(size_t n);                                    // fabric.rs:917-928
@@ -289,6 +363,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     std::unique_ptr<MpcNetwork> net_;
     std::unique_ptr<PreprocessingPhase> prep_;
     Scalar mac_key_;
+    bool wire_ = false;
     uint64_t next_id_ = 6;   // N_CONSTANT_RESULTS (fabric.rs:55-70)
 };
 
@@ -591,17 +666,11 @@ inline APB MpcFabric::batch_share_point(const std::vector<uint64_t>& points, siz
         if (n) check(ctx(), arkmpc_g1_generator_mul(ctx(), n, masks.buf.ptr(), mg.buf.ptr()), "g1_generator_mul");
         masked = APB::alloc_points(self, n);
         if (n) check(ctx(), arkmpc_g1_sub(ctx(), n, vals.buf.ptr(), mg.buf.ptr(), masked.buf.ptr()), "g1_sub");
-        // plaintext broadcast of the masked points (batch_share_plaintext)
-        std::vector<uint64_t> h = masked.to_host();
-        std::vector<Scalar> pay(3 * n);
-        std::memcpy(pay.data(), h.data(), h.size() * 8);
-        net_->send(NetworkOutbound{next_id_++, std::move(pay)});
+        send_points(masked);                                // plaintext broadcast of the masked points (batch_share_plaintext)
         mask_shares = std::move(lm.second);
     } else {
         mask_shares = prep_->next_counterparty_input_mask_batch(n);
-        NetworkOutbound got = net_->receive(); next_id_++;
-        masked = APB::alloc_points(self, n);
-        masked.buf.upload(got.payload.data(), n * 96);
+        masked = receive_points<PointBatch>(n);
     }
     AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
     APB masks_g = APB::batch_mul_generator(shares);
@@ -691,6 +760,7 @@ std::pair<T, T> execute_mock_mpc(int field_id, int device,
             std::unique_ptr<MpcNetwork> net(new MockNetwork(p, p == 0 ? q01 : q10, p == 0 ? q10 : q01));
             MpcNetwork* raw = net.get();
             auto fab = std::make_shared<MpcFabric>(p, eng, std::move(net), make_prep(p, *eng));
+            if (const char* w = std::getenv("ARKMPC_MOCK_WIRE")) fab->set_wire_frames(w[0] == '1');
             try { out[p] = f(fab); } catch (...) { raw->close(); throw; }
         } catch (...) { err[p] = std::current_exception(); }
     };

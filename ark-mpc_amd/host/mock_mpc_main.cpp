@@ -149,6 +149,7 @@ int main(int argc, char** argv) {
             return out;
         };
         auto both = execute_mock_mpc<PartyOut>(field_id, 0, make_prep, program);
+        std::printf("frames %llu\n", (unsigned long long)MpcFabric::frames_sent().load());
         std::ofstream out(argv[5], std::ios::binary);
         for (const PartyOut* po : {&both.first, &both.second}) {
             out.write(reinterpret_cast<const char*>(&po->err), 8);

@@ -172,6 +172,10 @@ int arkmpc_g1_generator_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* scalars, 
 int arkmpc_g1_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy, uint8_t* out_inf);
 /* CurvePoint::to_bytes (curve.rs:103-108): arkworks compressed encoding, n x 32 bytes */
 int arkmpc_g1_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes);
+/* CurvePoint::from_bytes (curve.rs:110-114) = deserialize_compressed with validation: n x 32 bytes -> n points (x, y, 1)
+ * (identity as (1,1,0)); out_ok[i] = 1 if the bytes are a point encoding (x < q, at most one flag bit, x^3 + 3 a square),
+ * else 0 and the identity is stored.  What a party runs on a received PointBatch (authenticated_curve.rs:74-89). */
+int arkmpc_g1_from_bytes(arkmpc_ctx* ctx, size_t n, const uint8_t* bytes, uint64_t* out_points, uint8_t* out_ok);
 /* PointShare ops, curve/share.rs:55-114 via authenticated_curve.rs batch_* */
 int arkmpc_pointshare_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);          /* :396-426 */
 int arkmpc_pointshare_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);          /* :520-550 */

@@ -493,6 +493,38 @@ void ora_g1_to_bytes(const u64 a[12], unsigned char out[32]) {
     int y_gt_neg = geq(yc, nyc) && memcmp(yc, nyc, 32) != 0;
     if (y_gt_neg) out[31] |= 0x80;
 }
+/* CurvePoint::from_bytes (curve.rs:110-114) = deserialize_compressed with validation: x must be canonical (< q), at most one
+ * flag bit set; infinity flag -> identity; otherwise y = sqrt(x^3 + 3) must exist (q = 3 mod 4: y = rhs^((q+1)/4)) and the
+ * root selected is the larger one iff bit 7 is set (the inverse of ora_g1_to_bytes).  Returns 1 if valid, 0 (and the
+ * identity) if the bytes are not a point encoding.  BN254 G1 has cofactor 1, so on-curve implies in-subgroup. */
+int ora_g1_from_bytes(const unsigned char in[32], u64 out[12]) {
+    const ora_field* q = FQ;
+    ora_g1_identity(out);
+    const int neg = (in[31] >> 7) & 1, inf = (in[31] >> 6) & 1;
+    if (neg && inf) return 0;
+    u64 xc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 32; ++i) { unsigned char b = in[i]; if (i == 31) b &= 0x3f; xc[i / 8] |= (u64)b << (8 * (i % 8)); }
+    if (geq(xc, q->p)) return 0;
+    if (inf) return 1;
+    u64 x[4], rhs[4], three[4] = {3, 0, 0, 0}, t[4];
+    ora_fp_from_canonical(q, xc, x);
+    fp_sqr(q, x, t); ora_fp_mul(q, t, x, rhs); ora_fp_from_canonical(q, three, t); ora_fp_add(q, rhs, t, rhs);
+    u64 e[4];
+    {   /* q + 1 does not overflow 256 bits (q < 2^254) */
+        unsigned __int128 cy = 1;
+        for (int i = 0; i < 4; ++i) { cy += q->p[i]; e[i] = (u64)cy; cy >>= 64; }
+        for (int i = 0; i < 4; ++i) e[i] = (e[i] >> 2) | (i < 3 ? e[i + 1] << 62 : 0);
+    }
+    u64 y[4]; memcpy(y, q->r, 32);
+    for (int i = 255; i >= 0; --i) { fp_sqr(q, y, y); if ((e[i / 64] >> (i % 64)) & 1) ora_fp_mul(q, y, rhs, y); }
+    fp_sqr(q, y, t);
+    if (memcmp(t, rhs, 32) != 0) return 0;                  /* x^3 + 3 is not a square */
+    u64 ny[4], yc[4], nyc[4];
+    ora_fp_neg(q, y, ny); ora_fp_to_canonical(q, y, yc); ora_fp_to_canonical(q, ny, nyc);
+    const int y_is_larger = geq(yc, nyc) && memcmp(yc, nyc, 32) != 0;
+    memcpy(out, x, 32); memcpy(out + 4, (y_is_larger == neg) ? y : ny, 32); memcpy(out + 8, q->r, 32);
+    return 1;
+}
 void ora_g1_batch_add(size_t n, const u64* a, const u64* b, u64* out) {
     for (size_t i = 0; i < n; ++i) ora_g1_add(a + 12 * i, b + 12 * i, out + 12 * i);
 }

@@ -119,6 +119,7 @@ int ora_g1_to_affine(const u64 a[12], u64 out_xy[8]);
 int ora_g1_eq(const u64 a[12], const u64 b[12]);
 /* arkworks serialize_compressed (curve.rs:103-108): x LE 32 B, bit7 of last byte = y > -y, bit6 = infinity */
 void ora_g1_to_bytes(const u64 a[12], unsigned char out[32]);
+int ora_g1_from_bytes(const unsigned char in[32], u64 out[12]);   /* curve.rs:110-114; 1 = valid encoding */
 void ora_g1_batch_add(size_t n, const u64* a, const u64* b, u64* out);
 void ora_g1_batch_scalar_mul(size_t n, const u64* pts, const u64* scalars, u64* out);
 void ora_g1_sum(size_t n, const u64* pts, size_t stride_u64, u64 out[12]);   /* authenticated_curve.rs:796-805 */

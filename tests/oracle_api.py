@@ -21,6 +21,7 @@ class Oracle:
         self.lib = ctypes.CDLL(path)
         self.lib.ora_mac_verify.restype = ctypes.c_int
         self.lib.ora_g1_to_affine.restype = ctypes.c_int
+        self.lib.ora_g1_from_bytes.restype = ctypes.c_int
 
     @staticmethod
     def _p(a):
@@ -142,6 +143,11 @@ class Oracle:
         for i in range(n):
             self.lib.ora_g1_to_bytes(self._p(pts[12 * i:12 * i + 12].copy()), ctypes.c_void_p(out.ctypes.data + 32 * i))
         return out
+    def g1_from_bytes(self, data):
+        n = len(data) // 32; out = np.zeros(12 * n, dtype=np.uint64); ok = np.zeros(n, dtype=np.uint8)
+        for i in range(n):
+            ok[i] = self.lib.ora_g1_from_bytes(ctypes.c_void_p(data.ctypes.data + 32 * i), ctypes.c_void_p(out.ctypes.data + 96 * i))
+        return out, ok
     def g1_sum(self, pts, stride=12, off=0):
         n = len(pts) // stride; out = np.zeros(12, dtype=np.uint64)
         self.lib.ora_g1_sum(ctypes.c_size_t(n), ctypes.c_void_p(pts.ctypes.data + 8 * off), ctypes.c_size_t(stride), self._p(out)); return out

@@ -181,3 +181,19 @@ def test_point_sums(hip, oracle, n):
         hip.eng(0).pointshare_sum(m, P, out2)
         assert affine_equal(hip, oracle, out2[:12].copy(), oracle.g1_sum(P, stride=24, off=0))
         assert affine_equal(hip, oracle, out2[12:].copy(), oracle.g1_sum(P, stride=24, off=12))
+
+
+def test_from_bytes(hip, oracle):
+    """arkmpc_g1_from_bytes vs the oracle: round trip of to_bytes, (x, y, 1) outputs bit-equal, invalid encodings flagged."""
+    n = 200
+    pts, P = random_points(n, 41)
+    data = hip.g1_to_bytes(P)
+    bad = [int(pyref.Q).to_bytes(32, "little"), bytes(31) + b"\xc0", (5).to_bytes(32, "little"), bytes(31) + b"\x40", (1).to_bytes(32, "little")]
+    data = np.concatenate([data, np.frombuffer(b"".join(bad), dtype=np.uint8)])
+    m = len(data) // 32
+    out = np.zeros(12 * m, dtype=np.uint64); ok = np.zeros(m, dtype=np.uint8)
+    hip.eng(0).g1_from_bytes(m, data, out, ok)
+    want, want_ok = oracle.g1_from_bytes(data)
+    assert np.array_equal(ok, want_ok) and np.array_equal(out, want)       # no addition chain involved: exact limbs
+    assert ok[:n].all() and affine_equal(hip, oracle, out[:12 * n], P)
+    assert ok[n:].tolist() == want_ok[n:].tolist()

@@ -80,3 +80,26 @@ def test_msm_vs_python(oracle):
     got = oracle.g1_msm_authenticated(P, shares)
     assert affine_of(oracle, got) == [ref(ks), ref(macs)]
     assert affine_of(oracle, oracle.g1_msm(P[:0], mont_array(0, []))) == [None]     # empty -> identity
+
+
+def test_from_bytes_vs_python(oracle):
+    """CurvePoint::from_bytes (curve.rs:110-114): inverse of the compressed encoding, with arkworks' validation."""
+    ks = [1, 2, 3, pyref.RORD - 1] + rand_values(0, 20, 90)
+    pts = [pyref.g1_mul(pyref.G, k) for k in ks] + [None]
+    data = np.frombuffer(b"".join(pyref.g1_compress(p) for p in pts), dtype=np.uint8).copy()
+    out, ok = oracle.g1_from_bytes(data)
+    assert ok.tolist() == [1] * len(pts)
+    assert affine_of(oracle, out) == pts
+    assert np.array_equal(out[-12:], oracle.g1_identity())
+    for i in range(len(ks)):                                              # decompressed points are (x, y, 1)
+        assert np.array_equal(out[12 * i + 8:12 * i + 12], oracle.g1_identity()[:4])
+    # invalid encodings: x >= q, both flags, x^3 + 3 a non-residue
+    bad = []
+    b = bytearray(int(pyref.Q).to_bytes(32, "little")); bad.append(bytes(b))
+    b = bytearray(pyref.g1_compress(pts[0])); b[31] |= 0xC0; bad.append(bytes(b))
+    x = 0
+    while pow((x ** 3 + 3) % pyref.Q, (pyref.Q - 1) // 2, pyref.Q) == 1 or (x ** 3 + 3) % pyref.Q == 0:
+        x += 1
+    bad.append(int(x).to_bytes(32, "little"))
+    out, ok = oracle.g1_from_bytes(np.frombuffer(b"".join(bad), dtype=np.uint8).copy())
+    assert ok.tolist() == [0, 0, 0]
