@@ -67,9 +67,10 @@ def build_host(force=False, verbose=False):
         return None
     exe = os.path.join(LIB, "arkmpc_mock_mpc")
     deps = [src, os.path.join(HOST, "fabric.hpp"), os.path.join(HERE, "..", "include", "arkmpc.h"), os.path.join(LIB, "libarkmpc_hip.so")]
-    if force or _newer(exe, deps):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(HERE, "..", "include"), "-I", HOST, "-o", exe, src,
-              "-L", LIB, "-larkmpc_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
+    for s_, e_ in ((src, exe), (os.path.join(HOST, "bench_main.cpp"), os.path.join(LIB, "arkmpc_host_bench"))):
+        if os.path.exists(s_) and (force or _newer(e_, [s_] + deps[1:])):
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(HERE, "..", "include"), "-I", HOST, "-o", e_, s_,
+                  "-L", LIB, "-larkmpc_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")])
     return exe
 
 

@@ -309,6 +309,18 @@ __global__ void __launch_bounds__(TPB) k_mac_verify(size_t n, const u64* mine, c
     }
 }
 
+// broadcast of one record of `w` 16-byte vectors to n slots (constant batches of a preprocessing source, fabric constants)
+struct FillRecord { uint4 v[6]; };
+__global__ void __launch_bounds__(TPB) k_fill_records(size_t n, u32 w, FillRecord rec, uint4* out) {
+    const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;      // one 16-byte vector per thread: coalesced
+    if (t >= n * w) return;
+    const u32 k = (u32)(t % w);
+    uint4 v = rec.v[0];
+#pragma unroll
+    for (int j = 1; j < 6; ++j) v = (k == (u32)j) ? rec.v[j] : v;
+    out[t] = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
 // ---------------------------------------------------------------------------------------------
@@ -399,6 +411,47 @@ static void scan_level(arkmpc_ctx* ctx, size_t n, const u64* in, u64* out, u64* 
 // ---------------------------------------------------------------------------------------------
 // C ABI: context
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Device memory pool behind arkmpc_malloc / arkmpc_free.  hipFree synchronises the whole device and unmaps the range
+// (about a millisecond for the 32-64 MiB batches of this path); a host-side protocol step allocates and drops a dozen of
+// them.  Freed blocks are kept per size class (power of two below 1 MiB, 2 MiB granules above) and handed out again.
+// A block may have been read by another context's stream (a batch handed to the peer party of the in-process mock), so
+// recycling is fenced by a device-wide synchronise -- what hipFree did implicitly.  ARKMPC_NO_POOL=1 restores plain
+// hipMalloc / hipFree; ARKMPC_POOL_MAX_MB caps the cached bytes (default 16 GiB of the 288 GB).
+// ---------------------------------------------------------------------------------------------
+#include <map>
+#include <unordered_map>
+namespace {
+struct DevicePool {
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> free_;
+    std::unordered_map<void*, size_t> live_;
+    size_t cached = 0;
+    int refs = 0;
+};
+DevicePool g_pool[16];
+bool pool_enabled() {
+    static const bool on = !(getenv("ARKMPC_NO_POOL") && getenv("ARKMPC_NO_POOL")[0] == '1');
+    return on;
+}
+size_t pool_cap() {
+    static const size_t cap = getenv("ARKMPC_POOL_MAX_MB") ? (size_t)atoll(getenv("ARKMPC_POOL_MAX_MB")) << 20 : (size_t)16 << 30;
+    return cap;
+}
+size_t pool_class(size_t bytes) {
+    if (bytes < 256) bytes = 256;
+    if (bytes >= ((size_t)1 << 20)) return (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+void pool_release_all(DevicePool& p) {   // caller holds p.mu
+    for (auto& kv : p.free_) for (void* q : kv.second) (void)hipFree(q);
+    p.free_.clear();
+    p.cached = 0;
+}
+}  // namespace
+
 extern "C" {
 
 const char* arkmpc_version(void) { return "arkmpc-hip 0.1 (gfx950)"; }
@@ -426,12 +479,18 @@ int arkmpc_ctx_create(int field_id, int device, arkmpc_ctx** out_ctx) {
         delete c;
         return ARKMPC_ERR_HIP;
     }
+    if (device < 16) { std::lock_guard<std::mutex> lk(g_pool[device].mu); g_pool[device].refs++; }
     *out_ctx = c;
     return ARKMPC_OK;
 }
 
 int arkmpc_ctx_destroy(arkmpc_ctx* ctx) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (ctx->device < 16) {          // the last context of a device returns the cached blocks
+        DevicePool& p = g_pool[ctx->device];
+        std::lock_guard<std::mutex> lk(p.mu);
+        if (--p.refs == 0) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); pool_release_all(p); }
+    }
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
@@ -493,11 +552,50 @@ const char* arkmpc_last_error(arkmpc_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
     ENTER(ctx);
     if (!out_dptr) return ark_bad(ctx, "null out pointer");
-    ARK_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 16));
+    if (!pool_enabled() || ctx->device >= 16) {
+        ARK_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 16));
+        return ARKMPC_OK;
+    }
+    DevicePool& p = g_pool[ctx->device];
+    const size_t cls = pool_class(bytes);
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.free_.find(cls);
+    if (it != p.free_.end() && !it->second.empty()) {
+        *out_dptr = it->second.back();
+        it->second.pop_back();
+        p.cached -= cls;
+    } else {
+        hipError_t e = hipMalloc(out_dptr, cls);
+        if (e != hipSuccess && p.cached) {       // out of memory with blocks cached: give them back and retry
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+            pool_release_all(p);
+            e = hipMalloc(out_dptr, cls);
+        }
+        if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    }
+    p.live_[*out_dptr] = cls;
     return ARKMPC_OK;
 }
 int arkmpc_free(arkmpc_ctx* ctx, void* dptr) {
     ENTER(ctx);
+    if (!dptr) return ARKMPC_OK;
+    if (pool_enabled() && ctx->device < 16) {
+        DevicePool& p = g_pool[ctx->device];
+        std::unique_lock<std::mutex> lk(p.mu);
+        auto it = p.live_.find(dptr);
+        if (it != p.live_.end()) {
+            const size_t cls = it->second;
+            p.live_.erase(it);
+            lk.unlock();
+            ARK_HIP(ctx, hipDeviceSynchronize());          // every stream that may still touch the block
+            lk.lock();
+            if (p.cached + cls <= pool_cap()) { p.free_[cls].push_back(dptr); p.cached += cls; return ARKMPC_OK; }
+            lk.unlock();
+            ARK_HIP(ctx, hipFree(dptr));
+            return ARKMPC_OK;
+        }
+    }
     ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ARK_HIP(ctx, hipFree(dptr));
     return ARKMPC_OK;
@@ -635,6 +733,19 @@ int arkmpc_share_join(arkmpc_ctx* ctx, size_t n, const uint64_t* share_col, cons
     int is = st.declare_in(share_col, n * 32), im = st.declare_in(mac_col, n * 32), io = st.declare_out(out_aos, n * 64);
     if (st.commit()) return st.rc;
     if (n) hipLaunchKernelGGL(k_share_join, dim3(blocks_for(n, TPB)), dim3(TPB), 0, ctx->stream, n, st.in<u64>(is), st.in<u64>(im), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_fill(arkmpc_ctx* ctx, size_t n, size_t words, const uint64_t* record, uint64_t* out) {
+    ENTER(ctx);
+    if (!record || words == 0 || words > 12 || (words & 1)) return ark_bad(ctx, "fill: record of 2, 4, ..., 12 u64 words");
+    Stage st(ctx);
+    int io = st.declare_out(out, n * words * 8);
+    if (st.commit()) return st.rc;
+    FillRecord rec;
+    memset(&rec, 0, sizeof(rec));
+    memcpy(&rec, record, words * 8);
+    const u32 w = (u32)(words / 2);
+    if (n) hipLaunchKernelGGL(k_fill_records, dim3(blocks_for(n * w, TPB)), dim3(TPB), 0, ctx->stream, n, w, rec, st.out<uint4>(io));
     return st.finish();
 }
 int arkmpc_share_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out) {

@@ -230,6 +230,9 @@ class Engine:
     def scalarshare_mul_point(self, n, ss, pts, out): self.call("scalarshare_mul_point", ("size", n), ss, pts, out)
     def pointshare_extract(self, n, shares, out): self.call("pointshare_extract", ("size", n), shares, out)
     def point_mac_check_shares(self, n, key, opened, shares, out): self.call("point_mac_check_shares", ("size", n), ("key", key), opened, shares, out)
+    def fill(self, n, record, out):
+        rec = np.ascontiguousarray(record, dtype=np.uint64)
+        self._ck(self.lib.arkmpc_fill(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(rec.size), ctypes.c_void_p(rec.ctypes.data), _ptr(out)))
     def g1_from_bytes(self, n, data, out, out_ok): self.call("g1_from_bytes", ("size", n), data, out, out_ok)
     def g1_sum(self, n, pts, out): self.call("g1_sum", ("size", n), pts, out)
     def pointshare_sum(self, n, shares, out): self.call("pointshare_sum", ("size", n), shares, out)

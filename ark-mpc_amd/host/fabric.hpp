@@ -110,6 +110,7 @@ class DeviceBuf {
     DeviceBuf(const DeviceBuf&) = delete;
     uint64_t* ptr() const { return p_; }
     size_t words() const { return words_; }
+    void set_words(size_t w) { words_ = w; }          // logical length of a buffer allocated with slack
     void upload(const void* host, size_t bytes) { if (bytes) check(e_->dev(), arkmpc_memcpy_h2d(e_->dev(), p_, host, bytes), "h2d"); }
     void download(void* host, size_t bytes) const {
         check(e_->dev(), arkmpc_sync(e_->dev()), "sync");
@@ -131,6 +132,9 @@ struct NetworkOutbound {
     // wire mode (MpcFabric::set_wire_frames): the message as QuicTwoPartyNet would put it on the stream -- u64 LE length +
     // serde_json text (network/quic.rs:303-306), produced and parsed by the engine's codec (csrc/arkmpc_wire.hip)
     std::vector<uint8_t> frame;
+    // device mode (LinkMode::Device): the batch stays in HBM and the message carries its buffer -- the in-memory move of
+    // network/mock.rs:63-88 for a GPU-resident value (both parties of the mock run in one process on one GPU)
+    std::shared_ptr<DeviceBuf> dev;
 };
 class MpcNetwork {
   public:
@@ -185,6 +189,10 @@ class PreprocessingPhase {
     virtual void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) = 0;
     virtual std::vector<ScalarShare> next_shared_value_batch(size_t n) = 0;                       // offline_prep.rs:45-50
     virtual void next_shared_inverse_pair_batch(size_t n, std::vector<ScalarShare>& l, std::vector<ScalarShare>& r) = 0;   // :54-60
+    // Optional: a source whose batches are n copies of one value (the dummy source below) may describe them by that value;
+    // the fabric then fills the batch on the GPU (arkmpc_fill) instead of building and uploading n-element host vectors.
+    virtual bool constant_triplet(ScalarShare&, ScalarShare&, ScalarShare&) { return false; }
+    virtual bool constant_input_masks(Scalar& /*local value*/, ScalarShare& /*local share*/, ScalarShare& /*counterparty share*/) { return false; }
 };
 // offline_prep.rs:88-170: a = 2, b = 3, c = 6 statically split; MAC key share = party id
 class PartyIDBeaverSource : public PreprocessingPhase {
@@ -208,6 +216,18 @@ class PartyIDBeaverSource : public PreprocessingPhase {
         else { ta.share = s_[1]; tb.share = s_[0]; tc.share = s_[4]; }
         ta.mac = s_[k * 2]; tb.mac = s_[k * 3]; tc.mac = s_[k * 6];
         a.assign(n, ta); b.assign(n, tb); c.assign(n, tc);
+    }
+
+    bool constant_triplet(ScalarShare& a, ScalarShare& b, ScalarShare& c) override {
+        std::vector<ScalarShare> va, vb, vc;
+        next_triplet_batch(1, va, vb, vc);
+        a = va[0]; b = vb[0]; c = vc[0];
+        return true;
+    }
+    bool constant_input_masks(Scalar& v, ScalarShare& local, ScalarShare& counterparty) override {
+        auto lm = next_local_input_mask_batch(1);
+        v = lm.first[0]; local = lm.second[0]; counterparty = next_counterparty_input_mask_batch(1)[0];
+        return true;
     }
 
     std::vector<ScalarShare> next_shared_value_batch(size_t n) override {                       // :166-168: (party_id, party_id)
@@ -258,25 +278,39 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // Wire mode: every batch crosses the mock link as the serde_json frame the QUIC transport would carry, so the
     // protocol-level scenarios exercise the GPU encoder / validating decoder end to end (env ARKMPC_MOCK_WIRE=1 in
     // execute_mock_mpc).  Off: payloads are handed over as host vectors (network/mock.rs).
-    void set_wire_frames(bool on) { wire_ = on; }
+    enum class LinkMode { Host, Device, Wire };
+    void set_link_mode(LinkMode m) { link_ = m; wire_ = (m == LinkMode::Wire); }
+    LinkMode link_mode() const { return link_; }
+    void set_wire_frames(bool on) { set_link_mode(on ? LinkMode::Wire : LinkMode::Host); }
     bool wire_frames() const { return wire_; }
     static std::atomic<uint64_t>& frames_sent() { static std::atomic<uint64_t> c{0}; return c; }   // process-wide, for the tests
     // send / receive / exchange of a scalar batch (fabric.rs:720-814): party 0 sends first then receives
     void send_values(const ScalarBatch& v) {
-        if (!wire_) { net_->send(NetworkOutbound{next_id_++, v.to_host(), {}}); return; }
+        if (link_ == LinkMode::Device) { send_device(v.buf, 4 * v.n); return; }
+        if (!wire_) { net_->send(NetworkOutbound{next_id_++, v.to_host(), {}, {}}); return; }
         const uint64_t id = next_id_++;
         size_t cap = 0, len = 0;
         arkmpc_wire_frame_bound(v.n, &cap);
         DeviceBuf fr(eng_, cap / 8 + 1);
         check(ctx(), arkmpc_wire_encode_scalar_batch(ctx(), id, v.n, v.buf.ptr(), reinterpret_cast<uint8_t*>(fr.ptr()), cap, &len), "wire_encode_scalar_batch");
-        NetworkOutbound m{id, {}, std::vector<uint8_t>(len)};
+        NetworkOutbound m{id, {}, std::vector<uint8_t>(len), {}};
         fr.download(m.frame.data(), len);
         frames_sent()++;
         net_->send(std::move(m));
     }
+    // device handoff: a private copy of the words (the sender keeps using its buffer), ordered before the receiver's
+    // stream by a sync of the sender's stream
+    void send_device(const DeviceBuf& src, size_t words) {
+        auto copy = std::make_shared<DeviceBuf>(eng_, words ? words : 1);
+        copy->set_words(words);
+        if (words) check(ctx(), arkmpc_memcpy_d2d(ctx(), copy->ptr(), src.ptr(), words * 8), "d2d");
+        check(ctx(), arkmpc_sync(ctx()), "sync");
+        net_->send(NetworkOutbound{next_id_++, {}, {}, std::move(copy)});
+    }
     ScalarBatch receive_values() {
         NetworkOutbound m = net_->receive();
         const uint64_t id = next_id_++;
+        if (link_ == LinkMode::Device) { ScalarBatch b; b.n = m.dev->words() / 4; b.buf = std::move(*m.dev); return b; }
         if (!wire_) return allocate_scalars(m.payload);
         // the element count is only known after parsing: a scalar's text is at least 66 bytes ("[0,0,...,0]," )
         const size_t max_n = m.frame.size() / 66 + 1;
@@ -304,12 +338,13 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // receiver decompresses with validation (CurvePoint::from_bytes, :57-63).
     template <class PB> void send_points(const PB& mine) {
         const size_t n = mine.n;
+        if (link_ == LinkMode::Device) { send_device(mine.buf, 12 * n); return; }
         const uint64_t id = next_id_++;
         if (!wire_) {
             std::vector<uint64_t> h = mine.to_host();
             std::vector<Scalar> pay(3 * n);
             std::memcpy(pay.data(), h.data(), h.size() * 8);
-            net_->send(NetworkOutbound{id, std::move(pay), {}});
+            net_->send(NetworkOutbound{id, std::move(pay), {}, {}});
             return;
         }
         DeviceBuf bytes(eng_, 4 * (n ? n : 1));
@@ -319,7 +354,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         DeviceBuf fr(eng_, cap / 8 + 1);
         check(ctx(), arkmpc_wire_encode_bytes32(ctx(), ARKMPC_WIRE_POINT_BATCH, id, n, reinterpret_cast<const uint8_t*>(bytes.ptr()),
                                                 reinterpret_cast<uint8_t*>(fr.ptr()), cap, &len), "wire_encode_bytes32");
-        NetworkOutbound m{id, {}, std::vector<uint8_t>(len)};
+        NetworkOutbound m{id, {}, std::vector<uint8_t>(len), {}};
         fr.download(m.frame.data(), len);
         frames_sent()++;
         net_->send(std::move(m));
@@ -327,6 +362,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     template <class PB> PB receive_points(size_t n) {
         NetworkOutbound m = net_->receive();
         const uint64_t id = next_id_++;
+        if (link_ == LinkMode::Device) { PB r; r.n = n; r.buf = std::move(*m.dev); return r; }
         PB r; r.n = n; r.buf = DeviceBuf(eng_, 12 * (n ? n : 1));
         if (!wire_) { r.buf.upload(m.payload.data(), n * 96); return r; }
         DeviceBuf fr(eng_, m.frame.size() / 8 + 2);
@@ -354,6 +390,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // fabric.rs:578-600
     AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
     AuthenticatedScalarBatch allocate_scalar_shares(const std::vector<ScalarShare>& s);
+    AuthenticatedScalarBatch fill_scalar_shares(const ScalarShare& s, size_t n);     // vec![s; n] on the GPU
     // fabric.rs:622-649: share public-format points (12 x u64 Jacobian each) held by `sender`
     template <class APB> APB batch_share_point(const std::vector<uint64_t>& points, size_t n, PartyId sender);
 
@@ -364,6 +401,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     std::unique_ptr<PreprocessingPhase> prep_;
     Scalar mac_key_;
     bool wire_ = false;
+    LinkMode link_ = LinkMode::Host;
     uint64_t next_id_ = 6;   // N_CONSTANT_RESULTS (fabric.rs:55-70)
 };
 
@@ -682,7 +720,18 @@ inline AuthenticatedScalarBatch MpcFabric::allocate_scalar_shares(const std::vec
     r.buf.upload(s.data(), s.size() * 64);
     return r;
 }
+inline AuthenticatedScalarBatch MpcFabric::fill_scalar_shares(const ScalarShare& s, size_t n) {
+    auto r = AuthenticatedScalarBatch::alloc(shared_from_this(), n);
+    check(ctx(), arkmpc_fill(ctx(), n, 8, s.share.l, r.buf.ptr()), "fill");
+    return r;
+}
 inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c) {
+    ScalarShare ca, cb, cc;
+    if (prep_->constant_triplet(ca, cb, cc)) {
+        next_id_ += 3 * n;
+        a = fill_scalar_shares(ca, n); b = fill_scalar_shares(cb, n); c = fill_scalar_shares(cc, n);
+        return;
+    }
     std::vector<ScalarShare> ha, hb, hc;
     prep_->next_triplet_batch(n, ha, hb, hc);
     if (ha.size() != n || hb.size() != n || hc.size() != n) throw std::runtime_error("preprocessing exhausted");   // structs.rs:189 asserts
@@ -704,6 +753,20 @@ inline AuthenticatedScalarBatch MpcFabric::random_shared_scalars(size_t n) {
 inline AuthenticatedScalarBatch MpcFabric::batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender) {
     ScalarBatch masked;
     std::vector<ScalarShare> mask_shares;
+    Scalar cv; ScalarShare cl, cc;
+    if (prep_->constant_input_masks(cv, cl, cc)) {            // masks described by one value: filled on the GPU
+        if (party_ == sender) {
+            ScalarBatch vals = allocate_scalars(vals_mont), masks;
+            masks.n = n; masks.buf = DeviceBuf(eng_, 4 * (n ? n : 1));
+            check(ctx(), arkmpc_fill(ctx(), n, 4, cv.l, masks.buf.ptr()), "fill");
+            masked.n = n; masked.buf = DeviceBuf(eng_, 4 * (n ? n : 1));
+            if (n) check(ctx(), arkmpc_scalar_sub(ctx(), n, vals.buf.ptr(), masks.buf.ptr(), masked.buf.ptr()), "scalar_sub");
+            send_values(masked);
+        } else {
+            masked = receive_values();
+        }
+        return AuthenticatedScalarBatch::batch_add_public(fill_scalar_shares(party_ == sender ? cl : cc, n), masked);
+    }
     if (party_ == sender) {
         auto lm = prep_->next_local_input_mask_batch(n);
         ScalarBatch vals = allocate_scalars(vals_mont), masks = allocate_scalars(lm.first);
@@ -761,11 +824,20 @@ std::pair<T, T> execute_mock_mpc(int field_id, int device,
             MpcNetwork* raw = net.get();
             auto fab = std::make_shared<MpcFabric>(p, eng, std::move(net), make_prep(p, *eng));
             if (const char* w = std::getenv("ARKMPC_MOCK_WIRE")) fab->set_wire_frames(w[0] == '1');
+            if (const char* l = std::getenv("ARKMPC_MOCK_LINK")) {            // host | device | wire
+                const std::string v = l;
+                fab->set_link_mode(v == "device" ? MpcFabric::LinkMode::Device : (v == "wire" ? MpcFabric::LinkMode::Wire : MpcFabric::LinkMode::Host));
+            }
             try { out[p] = f(fab); } catch (...) { raw->close(); throw; }
         } catch (...) { err[p] = std::current_exception(); }
     };
     std::thread t0(run, PARTY0), t1(run, PARTY1);
     t0.join(); t1.join();
+    // report the root cause: a party that failed closes the link, which surfaces as RecvError on the other side
+    auto is_recv_error = [](const std::exception_ptr& e) {
+        try { std::rethrow_exception(e); } catch (const std::exception& x) { return std::string(x.what()).find("RecvError") != std::string::npos; } catch (...) { return false; }
+    };
+    for (auto& e : err) if (e && !is_recv_error(e)) std::rethrow_exception(e);
     for (auto& e : err) if (e) std::rethrow_exception(e);
     return {std::move(out[0]), std::move(out[1])};
 }

@@ -113,6 +113,9 @@ int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const 
  * Import once, run the _v entry points on the columns (no dead MAC bytes in K1, cacheable re-reads), export at the end. */
 int arkmpc_share_split(arkmpc_ctx* ctx, size_t n, const uint64_t* aos, uint64_t* out_share_col, uint64_t* out_mac_col);
 int arkmpc_share_join(arkmpc_ctx* ctx, size_t n, const uint64_t* share_col, const uint64_t* mac_col, uint64_t* out_aos);
+/* n copies of one record of `words` u64 (2, 4, ..., 12; `record` is ALWAYS a host pointer): `vec![value; n]` for the
+ * constant batches of a preprocessing source (PartyIDBeaverSource, offline_prep.rs:103-170) and fabric constants. */
+int arkmpc_fill(arkmpc_ctx* ctx, size_t n, size_t words, const uint64_t* record, uint64_t* out);
 
 /* ---- Beaver multiplication, authenticated_scalar.rs:848-879 -------------------------------- */
 /* K1  batch_sub(a,&beaver_a), batch_sub(b,&beaver_b) + the `.share()` projection of open_batch's

@@ -343,3 +343,16 @@ def test_thread_safety_same_and_separate_contexts(pkg, oracle):
     assert errors == []
     for e in [shared] + own:
         e.close()
+
+
+def test_fill_records(pkg):
+    """arkmpc_fill: n copies of a 4 / 8 / 12-word record (vec![value; n] of a preprocessing source)."""
+    eng = pkg.Engine(0, device=0, host_buffers=True)
+    for words in (2, 4, 8, 12):
+        rec = np.arange(1, words + 1, dtype=np.uint64) * np.uint64(0x0123456789ABCDEF)
+        for n in (0, 1, 5, 1000):
+            out = np.zeros(max(n, 1) * words, dtype=np.uint64)
+            eng.fill(n, rec, out)
+            assert np.array_equal(out[:n * words], np.tile(rec, n))
+    with pytest.raises(pkg.ArkMpcError):
+        eng.fill(4, np.zeros(3, dtype=np.uint64), np.zeros(12, dtype=np.uint64))

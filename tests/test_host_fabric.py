@@ -16,13 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "ark-mpc_amd", "lib", "arkmpc_mock_mpc")
 
 
-@pytest.fixture(params=["mock", "wire"], autouse=True)
+@pytest.fixture(params=["host", "device", "wire"], autouse=True)
 def link_mode(request):
-    """Every scenario runs twice: payloads handed over as host vectors (network/mock.rs), and as the serde_json frames
-    QuicTwoPartyNet carries (network/quic.rs:303-306), produced and parsed by the engine's wire codec on the GPU."""
-    os.environ["ARKMPC_MOCK_WIRE"] = "1" if request.param == "wire" else "0"
+    """Every scenario runs three times: payloads handed over as host vectors (network/mock.rs), as device buffers (the same
+    in-memory move for HBM-resident batches), and as the serde_json frames QuicTwoPartyNet carries
+    (network/quic.rs:303-306), produced and parsed by the engine's wire codec on the GPU."""
+    os.environ["ARKMPC_MOCK_LINK"] = request.param
     yield request.param
-    os.environ.pop("ARKMPC_MOCK_WIRE", None)
+    os.environ.pop("ARKMPC_MOCK_LINK", None)
 
 
 def run(tmp_path, scenario, fid, a, b, *flags):
@@ -32,7 +33,7 @@ def run(tmp_path, scenario, fid, a, b, *flags):
     r = subprocess.run([EXE, scenario, str(fid), str(n), str(inp), str(outp), *flags], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     frames = int(r.stdout.split("frames")[1].split()[0])
-    assert (frames > 0) == (os.environ.get("ARKMPC_MOCK_WIRE") == "1"), r.stdout      # wire mode really framed the traffic
+    assert (frames > 0) == (os.environ.get("ARKMPC_MOCK_LINK") == "wire"), r.stdout    # wire mode really framed the traffic
     raw = outp.read_bytes()
     res, off = [], 0
     for _ in range(2):
