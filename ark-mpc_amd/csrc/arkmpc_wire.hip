@@ -347,8 +347,13 @@ static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, 
     if (!expect("{\"result_id\":")) return ark_bad(ctx, "malformed message: result_id");
     u64 rid = 0;
     size_t nd = 0;
-    while (p < hl && head[p] >= '0' && head[p] <= '9' && nd < 20) { rid = rid * 10 + (u64)(head[p] - '0'); ++p; ++nd; }
-    if (nd == 0 || (nd > 1 && head[p - nd] == '0')) return ark_bad(ctx, "malformed message: result_id");
+    bool rid_overflow = false;
+    while (p < hl && head[p] >= '0' && head[p] <= '9' && nd < 21) {
+        const u64 dgt = (u64)(head[p] - '0');
+        if (rid > (~(u64)0 - dgt) / 10) rid_overflow = true;          // usize on the reference side: must fit 64 bits
+        rid = rid * 10 + dgt; ++p; ++nd;
+    }
+    if (nd == 0 || nd > 20 || rid_overflow || (nd > 1 && head[p - nd] == '0')) return ark_bad(ctx, "malformed message: result_id");
     if (!expect(",\"payload\":{\"")) return ark_bad(ctx, "malformed message: payload");
     int kind = -1;
     if (expect("ScalarBatch\":[")) kind = ARKMPC_WIRE_SCALAR_BATCH;

@@ -140,3 +140,59 @@ def test_large_round_trip_device_buffers(pkg):
     back = torch.empty_like(x)
     cnt, rid = e.wire_decode_scalar_batch(frame, ln, n, back)
     assert (cnt, rid) == (n, 99) and torch.equal(back, x)
+
+
+import re
+
+_NUM = r"(?:0|[1-9][0-9]?|1[0-9][0-9]|2[0-4][0-9]|25[0-5])"
+_ELEM = r"\[" + _NUM + r"(?:," + _NUM + r"){31}\]"
+_STRICT = re.compile(r'\{"result_id":(0|[1-9][0-9]{0,19}),"payload":\{"ScalarBatch":\[(?:' + _ELEM + r"(?:," + _ELEM + r")*)?\]\}\}\Z")
+
+
+def strict_accepts(fid, body):
+    """The compact serde_json text of a ScalarBatch message and nothing else; scalars canonical; id fits a u64."""
+    m = _STRICT.match(body.decode("latin-1"))
+    if not m or int(m.group(1)) >= 1 << 64:
+        return False
+    import json
+    return all(int.from_bytes(bytes(e), "little") < pyref.P[fid] for e in json.loads(body)["payload"]["ScalarBatch"])
+
+
+@pytest.mark.gpu
+def test_decoder_agrees_with_strict_grammar_on_mutated_frames(hip, pkg):
+    """400 random byte edits of valid frames (replace / insert / delete, biased to structural characters): the GPU
+    decoder accepts exactly the frames a strict regular-expression model of the compact grammar accepts, and when it
+    accepts, the values are the ones Python's json reads."""
+    import json
+    import random
+    fid = 0
+    rng = random.Random(20260928)
+    eng = hip.eng(fid)
+    out = np.zeros(4 * 64, dtype=np.uint64)
+    accepted = 0
+    alphabet = b'[],0123456789{}":- eE.'
+    for trial in range(400):
+        n = rng.choice([0, 1, 2, 3, 9])
+        vals = [rng.choice([0, 1, 255, 256, pyref.P[fid] - 1, rng.randrange(pyref.P[fid])]) for _ in range(n)]
+        body = bytearray(pyref.wire_frame("ScalarBatch", rng.choice([0, 7, 10 ** 19, 2 ** 64 - 1]), pyref.wire_scalar_records(fid, vals))[8:])
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            pos = rng.randrange(len(body))
+            kind = rng.randrange(3)
+            if kind == 0: body[pos] = rng.choice(alphabet)
+            elif kind == 1: body.insert(pos, rng.choice(alphabet))
+            else: del body[pos]
+        frame = struct.pack("<Q", len(body)) + bytes(body)
+        arr = np.frombuffer(frame, dtype=np.uint8).copy()
+        want = strict_accepts(fid, bytes(body))
+        try:
+            cnt, rid = eng.wire_decode_scalar_batch(arr, len(arr), 64, out)
+            got = True
+        except pkg.ArkMpcError:
+            got = False
+        assert got == want, (trial, bytes(body)[:120])
+        if got:
+            accepted += 1
+            msg = json.loads(bytes(body))
+            assert rid == msg["result_id"] and cnt == len(msg["payload"]["ScalarBatch"])
+            assert np.array_equal(out[:4 * cnt], mont_array(fid, [int.from_bytes(bytes(e), "little") for e in msg["payload"]["ScalarBatch"]]))
+    assert 40 < accepted < 360          # the mutation mix exercises both outcomes
