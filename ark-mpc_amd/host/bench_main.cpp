@@ -5,6 +5,7 @@
 //   batch_ops        online-phase/benches/batch_ops.rs:20-39    share x, share y, batch_mul, open_authenticated_batch
 //   mul_throughput   benches/circuit_mul_throughput.rs:24-36    n SEQUENTIAL squarings res = res * res, then open
 //   msm_throughput   benches/circuit_msm_throughput.rs:24-38    AuthenticatedPointResult::msm of n (one, identity) pairs, open
+//   point_batch_mul  BASELINE config 4 secondary op: AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714)
 // usage: arkmpc_host_bench <bench> <n> [iters]      -> one JSON line
 #include <chrono>
 #include <cstdio>
@@ -61,6 +62,19 @@ int main(int argc, char** argv) {
                     auto res = AuthenticatedPointBatch::msm(scalars, points);
                     PointBatch o = res.open_batch();
                     (void)o.to_host();
+                    const double s = std::chrono::duration<double>(Clock::now() - t1).count();
+                    if (it) best = s < best ? s : best;
+                    continue;
+                } else if (bench == "point_batch_mul") {
+                    // BASELINE config 4, secondary op: AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714),
+                    // [x * yG] by a Beaver triple: 10 scalar-muls + 8 additions per element and party; timed without the sharing
+                    auto x = fabric->batch_share_scalar(a_m, n, PARTY0);
+                    auto y = fabric->batch_share_scalar(b_m, n, PARTY1);
+                    auto Y = AuthenticatedPointBatch::batch_mul_generator(y);
+                    check(fabric->ctx(), arkmpc_sync(fabric->ctx()), "sync");
+                    const auto t1 = Clock::now();
+                    auto Z = AuthenticatedPointBatch::batch_mul(x, Y);
+                    check(fabric->ctx(), arkmpc_sync(fabric->ctx()), "sync");
                     const double s = std::chrono::duration<double>(Clock::now() - t1).count();
                     if (it) best = s < best ? s : best;
                     continue;
