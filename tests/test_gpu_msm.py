@@ -133,3 +133,34 @@ def test_msm_task_splitting(hip, oracle, k):
     finally:
         del os.environ["ARKMPC_MSM_K"]; del os.environ["ARKMPC_MSM_C"]
     assert affine_equal(hip, oracle, got, oracle.g1_msm(P, S))
+
+
+def test_msm_random_configurations(hip):
+    """60 random (n, window width, task size, group size, scalar distribution) combinations against the closed form
+    (sum s_i k_i) G: run boundaries at multiples of the task size, empty buckets, single-window widths, skew."""
+    import random
+    rng = random.Random(4242)
+    r = pyref.RORD
+    eng = hip.eng(0)
+    nmax = 1500
+    ks = rand_values(0, nmax, 1001)
+    P_all = device_bases(hip, ks)
+    for trial in range(60):
+        n = rng.choice([1, 2, 3, 17, 255, 256, 257, 511, 1024, rng.randrange(1, nmax)])
+        c = rng.choice([2, 3, 5, 8, 9, 12, 15, 16])
+        K = rng.choice([1, 2, 7, 16, 256])
+        L = rng.choice([1, 2, 4, 8])
+        dist = rng.randrange(4)
+        if dist == 0: ss = [rng.randrange(r) for _ in range(n)]
+        elif dist == 1: ss = [rng.choice([0, 1, 2, r - 1]) for _ in range(n)]
+        elif dist == 2: ss = [rng.randrange(1 << rng.choice([1, 8, 64, 128, 200]))  for _ in range(n)]
+        else:
+            v = rng.randrange(r); ss = [v] * n
+        os.environ["ARKMPC_MSM_C"] = str(c); os.environ["ARKMPC_MSM_K"] = str(K)
+        if (1 << (c - 1)) % L == 0: os.environ["ARKMPC_MSM_L"] = str(L)
+        try:
+            got = msm(hip, np.ascontiguousarray(P_all[:12 * n]), mont_array(0, ss))
+        finally:
+            for k_ in ("ARKMPC_MSM_C", "ARKMPC_MSM_K", "ARKMPC_MSM_L"): os.environ.pop(k_, None)
+        want = pyref.g1_mul(pyref.G, sum(s * k for s, k in zip(ss, ks)) % r)
+        assert affine_ints(hip, got) == want, (trial, n, c, K, L, dist)
