@@ -164,3 +164,16 @@ def test_msm_random_configurations(hip):
             for k_ in ("ARKMPC_MSM_C", "ARKMPC_MSM_K", "ARKMPC_MSM_L"): os.environ.pop(k_, None)
         want = pyref.g1_mul(pyref.G, sum(s * k for s, k in zip(ss, ks)) % r)
         assert affine_ints(hip, got) == want, (trial, n, c, K, L, dist)
+
+
+def test_msm_normalised_bases_fast_path(hip, oracle):
+    """Bases given as (x, y, 1) / identity skip the batch inversion; a mix with one non-normalised point in the wave does not."""
+    n = 300
+    pts, _ = random_points(n, 1100, with_identity=True)
+    ks = rand_values(0, n, 1101)
+    S = mont_array(0, ks)
+    Pn = jac(pts, [1] * n)                                                 # every z is 1 (identity stays (1,1,0))
+    want = oracle.g1_msm(Pn, S)
+    assert affine_equal(hip, oracle, msm(hip, Pn, S), want)
+    zs = [1] * n; zs[137] = 9
+    assert affine_equal(hip, oracle, msm(hip, jac(pts, zs), S), want)
