@@ -20,6 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
+HOST_CPP_SOURCES = ["keccak_avx512.cpp"]
 ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "arkmpc_edwards.hip", "arkmpc_wire.hip", "sha3_host.hip"]
 # every header / include fragment in csrc (a stale .so after editing an .inc is the failure this guards against)
 ENGINE_DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".inc", ".hpp"))) + [os.path.join("..", "..", "include", "arkmpc.h")]
@@ -49,6 +50,12 @@ def build_engine(force=False, verbose=False):
         objs.append(o)
         if force or _newer(o, [s] + deps):
             jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+    for src in HOST_CPP_SOURCES:          # plain host C++ (per-function target attributes; no device pass)
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".cpp", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s]):
+            jobs.append(["g++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             for out in ex.map(_run, jobs):
