@@ -105,6 +105,30 @@ __device__ __noinline__ G1 g1_add(G1 p, G1 q) {
     out = g1_select(pinf, q, out);
     return out;
 }
+// mixed addition madd-2007-bl: Jacobian p + affine (x2, y2), never called with an affine identity
+__device__ __noinline__ G1 g1_madd(G1 p, Fe x2, Fe y2) {
+    const bool pinf = fe_is_zero(p.z);
+    Fe Z1Z1 = FQ_SQR(p.z);
+    Fe U2 = FQ_MUL(x2, Z1Z1);
+    Fe S2 = FQ_MUL(FQ_MUL(y2, p.z), Z1Z1);
+    Fe H = fe_sub<FQ>(U2, p.x);
+    Fe rr = fe_dbl<FQ>(fe_sub<FQ>(S2, p.y));
+    G1 q;
+    q.x = x2; q.y = y2; q.z = fe_one<FQ>();
+    if (!pinf && fe_is_zero(H)) {          // same x: the bucket holds this point already (double) or its negative
+        if (fe_is_zero(rr)) return g1_double(q);
+        return g1_identity();
+    }
+    Fe HH = FQ_SQR(H);
+    Fe I = fe_dbl<FQ>(fe_dbl<FQ>(HH));
+    Fe J = FQ_MUL(H, I);
+    Fe V = FQ_MUL(p.x, I);
+    G1 out;
+    out.x = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(rr), J), fe_dbl<FQ>(V));
+    out.y = fe_sub<FQ>(FQ_MUL(rr, fe_sub<FQ>(V, out.x)), fe_dbl<FQ>(FQ_MUL(p.y, J)));
+    out.z = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(fe_add<FQ>(p.z, H)), Z1Z1), HH);
+    return g1_select(pinf, q, out);
+}
 // window table T[k-1] = k*P for k = 1..15 in the HBM workspace: even entries by doubling (7 Fq-mults) the half entry read
 // back from the table, odd ones by adding P (16): 7 dbl + 7 add instead of 1 dbl + 13 add
 __device__ __forceinline__ void g1_build_table(const G1& p, u64* tab, size_t tid, size_t nthreads) {
@@ -281,6 +305,62 @@ __device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& in
     x = FQ_MUL(a.x, zi2);
     y = FQ_MUL(a.y, FQ_MUL(zi2, zi));
     if (inf) { x = fe_zero<FQ>(); y = fe_zero<FQ>(); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-base multiplication by the generator (CurvePointResult / AuthenticatedPointResult::batch_mul_generator,
+// authenticated_curve.rs:754-780; 4 of the 10 scalar-muls of the Beaver point multiplication :696-708; input sharing of
+// points, fabric.rs:622-649).  The base never changes, so its multiples are tabulated once per device:
+// T[w][d-1] = d * 2^(8w) * G for the 32 byte positions w and d = 1..255, affine, 8160 x 64 B = 510 KiB (L2-resident).
+// [s]G is then 32 table lookups and at most 32 mixed additions -- no doublings: ~350 Fq multiplications instead of
+// ~2200 for the variable-base GLV path.
+// ---------------------------------------------------------------------------------------------
+#define GEN_WINDOWS 32
+#define GEN_ENTRIES 255
+__global__ void k_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(8w) G
+    if (blockIdx.x | threadIdx.x) return;
+    G1 b = g1_generator();
+    for (int w = 0; w < GEN_WINDOWS; ++w) {
+        g1_store(bases + 12 * w, b);
+        for (int k = 0; k < 8; ++k) b = g1_double(b);
+    }
+}
+__global__ void __launch_bounds__(TPB_EC) k_gen_table_fill(const u64* bases, u64* table) {     // thread (w, d): d * B_w, normalised
+    const u32 t = blockIdx.x * TPB_EC + threadIdx.x;
+    if (t >= GEN_WINDOWS * GEN_ENTRIES) return;
+    const u32 w = t / GEN_ENTRIES, d = t % GEN_ENTRIES + 1;
+    const G1 b = g1_load(bases + 12 * w);
+    G1 acc = g1_identity();
+    for (int bit = 7; bit >= 0; --bit) {
+        acc = g1_double(acc);
+        if ((d >> bit) & 1u) acc = g1_add(acc, b);
+    }
+    Fe x, y; bool inf;
+    g1_to_affine(acc, x, y, inf);                        // never the identity: d * 2^(8w) < r
+    fe_store(table + 8 * (size_t)t, x);
+    fe_store(table + 8 * (size_t)t + 4, y);
+}
+__global__ void __launch_bounds__(TPB_EC) k_g1_generator_mul_fixed(size_t n, const u64* scalars, u32 s_stride, u32 s_div, const u64* table, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    const Fe s = fe_to_canonical<FR>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
+    G1 acc = g1_identity();
+#pragma unroll 1
+    for (int limb = 0; limb < 8; ++limb) {
+        u32 wv = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv = (limb == k) ? s.v[k] : wv;
+#pragma unroll 1
+        for (int by = 0; by < 4; ++by) {
+            const u32 d = (wv >> (8 * by)) & 255u;
+            if (__any(d != 0)) {
+                const u64* q = table + 8 * ((size_t)(4 * limb + by) * GEN_ENTRIES + (d ? d - 1 : 0));
+                const G1 sum = g1_madd(acc, fe_load(q), fe_load(q + 4));
+                acc = g1_select(d != 0, sum, acc);
+            }
+        }
+    }
+    g1_store(out + 12 * i, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -530,6 +610,27 @@ __global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* p
 
 static inline bool party_ok(int p) { return p == 0 || p == 1; }
 
+// generator table, one per device, built on first use (a few milliseconds) and kept for the life of the process
+static std::mutex g_gen_mu;
+static u64* g_gen_table[16] = {nullptr};
+static int gen_table(arkmpc_ctx* ctx, const u64** out) {
+    const int dev = ctx->device;
+    if (dev < 0 || dev >= 16) return ark_bad(ctx, "device index");
+    std::lock_guard<std::mutex> lk(g_gen_mu);
+    if (!g_gen_table[dev]) {
+        u64 *bases = nullptr, *table = nullptr;
+        ARK_HIP(ctx, hipMalloc((void**)&bases, GEN_WINDOWS * 96));
+        ARK_HIP(ctx, hipMalloc((void**)&table, (size_t)GEN_WINDOWS * GEN_ENTRIES * 64));
+        hipLaunchKernelGGL(k_gen_table_bases, dim3(1), dim3(64), 0, ctx->stream, bases);
+        hipLaunchKernelGGL(k_gen_table_fill, dim3(blocks_for(GEN_WINDOWS * GEN_ENTRIES, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, bases, table);
+        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ARK_HIP(ctx, hipFree(bases));
+        g_gen_table[dev] = table;
+    }
+    *out = g_gen_table[dev];
+    return ARKMPC_OK;
+}
+
 extern "C" {
 
 static int g1_addsub(arkmpc_ctx* ctx, bool sub, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t mult) {
@@ -571,8 +672,17 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
     int is = st.declare_in(scalars, scalar_bytes), io = st.declare_out(out, m * 96);
     const size_t CH = (size_t)1 << 20;
     const size_t chunk = m < CH ? m : CH;
-    int iw = st.declare_scratch(chunk * 15 * 96);
+    static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
+    int iw = (points || !fixed_base) ? st.declare_scratch(chunk * 15 * 96) : -1;     // window tables of the variable-base path
     if (st.commit()) return st.rc;
+    if (m && !points && fixed_base) {          // multiplication by the generator: tabulated multiples, no doublings
+        const u64* table = nullptr;
+        int rc = gen_table(ctx, &table);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_g1_generator_mul_fixed, dim3(blocks_for(m, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, m, st.in<u64>(is), s_stride, s_div, table,
+                           st.out<u64>(io));
+        return st.finish();
+    }
     if (m) {
         // chunk boundaries must respect the point / scalar divisors (1 or 2)
         for (size_t lo = 0; lo < m; lo += chunk) {
