@@ -393,22 +393,23 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* p
     g1_store(out + 12 * i, glv ? g1_scalar_mul_glv(p, s, table_ws, i, n) : g1_scalar_mul_w4(p, s, table_ws, i, n));
 }
 // PointShare::add_public (curve/share.rs:57-60): share += rhs iff PARTY0 ; mac += mac_key * rhs
-__global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public(size_t n, int party, Fe key, const u64* shares, const u64* pub, u64* out) {
+// (mac_key * rhs through the GLV window path: ~2.2 k instead of ~3.8 k Fq multiplications for plain double-and-add)
+__global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public(size_t n, int party, Fe key, const u64* shares, const u64* pub, u64* out, u64* table_ws) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     G1 rhs = g1_load(pub + 12 * i);
     G1 sh = g1_load(shares + 24 * i), mac = g1_load(shares + 24 * i + 12);
     if (party == 0) sh = g1_add(sh, rhs);
-    mac = g1_add(mac, g1_scalar_mul(rhs, key));
+    mac = g1_add(mac, g1_scalar_mul_glv(rhs, key, table_ws, i, n));
     g1_store(out + 24 * i, sh);
     g1_store(out + 24 * i + 12, mac);
 }
 // value * mac_key - share.mac()  (authenticated_curve.rs:215-220)
-__global__ void __launch_bounds__(TPB_EC) k_point_mac_check(size_t n, Fe key, const u64* opened, const u64* shares, u64* out) {
+__global__ void __launch_bounds__(TPB_EC) k_point_mac_check(size_t n, Fe key, const u64* opened, const u64* shares, u64* out, u64* table_ws) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     G1 v = g1_load(opened + 12 * i), mac = g1_load(shares + 24 * i + 12);
-    g1_store(out + 12 * i, g1_add(g1_scalar_mul(v, key), g1_neg(mac)));
+    g1_store(out + 12 * i, g1_add(g1_scalar_mul_glv(v, key, table_ws, i, n), g1_neg(mac)));
 }
 // my + peer == identity  (authenticated_curve.rs:127-131), per element
 __global__ void __launch_bounds__(TPB_EC) k_point_mac_verify(size_t n, const u64* mine, const u64* peer, unsigned char* ok) {
@@ -609,6 +610,7 @@ __global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* p
     if ((ctx)->field_id != ARKMPC_BN254_FR) { (ctx)->err = "point ops need a BN254_FR context"; return ARKMPC_ERR_UNSUPPORTED; }
 
 static inline bool party_ok(int p) { return p == 0 || p == 1; }
+static const size_t EC_CHUNK = (size_t)1 << 20;     // scalar-muls per launch: bounds the window-table workspace at 1.4 GiB
 
 // generator table, one per device, built on first use (a few milliseconds) and kept for the life of the process
 static std::mutex g_gen_mu;
@@ -725,9 +727,14 @@ int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const 
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int is = st.declare_in(shares, n * 192), ip = st.declare_in(pub_points, n * 96), io = st.declare_out(out, n * 192);
+    const size_t chunk = n < EC_CHUNK ? n : EC_CHUNK;
+    int iw = st.declare_scratch(chunk * 15 * 96);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_pointshare_add_public, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, party_id,
-                              fe_from_host(mac_key), st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
+    for (size_t lo = 0; lo < n; lo += chunk) {
+        const size_t cnt = (n - lo < chunk) ? (n - lo) : chunk;
+        hipLaunchKernelGGL(k_pointshare_add_public, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, party_id, fe_from_host(mac_key),
+                           st.in<u64>(is) + 24 * lo, st.in<u64>(ip) + 12 * lo, st.out<u64>(io) + 24 * lo, st.scratch<u64>(iw));
+    }
     return st.finish();
 }
 int arkmpc_pointshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points) {
@@ -744,9 +751,14 @@ int arkmpc_point_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int iv = st.declare_in(opened_points, n * 96), is = st.declare_in(shares, n * 192), io = st.declare_out(out_chk_points, n * 96);
+    const size_t chunk = n < EC_CHUNK ? n : EC_CHUNK;
+    int iw = st.declare_scratch(chunk * 15 * 96);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_point_mac_check, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, fe_from_host(mac_key),
-                              st.in<u64>(iv), st.in<u64>(is), st.out<u64>(io));
+    for (size_t lo = 0; lo < n; lo += chunk) {
+        const size_t cnt = (n - lo < chunk) ? (n - lo) : chunk;
+        hipLaunchKernelGGL(k_point_mac_check, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, fe_from_host(mac_key),
+                           st.in<u64>(iv) + 12 * lo, st.in<u64>(is) + 24 * lo, st.out<u64>(io) + 12 * lo, st.scratch<u64>(iw));
+    }
     return st.finish();
 }
 int arkmpc_point_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok) {
