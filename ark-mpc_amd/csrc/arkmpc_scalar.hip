@@ -415,18 +415,23 @@ static void scan_level(arkmpc_ctx* ctx, size_t n, const u64* in, u64* out, u64* 
 // Device memory pool behind arkmpc_malloc / arkmpc_free.  hipFree synchronises the whole device and unmaps the range
 // (about a millisecond for the 32-64 MiB batches of this path); a host-side protocol step allocates and drops a dozen of
 // them.  Freed blocks are kept per size class (power of two below 1 MiB, 2 MiB granules above) and handed out again.
-// A block may have been read by another context's stream (a batch handed to the peer party of the in-process mock), so
-// recycling is fenced by a device-wide synchronise -- what hipFree did implicitly.  ARKMPC_NO_POOL=1 restores plain
-// hipMalloc / hipFree; ARKMPC_POOL_MAX_MB caps the cached bytes (default 16 GiB of the 288 GB).
+// arkmpc_free is STREAM-ORDERED (hipFreeAsync semantics): it records an event on the context's stream and the block
+// becomes reusable once that event has completed -- no host-side wait.  A buffer must therefore be freed through the
+// context whose stream last used it (the host mirror rebinds a batch received from the peer party to the receiver's
+// engine).  ARKMPC_NO_POOL=1 restores plain hipMalloc / hipFree; ARKMPC_POOL_MAX_MB caps the cached bytes (default 16 GiB
+// of the 288 GB).
 // ---------------------------------------------------------------------------------------------
 #include <map>
 #include <unordered_map>
 namespace {
+struct PendingBlock { void* ptr; size_t cls; hipEvent_t ev; };
 struct DevicePool {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> free_;
+    std::vector<PendingBlock> pending_;      // freed, waiting for the freeing stream to pass the event
+    std::vector<hipEvent_t> events_;         // recycled events
     std::unordered_map<void*, size_t> live_;
-    size_t cached = 0;
+    size_t cached = 0;                       // bytes in free_ + pending_
     int refs = 0;
 };
 DevicePool g_pool[16];
@@ -445,9 +450,24 @@ size_t pool_class(size_t bytes) {
     while (c < bytes) c <<= 1;
     return c;
 }
-void pool_release_all(DevicePool& p) {   // caller holds p.mu
+// move every pending block whose event has completed to the free lists (caller holds p.mu)
+void pool_reclaim(DevicePool& p, bool wait) {
+    size_t k = 0;
+    for (size_t i = 0; i < p.pending_.size(); ++i) {
+        PendingBlock& b = p.pending_[i];
+        const bool done = wait ? (hipEventSynchronize(b.ev) == hipSuccess) : (hipEventQuery(b.ev) == hipSuccess);
+        if (done) { p.free_[b.cls].push_back(b.ptr); p.events_.push_back(b.ev); }
+        else p.pending_[k++] = b;
+    }
+    p.pending_.resize(k);
+    (void)hipGetLastError();     // hipEventQuery reports "not ready" through the error state
+}
+void pool_release_all(DevicePool& p) {   // caller holds p.mu; blocks everything pending first
+    pool_reclaim(p, true);
     for (auto& kv : p.free_) for (void* q : kv.second) (void)hipFree(q);
     p.free_.clear();
+    for (hipEvent_t e : p.events_) (void)hipEventDestroy(e);
+    p.events_.clear();
     p.cached = 0;
 }
 }  // namespace
@@ -560,6 +580,7 @@ int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
     const size_t cls = pool_class(bytes);
     std::lock_guard<std::mutex> lk(p.mu);
     auto it = p.free_.find(cls);
+    if (it == p.free_.end() || it->second.empty()) { pool_reclaim(p, false); it = p.free_.find(cls); }
     if (it != p.free_.end() && !it->second.empty()) {
         *out_dptr = it->second.back();
         it->second.pop_back();
@@ -568,7 +589,6 @@ int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
         hipError_t e = hipMalloc(out_dptr, cls);
         if (e != hipSuccess && p.cached) {       // out of memory with blocks cached: give them back and retry
             (void)hipGetLastError();
-            (void)hipDeviceSynchronize();
             pool_release_all(p);
             e = hipMalloc(out_dptr, cls);
         }
@@ -582,17 +602,22 @@ int arkmpc_free(arkmpc_ctx* ctx, void* dptr) {
     if (!dptr) return ARKMPC_OK;
     if (pool_enabled() && ctx->device < 16) {
         DevicePool& p = g_pool[ctx->device];
-        std::unique_lock<std::mutex> lk(p.mu);
+        std::lock_guard<std::mutex> lk(p.mu);
         auto it = p.live_.find(dptr);
         if (it != p.live_.end()) {
             const size_t cls = it->second;
             p.live_.erase(it);
-            lk.unlock();
-            ARK_HIP(ctx, hipDeviceSynchronize());          // every stream that may still touch the block
-            lk.lock();
-            if (p.cached + cls <= pool_cap()) { p.free_[cls].push_back(dptr); p.cached += cls; return ARKMPC_OK; }
-            lk.unlock();
-            ARK_HIP(ctx, hipFree(dptr));
+            if (p.cached + cls > pool_cap()) {           // over the cap: a real free (waits for the device)
+                ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                ARK_HIP(ctx, hipFree(dptr));
+                return ARKMPC_OK;
+            }
+            hipEvent_t ev;
+            if (!p.events_.empty()) { ev = p.events_.back(); p.events_.pop_back(); }
+            else ARK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ARK_HIP(ctx, hipEventRecord(ev, ctx->stream));
+            p.pending_.push_back({dptr, cls, ev});
+            p.cached += cls;
             return ARKMPC_OK;
         }
     }

@@ -111,6 +111,9 @@ class DeviceBuf {
     uint64_t* ptr() const { return p_; }
     size_t words() const { return words_; }
     void set_words(size_t w) { words_ = w; }          // logical length of a buffer allocated with slack
+    // a batch handed over by the peer party: from now on this engine's stream uses it, so this engine frees it (arkmpc_free is
+    // ordered on the freeing context's stream)
+    void rebind(std::shared_ptr<Engine> e) { e_ = std::move(e); }
     void upload(const void* host, size_t bytes) { if (bytes) check(e_->dev(), arkmpc_memcpy_h2d(e_->dev(), p_, host, bytes), "h2d"); }
     void download(void* host, size_t bytes) const {
         check(e_->dev(), arkmpc_sync(e_->dev()), "sync");
@@ -310,7 +313,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     ScalarBatch receive_values() {
         NetworkOutbound m = net_->receive();
         const uint64_t id = next_id_++;
-        if (link_ == LinkMode::Device) { ScalarBatch b; b.n = m.dev->words() / 4; b.buf = std::move(*m.dev); return b; }
+        if (link_ == LinkMode::Device) { ScalarBatch b; b.n = m.dev->words() / 4; b.buf = std::move(*m.dev); b.buf.rebind(eng_); return b; }
         if (!wire_) return allocate_scalars(m.payload);
         // the element count is only known after parsing: a scalar's text is at least 66 bytes ("[0,0,...,0]," )
         const size_t max_n = m.frame.size() / 66 + 1;
@@ -362,7 +365,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     template <class PB> PB receive_points(size_t n) {
         NetworkOutbound m = net_->receive();
         const uint64_t id = next_id_++;
-        if (link_ == LinkMode::Device) { PB r; r.n = n; r.buf = std::move(*m.dev); return r; }
+        if (link_ == LinkMode::Device) { PB r; r.n = n; r.buf = std::move(*m.dev); r.buf.rebind(eng_); return r; }
         PB r; r.n = n; r.buf = DeviceBuf(eng_, 12 * (n ? n : 1));
         if (!wire_) { r.buf.upload(m.payload.data(), n * 96); return r; }
         DeviceBuf fr(eng_, m.frame.size() / 8 + 2);

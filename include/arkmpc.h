@@ -75,7 +75,9 @@ int arkmpc_kernel_timer_arm(arkmpc_ctx* ctx, int slot);
 int arkmpc_kernel_timer_ms(arkmpc_ctx* ctx, int slot, float* out_ms);
 const char* arkmpc_version(void);
 int arkmpc_device_count(void);
-/* device memory helpers for callers without their own allocator (Rust shim, tests) */
+/* device memory helpers for callers without their own allocator (Rust shim, tests).  Blocks come from a per-device pool;
+ * arkmpc_free is STREAM-ORDERED like hipFreeAsync: the block is recycled once the work already submitted on ctx's stream
+ * has passed, without blocking the host -- free a buffer through the context whose stream used it last. */
 int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr);
 int arkmpc_free(arkmpc_ctx* ctx, void* dptr);
 int arkmpc_memcpy_h2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
