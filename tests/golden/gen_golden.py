@@ -113,9 +113,68 @@ def curve_vectors():
     }
 
 
+def msm_vectors():
+    """CurvePoint::msm / msm_authenticated (curve.rs:549-560, 618-642) and CurvePoint::from_bytes (:110-114)."""
+    rng = random.Random(0x3535)
+    r, q = pyref.RORD, pyref.Q
+    n = 24
+    base = [rng.randrange(r) for _ in range(n)]
+    pts = [pyref.g1_mul(pyref.G, b) for b in base]
+    pts[3] = None                                   # identity among the bases
+    pts[9] = pts[8]                                 # repeated base
+    scalars = [0, 1, r - 1, 2, (1 << 253) % r] + [rng.randrange(r) for _ in range(n - 5)]
+    scalars[9] = scalars[8]                         # ... with the same scalar: doubling inside a bucket
+    macs = [rng.randrange(r) for _ in range(n)]
+    enc = lambda P: None if P is None else [hx(P[0]), hx(P[1])]
+    def msm(ss):
+        acc = None
+        for k, P in zip(ss, pts):
+            acc = pyref.g1_add(acc, pyref.g1_mul(P, k) if P else None)
+        return acc
+    # encodings that are NOT points: x >= q, both flag bits, x^3 + 3 a non-residue
+    x = 0
+    while pow((x ** 3 + 3) % q, (q - 1) // 2, q) == 1 or (x ** 3 + 3) % q == 0:
+        x += 1
+    bad = [int(q).to_bytes(32, "little").hex(), (bytes(31) + b"\xc0").hex(), int(x).to_bytes(32, "little").hex()]
+    return {"points": [enc(P) for P in pts], "scalars": [hx(k) for k in scalars], "macs": [hx(k) for k in macs],
+            "msm": enc(msm(scalars)), "msm_macs": enc(msm(macs)),
+            "compressed": [pyref.g1_compress(P).hex() for P in pts], "invalid_encodings": bad}
+
+
+def wire_vectors():
+    """QuicTwoPartyNet frames (network/quic.rs:303-306): u64 LE length + serde_json text, see pyref.wire_frame."""
+    out = {"scalar_batches": [], "point_batches": []}
+    for fid in (0, 1, 2):
+        p = pyref.P[fid]
+        rng = random.Random(0x77 + fid)
+        for n, rid in ((0, 0), (1, 7), (5, 4294967296), (40, 18446744073709551615)):
+            vals = ([0, 1, p - 1, 255, 256] + [rng.randrange(p) for _ in range(n)])[:n]
+            out["scalar_batches"].append({"field": fid, "result_id": rid, "values": [hx(v) for v in vals],
+                                          "frame": pyref.wire_frame("ScalarBatch", rid, pyref.wire_scalar_records(fid, vals)).hex()})
+    rng = random.Random(0x78)
+    pts = [pyref.g1_mul(pyref.G, rng.randrange(pyref.RORD)) for _ in range(6)] + [None]
+    out["point_batches"].append({"result_id": 12, "points": [None if P is None else [hx(P[0]), hx(P[1])] for P in pts],
+                                 "frame": pyref.wire_frame("PointBatch", 12, [pyref.g1_compress(P) for P in pts]).hex()})
+    good = pyref.wire_frame("ScalarBatch", 3, pyref.wire_scalar_records(0, [5, 255 * 256, 77]))[8:]
+    import struct
+    fr = lambda b: (struct.pack("<Q", len(b)) + b).hex()
+    out["malformed_scalar_batches_field0"] = {
+        "length prefix": (struct.pack("<Q", len(good) + 1) + good).hex(),
+        "whitespace": fr(good.replace(b"[[", b"[ [", 1)),
+        "byte > 255": fr(good.replace(b"[[5,", b"[[256,", 1)),
+        "leading zero": fr(good.replace(b",255,", b",0255,", 1)),
+        "31 numbers": fr(good.replace(b",255,", b",", 1)),
+        "33 numbers": fr(good.replace(b",255,", b",255,255,", 1)),
+        "other variant": fr(good.replace(b"ScalarBatch", b"ScalarShare", 1)),
+        "scalar >= modulus": pyref.wire_frame("ScalarBatch", 3, [int(pyref.P[0]).to_bytes(32, "little")]).hex(),
+    }
+    return out
+
+
 if __name__ == "__main__":
     for name, fn in (("field_vectors", field_vectors), ("dummy_source_vectors", dummy_source_vectors),
-                     ("commitment_vectors", commitment_vectors), ("curve_vectors", curve_vectors)):
+                     ("commitment_vectors", commitment_vectors), ("curve_vectors", curve_vectors), ("msm_vectors", msm_vectors),
+                     ("wire_vectors", wire_vectors)):
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1)
         print("wrote", name + ".json")

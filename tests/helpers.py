@@ -134,3 +134,7 @@ class EngineAdapter:
         n = len(sh) // 24; o = self._o(n, 24); self.eng(0).pointshare_add_public(n, party, key, sh, pub, o); return o
     def scalarshare_mul_generator(self, ss): n = len(ss) // 8; o = self._o(n, 24); self.eng(0).scalarshare_mul_generator(n, ss, o); return o
     def scalarshare_mul_point(self, ss, pts): n = len(ss) // 8; o = self._o(n, 24); self.eng(0).scalarshare_mul_point(n, ss, pts, o); return o
+    def g1_msm(self, pts, sc): n = len(pts) // 12; o = self._o(1, 12); self.eng(0).g1_msm(n, pts, sc, o); return o
+    def g1_msm_authenticated(self, pts, ss): n = len(pts) // 12; o = self._o(1, 24); self.eng(0).g1_msm_authenticated(n, pts, ss, o); return o
+    def g1_from_bytes(self, data):
+        n = len(data) // 32; o = self._o(n, 12); ok = np.zeros(n, dtype=np.uint8); self.eng(0).g1_from_bytes(n, data, o, ok); return o, ok
