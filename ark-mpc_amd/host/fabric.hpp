@@ -153,25 +153,36 @@ struct DuplexQueue {
     std::condition_variable cv;
     std::deque<NetworkOutbound> q;
     bool closed = false;
+    std::atomic<int> pending{0};           // mirrors q.size() / closed for the lock-free poll in receive()
+    std::atomic<bool> closed_flag{false};
 };
 class MockNetwork : public MpcNetwork {
   public:
     MockNetwork(PartyId id, std::shared_ptr<DuplexQueue> out, std::shared_ptr<DuplexQueue> in) : id_(id), out_(std::move(out)), in_(std::move(in)) {}
     PartyId party_id() const override { return id_; }
     void send(NetworkOutbound&& msg) override {
-        { std::lock_guard<std::mutex> lk(out_->mu); out_->q.push_back(std::move(msg)); }
+        { std::lock_guard<std::mutex> lk(out_->mu); out_->q.push_back(std::move(msg)); out_->pending.fetch_add(1, std::memory_order_release); }
         out_->cv.notify_one();
     }
     NetworkOutbound receive() override {
+        // a round trip of the latency-bound circuits (one network op per sequential gate) is ~100 us, of which a condition-
+        // variable wake-up is 20-50: poll the queue briefly before blocking
+        for (int spin = 0; spin < 20000; ++spin) {
+            if (in_->pending.load(std::memory_order_acquire) > 0 || in_->closed_flag.load(std::memory_order_acquire)) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
         std::unique_lock<std::mutex> lk(in_->mu);
         in_->cv.wait(lk, [&] { return !in_->q.empty() || in_->closed; });
         if (in_->q.empty()) throw std::runtime_error("MpcNetworkError::RecvError: peer closed");
         NetworkOutbound m = std::move(in_->q.front());
         in_->q.pop_front();
+        in_->pending.fetch_sub(1, std::memory_order_release);
         return m;
     }
     void close() override {
-        { std::lock_guard<std::mutex> lk(out_->mu); out_->closed = true; }
+        { std::lock_guard<std::mutex> lk(out_->mu); out_->closed = true; out_->closed_flag.store(true, std::memory_order_release); }
         out_->cv.notify_all();
     }
 
