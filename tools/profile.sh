@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"
+ARGS="--steps 200 --warmup 20 --no-cpu-baseline $*"
 # pass 1: per-kernel durations
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- python $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 # pass 2/3: HBM traffic counters, each in its own run (TCC slots: FETCH_SIZE=3, WRITE_SIZE=2)
