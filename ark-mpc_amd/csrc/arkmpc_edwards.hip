@@ -176,6 +176,92 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_to_bytes(size_t n, const u64* pts
     q[1] = make_uint4(yc.v[4], yc.v[5], yc.v[6], top);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fixed-base multiplication by the Curve25519 generator (batch_mul_generator on this curve): the multiples
+// d * 2^(8w) * G, w = 0..31, d = 1..255, tabulated once per device in "Niels" form (y + x, y - x, 2d*x*y: 96 B each,
+// 765 KiB); [s]G is then 32 lookups and at most 32 additions of 7 multiplications each -- no doublings.
+// ---------------------------------------------------------------------------------------------
+#define EDG_WINDOWS 32
+#define EDG_ENTRIES 255
+struct EdNiels { Fe ypx, ymx, t2d; };
+__device__ __noinline__ Ed ed_madd_niels(Ed p, EdNiels q) {
+    Fe A = EQ_MUL(fe_sub<EQ>(p.y, p.x), q.ymx);
+    Fe B = EQ_MUL(fe_add<EQ>(p.y, p.x), q.ypx);
+    Fe C = EQ_MUL(p.t, q.t2d);
+    Fe D = fe_dbl<EQ>(p.z);
+    Fe E = fe_sub<EQ>(B, A), F = fe_sub<EQ>(D, C), G = fe_add<EQ>(D, C), H = fe_add<EQ>(B, A);
+    Ed r;
+    r.x = EQ_MUL(E, F); r.y = EQ_MUL(G, H); r.t = EQ_MUL(E, H); r.z = EQ_MUL(F, G);
+    return r;
+}
+__global__ void k_ed_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(8w) G
+    if (blockIdx.x | threadIdx.x) return;
+    Ed b = ed_generator();
+    for (int w = 0; w < EDG_WINDOWS; ++w) {
+        ed_store(bases + 16 * w, b);
+        for (int k = 0; k < 8; ++k) b = ed_double(b);
+    }
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_gen_table_fill(const u64* bases, u64* table) {
+    const u32 t = blockIdx.x * TPB_ED + threadIdx.x;
+    if (t >= EDG_WINDOWS * EDG_ENTRIES) return;
+    const u32 w = t / EDG_ENTRIES, d = t % EDG_ENTRIES + 1;
+    const Ed b = ed_load(bases + 16 * w);
+    Ed acc = ed_identity();
+    for (int bit = 7; bit >= 0; --bit) {
+        acc = ed_double(acc);
+        if ((d >> bit) & 1u) acc = ed_add(acc, b);
+    }
+    const Fe zi = fe_inv_fermat<EQ>(acc.z);
+    const Fe x = EQ_MUL(acc.x, zi), y = EQ_MUL(acc.y, zi);
+    fe_store(table + 12 * (size_t)t, fe_add<EQ>(y, x));
+    fe_store(table + 12 * (size_t)t + 4, fe_sub<EQ>(y, x));
+    fe_store(table + 12 * (size_t)t + 8, EQ_MUL(EQ_MUL(x, y), ed_const(ED_D2_MONT)));
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_generator_mul_fixed(size_t n, const u64* scalars, u32 s_stride, u32 s_div, const u64* table, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    const Fe s = fe_to_canonical<ER>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
+    Ed acc = ed_identity();
+#pragma unroll 1
+    for (int limb = 0; limb < 8; ++limb) {
+        u32 wv = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv = (limb == k) ? s.v[k] : wv;
+#pragma unroll 1
+        for (int by = 0; by < 4; ++by) {
+            const u32 d = (wv >> (8 * by)) & 255u;
+            if (__any(d != 0)) {
+                const u64* q = table + 12 * ((size_t)(4 * limb + by) * EDG_ENTRIES + (d ? d - 1 : 0));
+                EdNiels e;
+                e.ypx = fe_load(q); e.ymx = fe_load(q + 4); e.t2d = fe_load(q + 8);
+                acc = ed_select(d != 0, ed_madd_niels(acc, e), acc);
+            }
+        }
+    }
+    ed_store(out + 16 * i, acc);
+}
+
+static std::mutex g_ed_gen_mu;
+static u64* g_ed_gen_table[16] = {nullptr};
+static int ed_gen_table(arkmpc_ctx* ctx, const u64** out) {
+    const int dev = ctx->device;
+    if (dev < 0 || dev >= 16) return ark_bad(ctx, "device index");
+    std::lock_guard<std::mutex> lk(g_ed_gen_mu);
+    if (!g_ed_gen_table[dev]) {
+        u64 *bases = nullptr, *table = nullptr;
+        ARK_HIP(ctx, hipMalloc((void**)&bases, EDG_WINDOWS * 128));
+        ARK_HIP(ctx, hipMalloc((void**)&table, (size_t)EDG_WINDOWS * EDG_ENTRIES * 96));
+        hipLaunchKernelGGL(k_ed_gen_table_bases, dim3(1), dim3(64), 0, ctx->stream, bases);
+        hipLaunchKernelGGL(k_ed_gen_table_fill, dim3(blocks_for(EDG_WINDOWS * EDG_ENTRIES, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, bases, table);
+        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ARK_HIP(ctx, hipFree(bases));
+        g_ed_gen_table[dev] = table;
+    }
+    *out = g_ed_gen_table[dev];
+    return ARKMPC_OK;
+}
+
 #define ENTER_ED(ctx)                                                                           \
     if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
     CtxGuard guard__(ctx);                                                                      \
@@ -220,8 +306,17 @@ static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_
     int is = st.declare_in(scalars, scalar_bytes), io = st.declare_out(out, m * 128);
     const size_t CH = (size_t)1 << 20;
     const size_t chunk = m < CH ? m : CH;
-    int iw = st.declare_scratch(chunk * 15 * 128);
+    static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
+    int iw = (points || !fixed_base) ? st.declare_scratch(chunk * 15 * 128) : -1;
     if (st.commit()) return st.rc;
+    if (m && !points && fixed_base) {
+        const u64* table = nullptr;
+        int rc = ed_gen_table(ctx, &table);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ed_generator_mul_fixed, dim3(blocks_for(m, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, m, st.in<u64>(is), s_stride, s_div, table,
+                           st.out<u64>(io));
+        return st.finish();
+    }
     for (size_t lo = 0; lo < m; lo += chunk) {
         const size_t cnt = (m - lo < chunk) ? (m - lo) : chunk;
         const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;

@@ -20,3 +20,12 @@ for _ in range(3): e.edshare_mul_public(n, shares, sc, out)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 3 * 1e-3
 print(json.dumps({"workload": "2^%d EdPointShare x Scalar = %d scalar-muls" % (int(np.log2(n)), 2 * n), "ms": t * 1e3, "scalar_muls_per_s": 2 * n / t}))
+# generator multiplication (fixed-base table)
+gs = rnd(2 * n)
+e.scalarshare_mul_ed_generator(n, gs, shares); torch.cuda.synchronize()
+e0.record()
+for _ in range(3): e.scalarshare_mul_ed_generator(n, gs, shares)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 3 * 1e-3
+print(json.dumps({"workload": "2^%d ScalarShare x Ed generator = %d generator muls" % (int(np.log2(n)), 2 * n), "fixed_base": os.environ.get("ARKMPC_NO_FIXED_BASE") != "1",
+                  "ms": t * 1e3, "generator_muls_per_s": 2 * n / t}))
