@@ -176,6 +176,77 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_to_bytes(size_t n, const u64* pts
     q[1] = make_uint4(yc.v[4], yc.v[5], yc.v[6], top);
 }
 
+// CurvePoint::from_bytes on this curve (curve.rs:110-114 -> ark-ec twisted-Edwards deserialize_compressed with validation),
+// the inverse of k_ed_to_bytes: y = low 255 bits (< q), bit 255 selects the larger root x of x^2 = (y^2 - 1) / (d y^2 + 1)
+// (q = 5 mod 8: w^((q+3)/8), times sqrt(-1) when that squares to -w), and the point must be in the prime-order subgroup
+// ([l]P = O).  ok[i] = 0 and the identity for anything else.
+template <int NB> __device__ __forceinline__ Fe eq_pow(const Fe& base, const u32 (&e)[NB]) {
+    Fe acc = fe_one<EQ>();
+    for (int limb = NB - 1; limb >= 0; --limb) {
+        u32 w = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) w = (limb == k) ? e[k] : w;
+        for (int bit = 31; bit >= 0; --bit) {
+            acc = EQ_SQR(acc);
+            if ((w >> bit) & 1u) acc = EQ_MUL(acc, base);
+        }
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_from_bytes(size_t n, const unsigned char* in, u64* out, unsigned char* ok) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    using PQ = FieldParams<EQ>;
+    using PR = FieldParams<ER>;
+    const uint4* qv = reinterpret_cast<const uint4*>(in + 32 * i);
+    const uint4 a = qv[0], b = qv[1];
+    Fe yc;
+    yc.v[0] = a.x; yc.v[1] = a.y; yc.v[2] = a.z; yc.v[3] = a.w; yc.v[4] = b.x; yc.v[5] = b.y; yc.v[6] = b.z; yc.v[7] = b.w & 0x7fffffffu;
+    const bool flag = (b.w >> 31) & 1u;
+    u32 br = 0, bo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { (void)__builtin_subc(yc.v[k], PQ::P(k), br, &bo); br = bo; }
+    bool valid = br != 0;                               // y < q
+    Ed r = ed_identity();
+    if (valid) {
+        const Fe y = fe_from_canonical<EQ>(yc);
+        const Fe yy = EQ_SQR(y), one = fe_one<EQ>();
+        const Fe u = fe_sub<EQ>(yy, one), v = fe_add<EQ>(EQ_MUL(ed_const(ED_D_MONT), yy), one);
+        const Fe w = EQ_MUL(u, fe_inv_fermat<EQ>(v));
+        u32 e[8], cy = 3;                               // (q + 3) / 8
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const u64 t = (u64)PQ::P(k) + cy; e[k] = (u32)t; cy = (u32)(t >> 32); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = (e[k] >> 3) | (k < 7 ? e[k + 1] << 29 : 0u);
+        Fe x = eq_pow<8>(w, e);
+        const Fe xx = EQ_SQR(x);
+        if (!fe_eq(xx, w)) {
+            if (fe_eq(xx, fe_neg<EQ>(w))) x = EQ_MUL(x, ed_const(ED_SQRT_M1_MONT));
+            else valid = false;
+        }
+        const Fe nx = fe_neg<EQ>(x);
+        const Fe xc = fe_to_canonical<EQ>(x), nxc = fe_to_canonical<EQ>(nx);
+        u32 b2 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nxc.v[k], xc.v[k], b2, &bo); b2 = bo; }     // borrows <=> x > -x
+        Ed p;
+        p.x = ((b2 != 0) == flag) ? x : nx; p.y = y; p.t = EQ_MUL(p.x, y); p.z = one;
+        // prime-order subgroup: [l]P == identity (x = 0, y = z)
+        Ed acc = ed_identity();
+        for (int limb = 7; limb >= 0; --limb) {
+            const u32 lw = PR::P(limb);
+            for (int bit = 31; bit >= 0; --bit) {
+                acc = ed_double(acc);
+                if ((lw >> bit) & 1u) acc = ed_add(acc, p);       // l is a constant: uniform control flow
+            }
+        }
+        valid = valid && fe_is_zero(acc.x) && fe_eq(acc.y, acc.z);
+        if (valid) r = p;
+    }
+    ed_store(out + 16 * i, r);
+    ok[i] = valid ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fixed-base multiplication by the Curve25519 generator (batch_mul_generator on this curve): the multiples
 // d * 2^(8w) * G, w = 0..31, d = 1..255, tabulated once per device in "Niels" form (y + x, y - x, 2d*x*y: 96 B each,
@@ -358,6 +429,15 @@ int arkmpc_ed_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint6
     int ip = st.declare_in(points, n * 128), io = st.declare_out(out_xy, n * 64);
     if (st.commit()) return st.rc;
     if (n) hipLaunchKernelGGL(k_ed_to_affine, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_ed_from_bytes(arkmpc_ctx* ctx, size_t n, const uint8_t* bytes, uint64_t* out_points, uint8_t* out_ok) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ib = st.declare_in(bytes, n * 32), io = st.declare_out(out_points, n * 128), ik = st.declare_out(out_ok, n);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_ed_from_bytes, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<unsigned char>(ib), st.out<u64>(io),
+                              st.out<unsigned char>(ik));
     return st.finish();
 }
 int arkmpc_ed_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes) {

@@ -267,6 +267,7 @@ class Engine:
 
     # ---- Curve25519 (Edwards) points
     def ed_add(self, n, a, b, out): self.call("ed_add", ("size", n), a, b, out)
+    def ed_from_bytes(self, n, data, out, out_ok): self.call("ed_from_bytes", ("size", n), data, out, out_ok)
     def ed_sub(self, n, a, b, out): self.call("ed_sub", ("size", n), a, b, out)
     def ed_neg(self, n, a, out): self.call("ed_neg", ("size", n), a, out)
     def ed_scalar_mul(self, n, pts, sc, out): self.call("ed_scalar_mul", ("size", n), pts, sc, out)

@@ -231,6 +231,10 @@ int arkmpc_ed_scalar_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* points, cons
 int arkmpc_ed_generator_mul(arkmpc_ctx* ctx, size_t n, const uint64_t* scalars, uint64_t* out);
 int arkmpc_ed_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy);        /* n x { x[4], y[4] } */
 int arkmpc_ed_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes);         /* y LE, bit 7 = x > -x */
+/* CurvePoint::from_bytes on Curve25519 (curve.rs:110-114 -> twisted-Edwards deserialize_compressed with validation): n x 32
+ * bytes -> n extended points (x, y, xy, 1); out_ok[i] = 0 (and the identity) unless y < q, x^2 = (y^2-1)/(d y^2+1) is a
+ * square and the point lies in the prime-order subgroup (cofactor 8: [l]P = O). */
+int arkmpc_ed_from_bytes(arkmpc_ctx* ctx, size_t n, const uint8_t* bytes, uint64_t* out_points, uint8_t* out_ok);
 int arkmpc_edshare_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
 int arkmpc_edshare_sub(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
 int arkmpc_edshare_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);

@@ -746,6 +746,61 @@ void ora_ed_to_bytes(const u64 a[16], unsigned char out[32]) {
     for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) out[8 * i + b] = (unsigned char)(yc[i] >> (8 * b));
     if (geq(xc, nxc) && memcmp(xc, nxc, 32) != 0) out[31] |= 0x80;
 }
+/* generic square-and-multiply in a field (exponent little-endian u64 limbs) */
+static void fp_pow4(const ora_field* f, const u64 base[4], const u64 e[4], u64 out[4]) {
+    u64 acc[4]; memcpy(acc, f->r, 32);
+    for (int i = 255; i >= 0; --i) { fp_sqr(f, acc, acc); if ((e[i / 64] >> (i % 64)) & 1) ora_fp_mul(f, acc, base, acc); }
+    memcpy(out, acc, 32);
+}
+/* CurvePoint::from_bytes on this curve (curve.rs:110-114 -> ark-ec twisted-Edwards deserialize_compressed with validation):
+ * y = the low 255 bits (must be < q), bit 255 = "x is the larger root"; x^2 = (y^2 - 1) / (d y^2 + 1) must be a square
+ * (q = 5 mod 8: x = w^((q+3)/8), times sqrt(-1) if x^2 = -w); the point must lie in the prime-order subgroup ([l]P = O,
+ * the default is_in_correct_subgroup_assuming_on_curve: cofactor 8).  Returns 1 if valid; else 0 and the identity. */
+int ora_ed_from_bytes(const unsigned char in[32], u64 out[16]) {
+    const ora_field* q = EQF;
+    ora_ed_identity(out);
+    const int flag = (in[31] >> 7) & 1;
+    u64 yc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 32; ++i) { unsigned char b = in[i]; if (i == 31) b &= 0x7f; yc[i / 8] |= (u64)b << (8 * (i % 8)); }
+    if (geq(yc, q->p)) return 0;
+    u64 y[4], yy[4], u[4], v[4], d2[4], d[4], two[4] = {2, 0, 0, 0}, twom[4], twoi[4], w[4], vi[4];
+    ora_fp_from_canonical(q, yc, y);
+    fp_sqr(q, y, yy);
+    ora_fp_sub(q, yy, q->r, u);                                    /* y^2 - 1 */
+    ed_d2(d2); ora_fp_from_canonical(q, two, twom); ora_fp_inv(q, twom, twoi); ora_fp_mul(q, d2, twoi, d);
+    ora_fp_mul(q, d, yy, v); ora_fp_add(q, v, q->r, v);             /* d y^2 + 1 (never zero: -1/d is not a square) */
+    ora_fp_inv(q, v, vi); ora_fp_mul(q, u, vi, w);
+    u64 e[4], x[4], xx[4], nw[4];
+    {   /* (q + 3) / 8 = 2^252 - 2 */
+        unsigned __int128 cy = 3;
+        for (int i = 0; i < 4; ++i) { cy += q->p[i]; e[i] = (u64)cy; cy >>= 64; }
+        for (int i = 0; i < 4; ++i) e[i] = (e[i] >> 3) | (i < 3 ? e[i + 1] << 61 : 0);
+    }
+    fp_pow4(q, w, e, x);
+    fp_sqr(q, x, xx); ora_fp_neg(q, w, nw);
+    if (memcmp(xx, w, 32) != 0) {
+        if (memcmp(xx, nw, 32) != 0) return 0;                      /* not a square */
+        u64 e4[4], s[4];                                            /* sqrt(-1) = 2^((q-1)/4) */
+        for (int i = 0; i < 4; ++i) e4[i] = q->p[i];
+        e4[0] -= 1;
+        for (int i = 0; i < 4; ++i) e4[i] = (e4[i] >> 2) | (i < 3 ? e4[i + 1] << 62 : 0);
+        fp_pow4(q, twom, e4, s);
+        ora_fp_mul(q, x, s, x);
+    }
+    u64 nx[4], xc[4], nxc[4];
+    ora_fp_neg(q, x, nx); ora_fp_to_canonical(q, x, xc); ora_fp_to_canonical(q, nx, nxc);
+    const int x_is_larger = geq(xc, nxc) && memcmp(xc, nxc, 32) != 0;
+    u64 pt[16];
+    memcpy(pt, (x_is_larger == flag) ? x : nx, 32); memcpy(pt + 4, y, 32); ora_fp_mul(q, pt, y, pt + 8); memcpy(pt + 12, q->r, 32);
+    /* subgroup check: [l]P == identity  (x = 0 and y = z) */
+    u64 acc[16]; ora_ed_identity(acc);
+    const u64* l = ERF->p;
+    for (int i = 255; i >= 0; --i) { ora_ed_add(acc, acc, acc); if ((l[i / 64] >> (i % 64)) & 1) ora_ed_add(acc, pt, acc); }
+    u64 zero[4] = {0, 0, 0, 0};
+    if (memcmp(acc, zero, 32) != 0 || memcmp(acc + 4, acc + 12, 32) != 0) return 0;
+    memcpy(out, pt, 128);
+    return 1;
+}
 void ora_ed_batch_add(size_t n, const u64* a, const u64* b, u64* out) { for (size_t i = 0; i < n; ++i) ora_ed_add(a + 16 * i, b + 16 * i, out + 16 * i); }
 void ora_ed_batch_neg(size_t n, const u64* a, u64* out) { for (size_t i = 0; i < n; ++i) ora_ed_neg(a + 16 * i, out + 16 * i); }
 void ora_ed_batch_scalar_mul(size_t n, const u64* pts, size_t p_div, const u64* scalars, size_t s_div, u64* out) {

@@ -144,6 +144,7 @@ void ora_ed_neg(const u64 a[16], u64 out[16]);
 void ora_ed_scalar_mul(const u64 pt[16], const u64 scalar_mont[4], u64 out[16]);
 void ora_ed_to_affine(const u64 a[16], u64 out_xy[8]);
 void ora_ed_to_bytes(const u64 a[16], unsigned char out[32]);
+int ora_ed_from_bytes(const unsigned char in[32], u64 out[16]);   /* curve.rs:110-114 on Curve25519; 1 = valid */
 void ora_ed_batch_add(size_t n, const u64* a, const u64* b, u64* out);
 void ora_ed_batch_neg(size_t n, const u64* a, u64* out);
 void ora_ed_batch_scalar_mul(size_t n, const u64* pts, size_t p_div, const u64* scalars, size_t s_div, u64* out);

@@ -22,6 +22,7 @@ class Oracle:
         self.lib.ora_mac_verify.restype = ctypes.c_int
         self.lib.ora_g1_to_affine.restype = ctypes.c_int
         self.lib.ora_g1_from_bytes.restype = ctypes.c_int
+        self.lib.ora_ed_from_bytes.restype = ctypes.c_int
 
     @staticmethod
     def _p(a):
@@ -195,6 +196,11 @@ class Oracle:
         for i in range(n):
             self.lib.ora_ed_to_bytes(self._p(pts[16 * i:16 * i + 16].copy()), ctypes.c_void_p(out.ctypes.data + 32 * i))
         return out
+    def ed_from_bytes(self, data):
+        n = len(data) // 32; out = np.zeros(16 * n, dtype=np.uint64); ok = np.zeros(n, dtype=np.uint8)
+        for i in range(n):
+            ok[i] = self.lib.ora_ed_from_bytes(ctypes.c_void_p(data.ctypes.data + 32 * i), ctypes.c_void_p(out.ctypes.data + 128 * i))
+        return out, ok
     def edshare_add_public(self, party, key, shares, pub):
         n = len(shares) // 32; out = np.zeros(32 * n, dtype=np.uint64)
         self._call("ora_edshare_batch_add_public", n, party, key, shares, pub, out); return out

@@ -153,6 +153,31 @@ def ed_compress(a):
     return bytes(b)
 
 
+def ed_decompress(b):
+    """Inverse of ed_compress with arkworks' validation: None if the bytes are not a point of the prime-order subgroup."""
+    y = int.from_bytes(b, "little") & ((1 << 255) - 1)
+    flag = b[31] >> 7
+    if y >= EQ:
+        return None
+    w = (y * y - 1) * pow(ED_D * y * y + 1, -1, EQ) % EQ
+    x = pow(w, (EQ + 3) // 8, EQ)
+    if (x * x - w) % EQ:
+        if (x * x + w) % EQ:
+            return None
+        x = x * pow(2, (EQ - 1) // 4, EQ) % EQ
+    if (x > (EQ - x) % EQ) != bool(flag):
+        x = (EQ - x) % EQ
+    pt = (x, y)
+    acc = (0, 1)                                   # [l]P by plain double-and-add (ed_mul reduces its scalar mod l)
+    for bit in bin(EL)[2:]:
+        acc = ed_add(acc, acc)
+        if bit == "1":
+            acc = ed_add(acc, pt)
+    if acc != (0, 1):
+        return None
+    return pt
+
+
 def ed_extended_mont(a, z=1):
     """extended coordinates (X, Y, T, Z) = (x z, y z, x y z, z) as Montgomery limbs"""
     x, y = a

@@ -88,3 +88,21 @@ def test_wrong_context_is_rejected(pkg):
     with pytest.raises(pkg.ArkMpcError):
         e.ed_neg(1, np.zeros(16, dtype=np.uint64), np.zeros(16, dtype=np.uint64))
     e.close()
+
+
+def test_from_bytes(eng, oracle):
+    """arkmpc_ed_from_bytes vs the oracle: round trip of to_bytes (exact limbs: no addition chain involved) and rejection of
+    a non-canonical y, a non-residue, a point of order 2 and points outside the prime-order subgroup."""
+    n = 120
+    pts, P = rand_points(n, 51)
+    data = np.zeros(32 * n, dtype=np.uint8); eng.ed_to_bytes(n, P, data)
+    bad = [int(pyref.EQ).to_bytes(32, "little"), int(pyref.EQ - 1).to_bytes(32, "little"), (2).to_bytes(32, "little")]
+    bad += [int(y).to_bytes(32, "little") for y in range(3, 40) if pyref.ed_decompress(int(y).to_bytes(32, "little")) is None]
+    data = np.concatenate([data, np.frombuffer(b"".join(bad), dtype=np.uint8)])
+    m = len(data) // 32
+    out = np.zeros(16 * m, dtype=np.uint64); ok = np.zeros(m, dtype=np.uint8)
+    eng.ed_from_bytes(m, data, out, ok)
+    want, want_ok = oracle.ed_from_bytes(data)
+    assert np.array_equal(ok, want_ok) and np.array_equal(out, want)
+    assert ok[:n].all() and not ok[n:].any()
+    assert aff_equal(eng, oracle, out[:16 * n], P)

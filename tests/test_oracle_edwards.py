@@ -57,3 +57,33 @@ def test_group_law_vs_python(oracle):
     assert affine(oracle, oracle.ed_batch_add(P, ext(pts))) == [pyref.ed_add(a, a) for a in pts]           # doubling via add
     assert affine(oracle, oracle.ed_batch_add(P, oracle.ed_batch_neg(ext(pts)))) == [(0, 1)] * len(pts)       # P + (-P)
     assert oracle.ed_to_bytes(P).tobytes() == b"".join(pyref.ed_compress(p) for p in pts)
+
+
+def test_from_bytes_vs_python(oracle):
+    """CurvePoint::from_bytes on Curve25519: decompression with arkworks' checks (canonical y, square, prime-order subgroup)."""
+    ks = [1, 2, 3, pyref.EL - 1] + rand_values(2, 12, 91)
+    pts = [pyref.ed_mul(pyref.ED_B, k) for k in ks] + [(0, 1)]
+    good = [pyref.ed_compress(p) for p in pts]
+    # not encodings: y >= q; a y whose x^2 is a non-residue; a point of small order (y = -1: order 2); a point outside the subgroup
+    bad = [int(pyref.EQ).to_bytes(32, "little"), int(pyref.EQ - 1).to_bytes(32, "little")]
+    y = 2
+    while pyref.ed_decompress(int(y).to_bytes(32, "little")) is not None or pow((y * y - 1) * pow(pyref.ED_D * y * y + 1, -1, pyref.EQ) % pyref.EQ, (pyref.EQ - 1) // 2, pyref.EQ) == 1:
+        y += 1
+    bad.append(int(y).to_bytes(32, "little"))                      # non-residue
+    y = 3
+    while True:                                                     # on the curve but with a cofactor component
+        w = (y * y - 1) * pow(pyref.ED_D * y * y + 1, -1, pyref.EQ) % pyref.EQ
+        if pow(w, (pyref.EQ - 1) // 2, pyref.EQ) == 1 and pyref.ed_decompress(int(y).to_bytes(32, "little")) is None:
+            break
+        y += 1
+    bad.append(int(y).to_bytes(32, "little"))
+    data = np.frombuffer(b"".join(good + bad), dtype=np.uint8).copy()
+    out, ok = oracle.ed_from_bytes(data)
+    assert ok.tolist() == [1] * len(good) + [0] * len(bad)
+    assert [pyref.ed_decompress(b) for b in good] == pts and all(pyref.ed_decompress(b) is None for b in bad)
+    xy = oracle.ed_batch_to_affine(out[:16 * len(good)])
+    got = []
+    for i in range(len(good)):
+        x, yv = limbs_to_ints(xy[8 * i:8 * i + 8])
+        got.append((pyref.from_mont(4, x), pyref.from_mont(4, yv)))
+    assert got == pts
