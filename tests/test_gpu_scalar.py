@@ -356,3 +356,29 @@ def test_fill_records(pkg):
             assert np.array_equal(out[:n * words], np.tile(rec, n))
     with pytest.raises(pkg.ArkMpcError):
         eng.fill(4, np.zeros(3, dtype=np.uint64), np.zeros(12, dtype=np.uint64))
+
+
+def test_one_context_shared_by_many_threads(pkg, oracle):
+    """a context is internally locked, so the gate closures of a multi-threaded executor
+    (fabric/executor/multi_threaded) may share one.  8 threads x 40 calls on ONE host-buffer context (ctypes releases the GIL);
+    every result must equal the oracle's."""
+    import threading
+    fid, n = 0, 3000
+    eng = pkg.Engine(fid, device=0, host_buffers=True)
+    errs = []
+    def work(tid):
+        try:
+            a = mont_array(fid, rand_values(fid, n, 7000 + tid)); b = mont_array(fid, rand_values(fid, n, 7100 + tid))
+            want_mul, want_add = oracle.scalar_mul(fid, a, b), oracle.scalar_add(fid, a, b)
+            out = np.zeros(4 * n, dtype=np.uint64)
+            for it in range(20):
+                eng.scalar_mul(n, a, b, out)
+                if not np.array_equal(out, want_mul): errs.append((tid, it, "mul"))
+                eng.scalar_add(n, a, b, out)
+                if not np.array_equal(out, want_add): errs.append((tid, it, "add"))
+        except Exception as ex:                     # noqa: BLE001
+            errs.append((tid, repr(ex)))
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs[:3]
