@@ -64,11 +64,13 @@ def run_slice(e, lo, cnt, keys, key):
 def main():
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("DIST_BACKEND", "nccl")          # gloo: lets a test oversubscribe one GPU with several ranks
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     use_dist = "TORCHELASTIC_RUN_ID" in os.environ or world > 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     n = 1 << int(os.environ.get("LOG2N", "24"))
     e = pkg.Engine(FID, device=local, stream=torch.cuda.current_stream().cuda_stream)
     ks = [field_elems(e, 0, 1, 101), field_elems(e, 0, 1, 103)]             # identical on every rank
@@ -80,9 +82,14 @@ def main():
     if use_dist:
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        full_opened = sharding.gather_ordered(opened, n, 4)
-        full_chk0 = sharding.gather_ordered(chk0, n, 4)
-        ok = sharding.all_ok(ok_local, "cuda")
+        if backend == "nccl":
+            full_opened = sharding.gather_ordered(opened, n, 4)
+            full_chk0 = sharding.gather_ordered(chk0, n, 4)
+            ok = sharding.all_ok(ok_local, "cuda")
+        else:                                                # gloo collectives run on host tensors
+            full_opened = sharding.gather_ordered(opened.cpu(), n, 4).cuda()
+            full_chk0 = sharding.gather_ordered(chk0.cpu(), n, 4).cuda()
+            ok = sharding.all_ok(ok_local, "cpu")
         torch.cuda.synchronize(); t_gather = time.perf_counter() - t0
     else:
         full_opened, full_chk0, ok, t_gather = opened, chk0, ok_local, 0.0
