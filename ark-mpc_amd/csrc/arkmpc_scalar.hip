@@ -279,6 +279,42 @@ __global__ void __launch_bounds__(TPB) k_beaver_finish_asm(u32 n, u32 mask, Fe k
                          out_s, out_m, key, mask);
 }
 
+// AoS form of K2+K3 (arkworks ScalarShare records, 64 B = one cache line): the share and MAC halves of a record share a
+// line, so the per-thread 16-byte loads of the body above touch every line with four instructions and the non-temporal hint
+// backfires (measured: slower in every combination).  Here the workgroup copies its 256 a / b / c records into LDS with
+// coalesced loads -- each line consumed by ONE instruction of four adjacent lanes, hint usable -- the body reads its record
+// from LDS, leaves the result record in the a-region, and the workgroup streams the results out the same way.
+template <int F>
+__global__ void __launch_bounds__(TPB) k_beaver_finish_asm_aos(u32 n, u32 mask, Fe key, const u64* my_d, const u64* my_e, const u64* peer_d,
+                                                               const u64* peer_e, const u64* a, const u64* b, const u64* c, u64* out) {
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    __shared__ v4u lds[3 * TPB * 4];                         // 48 KiB: a | b | c, 256 records of 4 x 16 B each
+    const u32 first = blockIdx.x * TPB, i = first + threadIdx.x;
+    const u32 cnt = (n - first < TPB) ? n - first : TPB;     // records of this workgroup
+    const v4u* a4 = reinterpret_cast<const v4u*>(a) + 4 * (size_t)first;
+    const v4u* b4 = reinterpret_cast<const v4u*>(b) + 4 * (size_t)first;
+    const v4u* c4 = reinterpret_cast<const v4u*>(c) + 4 * (size_t)first;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 idx = threadIdx.x + k * TPB;
+        if (idx < 4 * cnt) {
+            lds[idx] = __builtin_nontemporal_load(a4 + idx);
+            lds[4 * TPB + idx] = __builtin_nontemporal_load(b4 + idx);
+            lds[8 * TPB + idx] = __builtin_nontemporal_load(c4 + idx);
+        }
+    }
+    __syncthreads();
+    const u32 lds_base = (u32)(size_t)(__attribute__((address_space(3))) char*)lds;
+    if (i < n) beaver_finish_asm_lds<F>(i * 32u, lds_base + threadIdx.x * 64u, my_d, my_e, peer_d, peer_e, key, mask);
+    __syncthreads();
+    v4u* o4 = reinterpret_cast<v4u*>(out) + 4 * (size_t)first;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 idx = threadIdx.x + k * TPB;
+        if (idx < 4 * cnt) __builtin_nontemporal_store(lds[idx], o4 + idx);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // batch open + MAC check (authenticated_scalar.rs:278-354)
 // ---------------------------------------------------------------------------------------------
@@ -381,7 +417,16 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                 const size_t cnt = (n - lo < CH) ? (n - lo) : CH;
                 const size_t cs = (size_t)a_s.stride * lo, os = (size_t)o_s.stride * lo;
                 // split-column layout (stride 4): once-streamed data carries non-temporal hints; AoS: none (halves share lines)
-                if (a_s.stride == 4 && o_s.stride == 4)
+                static const bool k3_nt = !(getenv("ARKMPC_K3_NT") && getenv("ARKMPC_K3_NT")[0] == '0');     // A/B switch for the cache-policy measurement
+                static const bool aos_lds = !(getenv("ARKMPC_K3_AOS_LDS") && getenv("ARKMPC_K3_AOS_LDS")[0] == '0');
+                const bool aos_records = a_s.stride == 8 && o_s.stride == 8 && a_m.p == a_s.p + 4 && b_m.p == b_s.p + 4 && c_m.p == c_s.p + 4 &&
+                                         o_m.p == o_s.p + 4;
+                if (aos_records && aos_lds) {
+                    launch_k(ctx, k_beaver_finish_asm_aos<F>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_de + 4 * lo,
+                             my_de + 4 * (n + lo), peer_de + 4 * lo, peer_de + 4 * (n + lo), a_s.p + cs, b_s.p + cs, c_s.p + cs, o_s.p + os);
+                    continue;
+                }
+                if (a_s.stride == 4 && o_s.stride == 4 && k3_nt)
                     launch_k(ctx, k_beaver_finish_asm<F, 1>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k,
                                        my_de + 4 * lo, my_de + 4 * (n + lo), peer_de + 4 * lo, peer_de + 4 * (n + lo), a_s.p + cs, a_m.p + cs,
                                        b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u, o_s.stride * 8u);

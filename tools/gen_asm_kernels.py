@@ -114,15 +114,30 @@ def i_and(d, a, b): return Ins("v_and_b32_e32 %s, %s, %s" % (d, src(a), b), "and
 NT_SPLIT = {"c_s", "c_m", "out_s", "out_m", "a_m", "b_m"}
 NT_AOS = set(os.environ.get("ARKMPC_GEN_NT_AOS", "").split(",")) - {""}
 NT_BASES = set()
+# LDS-staged AoS variant: the workgroup has copied its 256 a / b / c records (64 B each) into LDS with coalesced non-temporal
+# loads -- every 64-byte line consumed by ONE instruction, which is what makes the hint usable for AoS data -- and the body
+# reads its own record from there; the result record goes back through the a-region.  Record layout: share at +0, MAC at +32.
+LDS_MODE = False
+LDS_STREAM = {"a": 0, "b": 16384, "c": 32768, "out": 0}
+def lds_offset(base, half):
+    stream, part = base.split("_")
+    return LDS_STREAM[stream] + (32 if part == "m" else 0) + 16 * half
 
 
 def i_load(regs, off, base, half):
+    if LDS_MODE and base.split("_")[0] in ("a", "b", "c"):
+        return Ins("ds_read_b128 %s, %%[lds_off] offset:%d" % (quad(regs), lds_offset(base, half)), "load", (regs, base, half),
+                   rd=["MEMORDER"], wr=list(regs) + ["MEMORDER"])
     return Ins("global_load_dwordx4 %s, %%[%s], %%[%s]%s%s" % (quad(regs), off, base, " offset:16" if half else "", " nt" if base in NT_BASES else ""), "load", (regs, base, half),
                rd=["MEMORDER"], wr=list(regs) + ["MEMORDER"])
 def i_store(regs, off, base, half):
+    if LDS_MODE:
+        return Ins("ds_write_b128 %%[lds_off], %s offset:%d" % (quad(regs), lds_offset(base, half)), "store", (regs, base, half),
+                   rd=list(regs) + ["MEMORDER"], wr=["MEMORDER"])
     return Ins("global_store_dwordx4 %%[%s], %s, %%[%s]%s%s" % (off, quad(regs), base, " offset:16" if half else "", " nt" if base in NT_BASES else ""), "store", (regs, base, half),
                rd=list(regs) + ["MEMORDER"], wr=["MEMORDER"])
 def i_wait(n): return Ins("s_waitcnt vmcnt(%d)" % n, "wait", (n,))
+def i_wait_lds(n): return Ins("s_waitcnt lgkmcnt(%d)" % n, "wait", (n,))
 
 
 class Emitter:
@@ -362,9 +377,17 @@ class Emu:
 # ------------------------------------------------------------------------------------------------
 # K2+K3 body
 # ------------------------------------------------------------------------------------------------
-def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
-    global NT_BASES
+def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False, lds=False):
+    global NT_BASES, LDS_MODE
     NT_BASES = NT_SPLIT if nt else NT_AOS
+    LDS_MODE = lds
+    try:
+        return _build_beaver_finish(p, first_vgpr, key_names, sched, lds)
+    finally:
+        LDS_MODE = False
+
+
+def _build_beaver_finish(p, first_vgpr, key_names, sched, lds):
     """Emit the fused combine + finish body for modulus p.  Returns (Emitter, regmap)."""
     key = key_names or ["%[k" + str(i) + "]" for i in range(8)]
     rg = Regs(first_vgpr)
@@ -397,14 +420,14 @@ def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
     for t in Tz:
         E.emit(i_mov(t[1], 0))
     # ---- segment 1: K2 (d = my_d + peer_d, e = my_e + peer_e) and de = d*e
-    E.emit(i_wait(8))
+    E.emit(i_wait(0 if lds else 8))                                  # LDS variant: the eight d||e loads are the only global loads
     d, e, de = dm, em, dp
     seg = fe_add_seq(P, dm, dp, dm, qflat[:8]) + fe_add_seq(P, em, ep, em, qflat[8:])
     mm, row = montmul_sum_seq(p, [(d, e)], T, Tz, q, m, P)
     seg += mm + cond_sub_final(p, 1, T, P, qflat, de)
     run(seg)
     # ---- segment 2: share' = d*b.s + e*a.s (one reduction); then c is loaded over the dead b.s / a.s registers
-    E.emit(i_wait(4))
+    E.emit(i_wait_lds(4) if lds else i_wait(4))
     rs = ep
     mm, row = montmul_sum_seq(p, [(d, bs), (e, as_)], T, Tz, q, m, P, row)
     seg = mm + cond_sub_final(p, 2, T, P, qflat, rs)
@@ -414,7 +437,7 @@ def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
             seg.append(i_load(regs[4 * h:4 * h + 4], "off_col", nm, h))
     run(seg)
     # ---- segment 3: mac' = d*b.m + e*a.m + key*de (one reduction); the c loads' latency hides under these rows
-    E.emit(i_wait(4))
+    E.emit(i_wait_lds(4) if lds else i_wait(4))
     rm = bm
     if t_bounds(p, 3)[0] < (1 << 288):
         mm, row = montmul_sum_seq(p, [(d, bm), (e, am), (key, de)], T, Tz, q, m, P, row)
@@ -430,7 +453,7 @@ def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
         seg += fe_add_seq(P, rm, kd, rm, qflat[:8])
         run(seg)
     # ---- segment 4: share = share' + c.s + (PARTY0 ? de : 0) ; mac = mac' + c.m ; stores
-    E.emit(i_wait(0))
+    E.emit(i_wait_lds(0) if lds else i_wait(0))
     dem = am
     seg = [i_and(dem[j], "%[mask]", de[j]) for j in range(8)]
     seg += fe_add_seq(P, rs, cs, rs, qflat[:8]) + fe_add_seq(P, rm, cm, rm, qflat[8:]) + fe_add_seq(P, rs, dem, rs, qflat[:8])
@@ -438,6 +461,8 @@ def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False):
         for h in (0, 1):
             seg.append(i_store(regs[4 * h:4 * h + 4], "off_out", nm, h))
     run(seg)
+    if lds:
+        E.emit(i_wait_lds(0))                                         # the caller's barrier must see the result record in LDS
     regmap = dict(P=P, dm=dm, dp=dp, em=em, ep=ep, bs=bs, as_=as_, bm=bm, am=am, rs=rs, rm=rm, first=first_vgpr, nv=nv)
     return E, regmap
 
@@ -503,9 +528,9 @@ def selftest_montmul(p, trials=200, seed=3):
     return E, mp
 
 
-def selftest_finish(p, trials=40, seed=1):
+def selftest_finish(p, trials=40, seed=1, lds=False):
     rng = random.Random(seed)
-    E, mp = build_beaver_finish(p, key_names=["s%d" % (70 + i) for i in range(8)])
+    E, mp = build_beaver_finish(p, key_names=["s%d" % (70 + i) for i in range(8)], lds=lds)
     # substitute the operand placeholders used by i_and / key
     Rinv = pow(R, -1, p)
     edge = [0, 1, p - 1, p - 2, (1 << 255) % p, R % p, (p + 1) // 2]
@@ -571,6 +596,25 @@ def emit_header(path):
             out.append("          " + ", ".join('[k%d] "s"(key.v[%d])' % (i, i) for i in range(8)))
             out.append("        : " + ", ".join(clob) + ");")
             out.append("}")
+    # LDS-staged AoS variant of the K2+K3 body
+    for fid, (name, p) in enumerate(FIELDS):
+        if name in COORD_ONLY:
+            continue
+        selftest_finish(p, trials=16, seed=fid, lds=True)
+        E, mp = build_beaver_finish(p, lds=True)
+        nvalu = sum(1 for i in E.order if i.op in ("mov", "mad", "mul_lo", "addco", "addc", "subco", "subb", "cnd", "and"))
+        clob = ['"memory"', '"vcc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mp["first"], mp["nv"])]
+        out.append("// %s (LDS-staged AoS): %d VALU, %d H1 wait states; a / b / c records read from LDS at lds_off, result written back to the a-region" % (name, nvalu, E.nops))
+        out.append("template <> __device__ __forceinline__ void beaver_finish_asm_lds<%d>(u32 off_de, u32 lds_off, const u64* my_d, const u64* my_e," % fid)
+        out.append("        const u64* peer_d, const u64* peer_e, const Fe& key, u32 mask) {")
+        out.append("    asm volatile(")
+        out.append(c_string(E.lines))
+        out.append("        :")
+        out.append('        : [off_de] "v"(off_de), [lds_off] "v"(lds_off), [my_d] "s"(my_d), [my_e] "s"(my_e), [peer_d] "s"(peer_d), [peer_e] "s"(peer_e),')
+        out.append('          [mask] "s"(mask),')
+        out.append("          " + ", ".join('[k%d] "s"(key.v[%d])' % (i, i) for i in range(8)))
+        out.append("        : " + ", ".join(clob) + ");")
+        out.append("}")
     # single Montgomery multiplication blocks
     for fid, (name, p) in enumerate(FIELDS):
         selftest_montmul(p, trials=60, seed=fid)
