@@ -325,7 +325,7 @@ def main():
                        "gates_per_gpu": n, "field": "bn254_fr", "layout": args.layout, "launches_per_step": 4 * args.chunks,
                        "workload_sets_rotated": len(sets),
                        "parallelism": "gate-range sharding, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_beaver_finish_asm<0,NT> (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": ("k_beaver_finish_asm<0,NT>" if args.layout == "split" else "k_beaver_finish_asm_aos<0>") + " (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": m_launch * ALG_BYTES_K3, "gates_per_launch": m_launch, "avg_launch_ms": k3_ms,
                          "avg_launch_ms_note": "HIP events bound to the kernel dispatch (hipExtLaunchKernelGGL) on sampled steps of the timed region",
