@@ -151,45 +151,26 @@ __global__ void __launch_bounds__(TPB) k_scan_apply(size_t n, u64* out, const u6
 // ---------------------------------------------------------------------------------------------
 // ScalarShare kernels (share.rs:72-133)
 // ---------------------------------------------------------------------------------------------
-// share.rs:85-91 / :95-101: component-wise on (share, mac)
-template <int F, int OP>
-__global__ void __launch_bounds__(TPB) k_share_binop(size_t n, const u64* a, const u64* b, u64* out) {
-    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    Fe as = fe_load(a + 8 * i), am = fe_load(a + 8 * i + 4), bs = fe_load(b + 8 * i), bm = fe_load(b + 8 * i + 4);
-    Fe rs = (OP == OP_ADD) ? fe_add<F>(as, bs) : fe_sub<F>(as, bs);
-    Fe rm = (OP == OP_ADD) ? fe_add<F>(am, bm) : fe_sub<F>(am, bm);
-    fe_store(out + 8 * i, rs);
-    fe_store(out + 8 * i + 4, rm);
-}
-// share.rs:115-121
+// share.rs:85-131: add / sub / neg / mul(Scalar) are component-wise on (share, mac); add_public / sub_public (:74-82) add the
+// public value to the share iff PARTY0 and mac_key * value to the MAC.
+// "Flat" forms: a ScalarShare array is 2n consecutive field elements (share, mac, share,
+// mac, ...), so one thread per ELEMENT (32 B, lanes 32 B apart) streams at the scalar kernels' 5.9 TB/s where one thread per
+// 64-byte record reached 4.7-4.9 (tools/kernel_suite.py).  add / sub / neg are literally the scalar kernels over 2n elements.
 template <int F>
-__global__ void __launch_bounds__(TPB) k_share_neg(size_t n, const u64* a, u64* out) {
-    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    fe_store(out + 8 * i, fe_neg<F>(fe_load(a + 8 * i)));
-    fe_store(out + 8 * i + 4, fe_neg<F>(fe_load(a + 8 * i + 4)));
+__global__ void __launch_bounds__(TPB) k_share_mul_public_flat(size_t m, const u64* a, const u64* pub, u64* out) {      // m = 2n
+    size_t j = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= m) return;
+    fe_store(out + 4 * j, fe_mul<F>(fe_load(a + 4 * j), fe_load(pub + 4 * (j >> 1))));
 }
-// share.rs:74-82: share (+/-)= rhs iff PARTY0 ; mac (+/-)= mac_key * rhs
 template <int F, bool SUB>
-__global__ void __launch_bounds__(TPB) k_share_addsub_public(size_t n, int party, Fe key, const u64* a, const u64* pub, u64* out) {
-    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    Fe as = fe_load(a + 8 * i), am = fe_load(a + 8 * i + 4), r = fe_load(pub + 4 * i);
+__global__ void __launch_bounds__(TPB) k_share_addsub_public_flat(size_t m, int party, Fe key, const u64* a, const u64* pub, u64* out) {
+    size_t j = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= m) return;
+    Fe v = fe_load(a + 4 * j), r = fe_load(pub + 4 * (j >> 1));
     if (SUB) r = fe_neg<F>(r);
-    Fe rs = (party == 0) ? fe_add<F>(as, r) : as;
-    Fe rm = fe_add<F>(am, fe_mul<F>(key, r));
-    fe_store(out + 8 * i, rs);
-    fe_store(out + 8 * i + 4, rm);
-}
-// share.rs:125-131
-template <int F>
-__global__ void __launch_bounds__(TPB) k_share_mul_public(size_t n, const u64* a, const u64* pub, u64* out) {
-    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    Fe as = fe_load(a + 8 * i), am = fe_load(a + 8 * i + 4), r = fe_load(pub + 4 * i);
-    fe_store(out + 8 * i, fe_mul<F>(as, r));
-    fe_store(out + 8 * i + 4, fe_mul<F>(am, r));
+    if (j & 1) v = fe_add<F>(v, fe_mul<F>(key, r));          // mac element
+    else if (party == 0) v = fe_add<F>(v, r);                // share element
+    fe_store(out + 4 * j, v);
 }
 // layout converters between arkworks' AoS records and the engine-native split columns (field-independent copies)
 __global__ void __launch_bounds__(TPB) k_share_split(size_t n, const u64* aos, u64* share_col, u64* mac_col) {
@@ -769,8 +750,9 @@ static int share_binop(arkmpc_ctx* ctx, int op, size_t n, const uint64_t* a, con
     if (n) {
         dim3 g(blocks_for(n, TPB)), t(TPB);
         DISPATCH_FIELD(ctx, {
-            if (op == OP_ADD) hipLaunchKernelGGL((k_share_binop<F, OP_ADD>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
-            if (op == OP_SUB) hipLaunchKernelGGL((k_share_binop<F, OP_SUB>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+            const dim3 g2(blocks_for(2 * n, TPB));                // one thread per field element: 2n of them
+            if (op == OP_ADD) hipLaunchKernelGGL((k_scalar_binop<F, OP_ADD>), g2, t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+            if (op == OP_SUB) hipLaunchKernelGGL((k_scalar_binop<F, OP_SUB>), g2, t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
         });
     }
     return st.finish();
@@ -785,7 +767,8 @@ int arkmpc_share_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out
     if (st.commit()) return st.rc;
     if (n) {
         dim3 g(blocks_for(n, TPB)), t(TPB);
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_neg<F>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.out<u64>(io)));
+        (void)g;
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_scalar_neg<F>), dim3(blocks_for(2 * n, TPB)), t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.out<u64>(io)));
     }
     return st.finish();
 }
@@ -842,8 +825,10 @@ static int share_addsub_public(arkmpc_ctx* ctx, bool sub, size_t n, int party, c
         Fe k = fe_from_host(key);
         dim3 g(blocks_for(n, TPB)), t(TPB);
         DISPATCH_FIELD(ctx, {
-            if (sub) hipLaunchKernelGGL((k_share_addsub_public<F, true>), g, t, 0, ctx->stream, n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
-            else hipLaunchKernelGGL((k_share_addsub_public<F, false>), g, t, 0, ctx->stream, n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
+            const dim3 g2(blocks_for(2 * n, TPB));
+            (void)g;
+            if (sub) hipLaunchKernelGGL((k_share_addsub_public_flat<F, true>), g2, t, 0, ctx->stream, 2 * n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
+            else hipLaunchKernelGGL((k_share_addsub_public_flat<F, false>), g2, t, 0, ctx->stream, 2 * n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
         });
     }
     return st.finish();
@@ -861,7 +846,8 @@ int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const 
     if (st.commit()) return st.rc;
     if (n) {
         dim3 g(blocks_for(n, TPB)), t(TPB);
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_mul_public<F>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io)));
+        (void)g;
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_mul_public_flat<F>), dim3(blocks_for(2 * n, TPB)), t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io)));
     }
     return st.finish();
 }
