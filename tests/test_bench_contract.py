@@ -65,3 +65,13 @@ def test_config5_driver_two_ranks_equals_single_slice():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["verify_ok"] is True and d["equals_single_slice_run"] is True
+
+
+def test_steps_above_2p20_gates_run_in_ranges():
+    """--log2n 21 with the default --chunks 0: two 2^20-gate ranges per step (8 launches), results still verified."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--log2n", "21", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["config"]["launches_per_step"] == 8 and d["roofline"]["gates_per_launch"] == 1 << 20
+    assert d["results_check"].endswith("ok") and d["value"] > 0

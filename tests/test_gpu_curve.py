@@ -197,3 +197,18 @@ def test_from_bytes(hip, oracle):
     assert np.array_equal(ok, want_ok) and np.array_equal(out, want)       # no addition chain involved: exact limbs
     assert ok[:n].all() and affine_equal(hip, oracle, out[:12 * n], P)
     assert ok[n:].tolist() == want_ok[n:].tolist()
+
+
+def test_empty_batches_on_point_entry_points(hip, oracle):
+    """n = 0 through the newer point entry points: no launch, no error, MSM of nothing is the identity."""
+    eng = hip.eng(0)
+    z12, z24, zb, zk = np.zeros(12, dtype=np.uint64), np.zeros(24, dtype=np.uint64), np.zeros(32, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+    eng.g1_from_bytes(0, zb, z12, zk)
+    out = np.zeros(24, dtype=np.uint64)
+    eng.g1_msm_authenticated(0, z12, np.zeros(8, dtype=np.uint64), out)
+    assert np.array_equal(out[:12], oracle.g1_identity()) and np.array_equal(out[12:], oracle.g1_identity())
+    eng.g1_generator_mul(0, np.zeros(4, dtype=np.uint64), z12)
+    eng.g1_to_bytes(0, z12, zb)
+    cap = eng.wire_frame_bound(0); buf = np.zeros(cap, dtype=np.uint8)
+    ln = eng.wire_encode_bytes32(1, 5, 0, zb, buf, cap)
+    assert buf[8:ln].tobytes() == b'{"result_id":5,"payload":{"PointBatch":[]}}'
