@@ -131,10 +131,10 @@ __device__ __noinline__ G1 g1_madd(G1 p, Fe x2, Fe y2) {
 }
 // window table T[k-1] = k*P for k = 1..15 in the HBM workspace: even entries by doubling (7 Fq-mults) the half entry read
 // back from the table, odd ones by adding P (16): 7 dbl + 7 add instead of 1 dbl + 13 add
-__device__ __forceinline__ void g1_build_table(const G1& p, u64* tab, size_t tid, size_t nthreads) {
+__device__ __forceinline__ void g1_build_table(const G1& p, u64* tab, size_t tid, size_t nthreads, int entries = 15) {
     g1_store(tab + ((size_t)0 * nthreads + tid) * 12, p);
     G1 prev = p;                       // T[k-1]
-    for (int k = 2; k <= 15; ++k) {
+    for (int k = 2; k <= entries; ++k) {
         G1 t;
         if (k & 1) t = g1_add(prev, p);                                                   // odd: T[k-1] + P
         else t = g1_double(g1_load(tab + ((size_t)(k / 2 - 1) * nthreads + tid) * 12));     // even: 2 * T[k/2]
@@ -267,6 +267,67 @@ __device__ __forceinline__ G1 g1_scalar_mul_glv(const G1& p, const Fe& s_mont, u
     }
     return acc;
 }
+// Signed 5-bit windows for the two GLV halves: digits in [-15, 16] (a digit above 16 becomes d - 32 with a carry into the next
+// window), so 27 windows x 2 additions replace 33 x 2 and the table grows by one entry (16 P): ~165 Fq multiplications fewer
+// per scalar-mul than the unsigned 4-bit form above.  Digits are recoded LSB-first once (fully unrolled, in registers), packed
+// five to a word: bits 0-4 = |d|, bit 5 = negative.
+#define GLV5_WINDOWS 27        // 135 bits >= the 132 the decomposition model bounds, plus the top carry
+struct GlvDigits { u32 w[6]; };
+__device__ __forceinline__ GlvDigits glv_recode5(const u32 (&mag)[5]) {
+    GlvDigits r;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.w[k] = 0;
+    u32 carry = 0;
+#pragma unroll
+    for (int j = 0; j < GLV5_WINDOWS; ++j) {
+        const int bit = 5 * j, limb = bit >> 5, sh = bit & 31;
+        u32 v = mag[limb] >> sh;
+        if (sh > 27 && limb + 1 < 5) v |= mag[limb + 1] << (32 - sh);
+        u32 d = (v & 31u) + carry, neg = 0;
+        if (d > 16u) { d = 32u - d; neg = 1; carry = 1; } else carry = 0;
+        r.w[j / 5] |= (d | (neg << 5)) << (6 * (j % 5));
+    }
+    return r;
+}
+__device__ __forceinline__ u32 glv_digit(const GlvDigits& d, int w) {
+    const int word = w / 5, pos = w - 5 * word;
+    u32 v = d.w[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) v = (word == k) ? d.w[k] : v;
+    return (v >> (6 * pos)) & 63u;
+}
+__device__ __forceinline__ G1 g1_scalar_mul_glv5(const G1& p, const Fe& s_mont, u64* tab, size_t tid, size_t nthreads) {
+    const Fe s = fe_to_canonical<FR>(s_mont);
+    GlvHalf h1, h2;
+    glv_decompose(s, h1, h2);
+    const GlvDigits D1 = glv_recode5(h1.mag), D2 = glv_recode5(h2.mag);
+    Fe beta;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) beta.v[i] = GLV_BETA_MONT[i];
+    g1_build_table(p, tab, tid, nthreads, 16);
+    G1 acc = g1_identity();
+    for (int w = GLV5_WINDOWS - 1; w >= 0; --w) {
+        if (w != GLV5_WINDOWS - 1) {
+            acc = g1_double(acc); acc = g1_double(acc); acc = g1_double(acc); acc = g1_double(acc); acc = g1_double(acc);
+        }
+        const u32 e1 = glv_digit(D1, w), e2 = glv_digit(D2, w);
+        const u32 m1 = e1 & 31u, m2 = e2 & 31u;
+        if (__any(m1 != 0)) {
+            G1 q = g1_load(tab + ((size_t)(m1 ? m1 - 1 : 0) * nthreads + tid) * 12);
+            if (h1.neg != (bool)(e1 >> 5)) q.y = fe_neg<FQ>(q.y);
+            G1 sum = g1_add(acc, q);
+            acc = g1_select(m1 != 0, sum, acc);
+        }
+        if (__any(m2 != 0)) {
+            G1 q = g1_load(tab + ((size_t)(m2 ? m2 - 1 : 0) * nthreads + tid) * 12);
+            q.x = FQ_MUL(q.x, beta);                 // phi on Jacobian coordinates: (beta X, Y, Z)
+            if (h2.neg != (bool)(e2 >> 5)) q.y = fe_neg<FQ>(q.y);
+            G1 sum = g1_add(acc, q);
+            acc = g1_select(m2 != 0, sum, acc);
+        }
+    }
+    return acc;
+}
 // plain MSB-first double-and-add (used for the single uniform-key multiplications inside other kernels)
 __device__ __forceinline__ G1 g1_scalar_mul(const G1& p, const Fe& s_mont) {
     const Fe s = fe_to_canonical<FR>(s_mont);
@@ -317,7 +378,7 @@ __device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& in
 // ---------------------------------------------------------------------------------------------
 #define GEN_WINDOWS 32
 #define GEN_ENTRIES 255
-__global__ void k_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(8w) G
+__global__ void __launch_bounds__(64) k_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(8w) G
     if (blockIdx.x | threadIdx.x) return;
     G1 b = g1_generator();
     for (int w = 0; w < GEN_WINDOWS; ++w) {
@@ -384,13 +445,18 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_neg(size_t n, const u64* a, u64* 
 // points == nullptr means the generator).  Covers CurvePoint*Scalar (curve.rs:403-409, :459-479),
 // PointShare*Scalar (curve/share.rs:108-114: two launches' worth, index i -> element i/2, scalar i/2),
 // ScalarShare*CurvePoint (scalar/share.rs:135-141) and ScalarShare*generator (authenticated_curve.rs:754-780).
+template <int GLV>      // 2 = GLV + signed 5-bit windows, 1 = GLV + unsigned 4-bit windows, 0 = plain 4-bit windows (one kernel each: separate register allocation)
 __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* points, u32 p_stride, u32 p_div,
-                                                           const u64* scalars, u32 s_stride, u32 s_div, u64* out, u64* table_ws, int glv) {
+                                                           const u64* scalars, u32 s_stride, u32 s_div, u64* out, u64* table_ws) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     G1 p = points ? g1_load(points + (size_t)p_stride * (i / p_div)) : g1_generator();
     Fe s = fe_load(scalars + (size_t)s_stride * (i / s_div));
-    g1_store(out + 12 * i, glv ? g1_scalar_mul_glv(p, s, table_ws, i, n) : g1_scalar_mul_w4(p, s, table_ws, i, n));
+    G1 r;
+    if (GLV == 2) r = g1_scalar_mul_glv5(p, s, table_ws, i, n);
+    else if (GLV == 1) r = g1_scalar_mul_glv(p, s, table_ws, i, n);
+    else r = g1_scalar_mul_w4(p, s, table_ws, i, n);
+    g1_store(out + 12 * i, r);
 }
 // PointShare::add_public (curve/share.rs:57-60): share += rhs iff PARTY0 ; mac += mac_key * rhs
 // (mac_key * rhs through the GLV window path: ~2.2 k instead of ~3.8 k Fq multiplications for plain double-and-add)
@@ -400,7 +466,7 @@ __global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public(size_t n, int 
     G1 rhs = g1_load(pub + 12 * i);
     G1 sh = g1_load(shares + 24 * i), mac = g1_load(shares + 24 * i + 12);
     if (party == 0) sh = g1_add(sh, rhs);
-    mac = g1_add(mac, g1_scalar_mul_glv(rhs, key, table_ws, i, n));
+    mac = g1_add(mac, g1_scalar_mul_glv5(rhs, key, table_ws, i, n));
     g1_store(out + 24 * i, sh);
     g1_store(out + 24 * i + 12, mac);
 }
@@ -409,7 +475,7 @@ __global__ void __launch_bounds__(TPB_EC) k_point_mac_check(size_t n, Fe key, co
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     G1 v = g1_load(opened + 12 * i), mac = g1_load(shares + 24 * i + 12);
-    g1_store(out + 12 * i, g1_add(g1_scalar_mul_glv(v, key, table_ws, i, n), g1_neg(mac)));
+    g1_store(out + 12 * i, g1_add(g1_scalar_mul_glv5(v, key, table_ws, i, n), g1_neg(mac)));
 }
 // my + peer == identity  (authenticated_curve.rs:127-131), per element
 __global__ void __launch_bounds__(TPB_EC) k_point_mac_verify(size_t n, const u64* mine, const u64* peer, unsigned char* ok) {
@@ -675,7 +741,7 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
     const size_t CH = (size_t)1 << 20;
     const size_t chunk = m < CH ? m : CH;
     static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
-    int iw = (points || !fixed_base) ? st.declare_scratch(chunk * 15 * 96) : -1;     // window tables of the variable-base path
+    int iw = (points || !fixed_base) ? st.declare_scratch(chunk * 16 * 96) : -1;     // window tables of the variable-base path
     if (st.commit()) return st.rc;
     if (m && !points && fixed_base) {          // multiplication by the generator: tabulated multiples, no doublings
         const u64* table = nullptr;
@@ -691,9 +757,13 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
             const size_t cnt = (m - lo < chunk) ? (m - lo) : chunk;
             const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
             const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
-            static const int glv = (getenv("ARKMPC_NO_GLV") && getenv("ARKMPC_NO_GLV")[0] == '1') ? 0 : 1;
-            hipLaunchKernelGGL(k_g1_scalar_mul, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, pp, p_stride, p_div, sp,
-                               s_stride, s_div, st.out<u64>(io) + 12 * lo, st.scratch<u64>(iw), glv);
+            // 2 = GLV with signed 5-bit windows (default), 1 = GLV with unsigned 4-bit windows (ARKMPC_GLV_W=4), 0 = no endomorphism
+            static const int glv = (getenv("ARKMPC_NO_GLV") && getenv("ARKMPC_NO_GLV")[0] == '1') ? 0 : ((getenv("ARKMPC_GLV_W") && getenv("ARKMPC_GLV_W")[0] == '4') ? 1 : 2);
+            const dim3 g(blocks_for(cnt, TPB_EC)), t(TPB_EC);
+            u64* op = st.out<u64>(io) + 12 * lo;
+            if (glv == 2) hipLaunchKernelGGL(k_g1_scalar_mul<2>, g, t, 0, ctx->stream, cnt, pp, p_stride, p_div, sp, s_stride, s_div, op, st.scratch<u64>(iw));
+            else if (glv == 1) hipLaunchKernelGGL(k_g1_scalar_mul<1>, g, t, 0, ctx->stream, cnt, pp, p_stride, p_div, sp, s_stride, s_div, op, st.scratch<u64>(iw));
+            else hipLaunchKernelGGL(k_g1_scalar_mul<0>, g, t, 0, ctx->stream, cnt, pp, p_stride, p_div, sp, s_stride, s_div, op, st.scratch<u64>(iw));
         }
     }
     return st.finish();
@@ -728,7 +798,7 @@ int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const 
     Stage st(ctx);
     int is = st.declare_in(shares, n * 192), ip = st.declare_in(pub_points, n * 96), io = st.declare_out(out, n * 192);
     const size_t chunk = n < EC_CHUNK ? n : EC_CHUNK;
-    int iw = st.declare_scratch(chunk * 15 * 96);
+    int iw = st.declare_scratch(chunk * 16 * 96);
     if (st.commit()) return st.rc;
     for (size_t lo = 0; lo < n; lo += chunk) {
         const size_t cnt = (n - lo < chunk) ? (n - lo) : chunk;
@@ -752,7 +822,7 @@ int arkmpc_point_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_
     Stage st(ctx);
     int iv = st.declare_in(opened_points, n * 96), is = st.declare_in(shares, n * 192), io = st.declare_out(out_chk_points, n * 96);
     const size_t chunk = n < EC_CHUNK ? n : EC_CHUNK;
-    int iw = st.declare_scratch(chunk * 15 * 96);
+    int iw = st.declare_scratch(chunk * 16 * 96);
     if (st.commit()) return st.rc;
     for (size_t lo = 0; lo < n; lo += chunk) {
         const size_t cnt = (n - lo < chunk) ? (n - lo) : chunk;

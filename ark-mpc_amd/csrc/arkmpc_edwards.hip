@@ -265,7 +265,7 @@ __device__ __noinline__ Ed ed_madd_niels(Ed p, EdNiels q) {
     r.x = EQ_MUL(E, F); r.y = EQ_MUL(G, H); r.t = EQ_MUL(E, H); r.z = EQ_MUL(F, G);
     return r;
 }
-__global__ void k_ed_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(8w) G
+__global__ void __launch_bounds__(64) k_ed_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(8w) G
     if (blockIdx.x | threadIdx.x) return;
     Ed b = ed_generator();
     for (int w = 0; w < EDG_WINDOWS; ++w) {
