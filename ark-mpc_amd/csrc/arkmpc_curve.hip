@@ -18,16 +18,84 @@
 // tools/gen_asm_kernels.py) unless -DARKMPC_EC_CPP selects the plain C++ core.  Measured on config 4: 12.2 ms vs 13.8 ms.
 // The block's 35 fixed temporaries sit in caller-saved VGPR blocks only -- with callee-saved registers among them the
 // __noinline__ point functions had to spill/restore around every call and the block was SLOWER (15.3 ms).
-#ifndef ARKMPC_EC_CPP
-#define FQ_MUL(a, b) fe_mul_fast<F_BN254_FQ>(a, b)
-#else
-#define FQ_MUL(a, b) fe_mul<F_BN254_FQ>(a, b)
-#endif
-#define FQ_SQR(a) FQ_MUL(a, a)
-
-#define TPB_EC 128
+//
+// Lazy range: inside the point formulas a coordinate lives in [0, 2q), not [0, q).  That is the multiplier block's natural
+// output range -- for inputs below 2q the product is below 4q^2 and (4q^2 + R q) / R < 2q because 4q < R = 2^256 (q < 2^254) --
+// so the conditional subtraction after EVERY multiplication (26 of 332 VALU instructions) disappears; add / sub / neg work
+// modulo 2q at the same cost as before, zero tests accept 0 and q, and values are brought below q where they leave the
+// formulas (g1_store, affine / byte conversions, comparisons of magnitudes).  Memory always holds canonical values.
 constexpr int FQ = F_BN254_FQ;
 constexpr int FR = F_BN254_FR;
+#ifndef ARKMPC_EC_CPP
+struct Fq2 {       // limbs of 2q
+    static constexpr __host__ __device__ u32 L(int i) {
+        return (u32)(((u64)FieldParams<F_BN254_FQ>::P(i) << 1) | (i ? (FieldParams<F_BN254_FQ>::P(i - 1) >> 31) : 0u));
+    }
+};
+__device__ __forceinline__ Fe fq_add_lz(const Fe& a, const Fe& b) {          // (a + b) mod 2q; a + b < 4q < 2^256
+    u32 s[8], d[8], c = 0, co, br = 0, bo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = __builtin_addc(a.v[i], b.v[i], c, &co); c = co; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i] = __builtin_subc(s[i], Fq2::L(i), br, &bo); br = bo; }
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = br ? s[i] : d[i];
+    return r;
+}
+__device__ __forceinline__ Fe fq_sub_lz(const Fe& a, const Fe& b) {          // a - b (+ 2q on borrow)
+    u32 d[8], br = 0, bo, c = 0, co;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i] = __builtin_subc(a.v[i], b.v[i], br, &bo); br = bo; }
+    const u32 mask = 0u - br;
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r.v[i] = __builtin_addc(d[i], Fq2::L(i) & mask, c, &co); c = co; }
+    return r;
+}
+__device__ __forceinline__ Fe fq_neg_lz(const Fe& a) {                       // 2q - a, and 0 stays 0
+    u32 d[8], br = 0, bo, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i] = __builtin_subc(Fq2::L(i), a.v[i], br, &bo); br = bo; nz |= a.v[i]; }
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = nz ? d[i] : 0u;
+    return r;
+}
+__device__ __forceinline__ Fe fq_canon(const Fe& a) {                        // [0, 2q) -> [0, q)
+    u32 d[8], br = 0, bo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i] = __builtin_subc(a.v[i], FieldParams<F_BN254_FQ>::P(i), br, &bo); br = bo; }
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = br ? a.v[i] : d[i];
+    return r;
+}
+__device__ __forceinline__ bool fq_is_zero_lz(const Fe& a) {                 // 0 or q
+    u32 z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { z |= a.v[i]; e |= a.v[i] ^ FieldParams<F_BN254_FQ>::P(i); }
+    return z == 0 || e == 0;
+}
+#define FQ_MUL(a, b) fe_mont_mul_asm<F_BN254_FQ>(a, b)
+#define FQ_ADD(a, b) fq_add_lz(a, b)
+#define FQ_SUB(a, b) fq_sub_lz(a, b)
+#define FQ_NEG(a) fq_neg_lz(a)
+#define FQ_CANON(a) fq_canon(a)
+#define FQ_ISZERO(a) fq_is_zero_lz(a)
+#else
+#define FQ_MUL(a, b) fe_mul<F_BN254_FQ>(a, b)
+#define FQ_ADD(a, b) fe_add<F_BN254_FQ>(a, b)
+#define FQ_SUB(a, b) fe_sub<F_BN254_FQ>(a, b)
+#define FQ_NEG(a) fe_neg<F_BN254_FQ>(a)
+#define FQ_CANON(a) (a)
+#define FQ_ISZERO(a) FQ_ISZERO(a)
+#endif
+#define FQ_SQR(a) FQ_MUL(a, a)
+#define FQ_DBL(a) FQ_ADD(a, a)
+#define FQ_EQ(a, b) FQ_ISZERO(FQ_SUB(a, b))
+
+#define TPB_EC 128
 
 struct G1 {
     Fe x, y, z;
@@ -40,11 +108,11 @@ __device__ __forceinline__ G1 g1_load(const u64* p) {
 }
 // stores the canonical identity (1,1,0) for any z == 0 value
 __device__ __forceinline__ void g1_store(u64* p, const G1& a) {
-    const bool inf = fe_is_zero(a.z);
+    const bool inf = FQ_ISZERO(a.z);
     const Fe one = fe_one<FQ>();
-    fe_store(p, fe_select(inf, one, a.x));
-    fe_store(p + 4, fe_select(inf, one, a.y));
-    fe_store(p + 8, a.z);
+    fe_store(p, fe_select(inf, one, FQ_CANON(a.x)));
+    fe_store(p + 4, fe_select(inf, one, FQ_CANON(a.y)));
+    fe_store(p + 8, inf ? fe_zero<FQ>() : FQ_CANON(a.z));
 }
 __device__ __forceinline__ G1 g1_identity() {
     G1 r;
@@ -53,7 +121,7 @@ __device__ __forceinline__ G1 g1_identity() {
 }
 __device__ __forceinline__ G1 g1_generator() {  // (1, 2, 1)
     G1 r;
-    r.x = fe_one<FQ>(); r.y = fe_dbl<FQ>(fe_one<FQ>()); r.z = fe_one<FQ>();
+    r.x = fe_one<FQ>(); r.y = FQ_DBL(fe_one<FQ>()); r.z = fe_one<FQ>();
     return r;
 }
 __device__ __forceinline__ G1 g1_select(bool c, const G1& a, const G1& b) {
@@ -63,43 +131,43 @@ __device__ __forceinline__ G1 g1_select(bool c, const G1& a, const G1& b) {
 }
 __device__ __forceinline__ G1 g1_neg(const G1& a) {
     G1 r = a;
-    r.y = fe_neg<FQ>(a.y);
+    r.y = FQ_NEG(a.y);
     return r;
 }
 // dbl-2009-l (a = 0).  z = 0 in -> z = 0 out, so the identity needs no branch.
 __device__ __noinline__ G1 g1_double(G1 p) {
     Fe A = FQ_SQR(p.x), B = FQ_SQR(p.y), C = FQ_SQR(B);
-    Fe t = FQ_SQR(fe_add<FQ>(p.x, B));
-    Fe D = fe_dbl<FQ>(fe_sub<FQ>(fe_sub<FQ>(t, A), C));
-    Fe E = fe_add<FQ>(fe_dbl<FQ>(A), A);
+    Fe t = FQ_SQR(FQ_ADD(p.x, B));
+    Fe D = FQ_DBL(FQ_SUB(FQ_SUB(t, A), C));
+    Fe E = FQ_ADD(FQ_DBL(A), A);
     Fe Fq_ = FQ_SQR(E);
     G1 r;
-    r.x = fe_sub<FQ>(Fq_, fe_dbl<FQ>(D));
-    Fe C8 = fe_dbl<FQ>(fe_dbl<FQ>(fe_dbl<FQ>(C)));
-    r.y = fe_sub<FQ>(FQ_MUL(E, fe_sub<FQ>(D, r.x)), C8);
-    r.z = fe_dbl<FQ>(FQ_MUL(p.y, p.z));
+    r.x = FQ_SUB(Fq_, FQ_DBL(D));
+    Fe C8 = FQ_DBL(FQ_DBL(FQ_DBL(C)));
+    r.y = FQ_SUB(FQ_MUL(E, FQ_SUB(D, r.x)), C8);
+    r.z = FQ_DBL(FQ_MUL(p.y, p.z));
     return r;
 }
 // add-2007-bl with the exceptional cases of the group law handled explicitly
 // (identity operands, P + P, P + (-P)), as ark-ec's `Projective += Projective` does.
 __device__ __noinline__ G1 g1_add(G1 p, G1 q) {
-    const bool pinf = fe_is_zero(p.z), qinf = fe_is_zero(q.z);
+    const bool pinf = FQ_ISZERO(p.z), qinf = FQ_ISZERO(q.z);
     Fe Z1Z1 = FQ_SQR(p.z), Z2Z2 = FQ_SQR(q.z);
     Fe U1 = FQ_MUL(p.x, Z2Z2), U2 = FQ_MUL(q.x, Z1Z1);
     Fe S1 = FQ_MUL(FQ_MUL(p.y, q.z), Z2Z2), S2 = FQ_MUL(FQ_MUL(q.y, p.z), Z1Z1);
-    Fe H = fe_sub<FQ>(U2, U1);
-    Fe rr = fe_dbl<FQ>(fe_sub<FQ>(S2, S1));
+    Fe H = FQ_SUB(U2, U1);
+    Fe rr = FQ_DBL(FQ_SUB(S2, S1));
     G1 out;
-    if (!pinf && !qinf && fe_is_zero(H)) {  // same x: doubling or inverse points (rare, divergent)
-        if (fe_is_zero(rr)) return g1_double(p);
+    if (!pinf && !qinf && FQ_ISZERO(H)) {  // same x: doubling or inverse points (rare, divergent)
+        if (FQ_ISZERO(rr)) return g1_double(p);
         return g1_identity();
     }
-    Fe I = FQ_SQR(fe_dbl<FQ>(H));
+    Fe I = FQ_SQR(FQ_DBL(H));
     Fe J = FQ_MUL(H, I);
     Fe V = FQ_MUL(U1, I);
-    out.x = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(rr), J), fe_dbl<FQ>(V));
-    out.y = fe_sub<FQ>(FQ_MUL(rr, fe_sub<FQ>(V, out.x)), fe_dbl<FQ>(FQ_MUL(S1, J)));
-    Fe zz = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(fe_add<FQ>(p.z, q.z)), Z1Z1), Z2Z2);
+    out.x = FQ_SUB(FQ_SUB(FQ_SQR(rr), J), FQ_DBL(V));
+    out.y = FQ_SUB(FQ_MUL(rr, FQ_SUB(V, out.x)), FQ_DBL(FQ_MUL(S1, J)));
+    Fe zz = FQ_SUB(FQ_SUB(FQ_SQR(FQ_ADD(p.z, q.z)), Z1Z1), Z2Z2);
     out.z = FQ_MUL(zz, H);
     out = g1_select(qinf, p, out);
     out = g1_select(pinf, q, out);
@@ -107,26 +175,26 @@ __device__ __noinline__ G1 g1_add(G1 p, G1 q) {
 }
 // mixed addition madd-2007-bl: Jacobian p + affine (x2, y2), never called with an affine identity
 __device__ __noinline__ G1 g1_madd(G1 p, Fe x2, Fe y2) {
-    const bool pinf = fe_is_zero(p.z);
+    const bool pinf = FQ_ISZERO(p.z);
     Fe Z1Z1 = FQ_SQR(p.z);
     Fe U2 = FQ_MUL(x2, Z1Z1);
     Fe S2 = FQ_MUL(FQ_MUL(y2, p.z), Z1Z1);
-    Fe H = fe_sub<FQ>(U2, p.x);
-    Fe rr = fe_dbl<FQ>(fe_sub<FQ>(S2, p.y));
+    Fe H = FQ_SUB(U2, p.x);
+    Fe rr = FQ_DBL(FQ_SUB(S2, p.y));
     G1 q;
     q.x = x2; q.y = y2; q.z = fe_one<FQ>();
-    if (!pinf && fe_is_zero(H)) {          // same x: the bucket holds this point already (double) or its negative
-        if (fe_is_zero(rr)) return g1_double(q);
+    if (!pinf && FQ_ISZERO(H)) {          // same x: the bucket holds this point already (double) or its negative
+        if (FQ_ISZERO(rr)) return g1_double(q);
         return g1_identity();
     }
     Fe HH = FQ_SQR(H);
-    Fe I = fe_dbl<FQ>(fe_dbl<FQ>(HH));
+    Fe I = FQ_DBL(FQ_DBL(HH));
     Fe J = FQ_MUL(H, I);
     Fe V = FQ_MUL(p.x, I);
     G1 out;
-    out.x = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(rr), J), fe_dbl<FQ>(V));
-    out.y = fe_sub<FQ>(FQ_MUL(rr, fe_sub<FQ>(V, out.x)), fe_dbl<FQ>(FQ_MUL(p.y, J)));
-    out.z = fe_sub<FQ>(fe_sub<FQ>(FQ_SQR(fe_add<FQ>(p.z, H)), Z1Z1), HH);
+    out.x = FQ_SUB(FQ_SUB(FQ_SQR(rr), J), FQ_DBL(V));
+    out.y = FQ_SUB(FQ_MUL(rr, FQ_SUB(V, out.x)), FQ_DBL(FQ_MUL(p.y, J)));
+    out.z = FQ_SUB(FQ_SUB(FQ_SQR(FQ_ADD(p.z, H)), Z1Z1), HH);
     return g1_select(pinf, q, out);
 }
 // window table T[k-1] = k*P for k = 1..15 in the HBM workspace: even entries by doubling (7 Fq-mults) the half entry read
@@ -253,14 +321,14 @@ __device__ __forceinline__ G1 g1_scalar_mul_glv(const G1& p, const Fe& s_mont, u
         const u32 d2 = (h2.mag[w >> 3] >> (4 * (w & 7))) & 15u;
         if (__any(d1 != 0)) {
             G1 q = g1_load(tab + ((size_t)(d1 ? d1 - 1 : 0) * nthreads + tid) * 12);
-            if (h1.neg) q.y = fe_neg<FQ>(q.y);
+            if (h1.neg) q.y = FQ_NEG(q.y);
             G1 sum = g1_add(acc, q);
             acc = g1_select(d1 != 0, sum, acc);
         }
         if (__any(d2 != 0)) {
             G1 q = g1_load(tab + ((size_t)(d2 ? d2 - 1 : 0) * nthreads + tid) * 12);
             q.x = FQ_MUL(q.x, beta);                 // phi on Jacobian coordinates: (beta X, Y, Z)
-            if (h2.neg) q.y = fe_neg<FQ>(q.y);
+            if (h2.neg) q.y = FQ_NEG(q.y);
             G1 sum = g1_add(acc, q);
             acc = g1_select(d2 != 0, sum, acc);
         }
@@ -314,14 +382,14 @@ __device__ __forceinline__ G1 g1_scalar_mul_glv5(const G1& p, const Fe& s_mont, 
         const u32 m1 = e1 & 31u, m2 = e2 & 31u;
         if (__any(m1 != 0)) {
             G1 q = g1_load(tab + ((size_t)(m1 ? m1 - 1 : 0) * nthreads + tid) * 12);
-            if (h1.neg != (bool)(e1 >> 5)) q.y = fe_neg<FQ>(q.y);
+            if (h1.neg != (bool)(e1 >> 5)) q.y = FQ_NEG(q.y);
             G1 sum = g1_add(acc, q);
             acc = g1_select(m1 != 0, sum, acc);
         }
         if (__any(m2 != 0)) {
             G1 q = g1_load(tab + ((size_t)(m2 ? m2 - 1 : 0) * nthreads + tid) * 12);
             q.x = FQ_MUL(q.x, beta);                 // phi on Jacobian coordinates: (beta X, Y, Z)
-            if (h2.neg != (bool)(e2 >> 5)) q.y = fe_neg<FQ>(q.y);
+            if (h2.neg != (bool)(e2 >> 5)) q.y = FQ_NEG(q.y);
             G1 sum = g1_add(acc, q);
             acc = g1_select(m2 != 0, sum, acc);
         }
@@ -360,11 +428,11 @@ __device__ __noinline__ Fe fq_inv(const Fe& a) {
     return acc;
 }
 __device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& inf) {
-    inf = fe_is_zero(a.z);
+    inf = FQ_ISZERO(a.z);
     Fe zi = fq_inv(a.z);  // 0 -> 0
     Fe zi2 = FQ_SQR(zi);
-    x = FQ_MUL(a.x, zi2);
-    y = FQ_MUL(a.y, FQ_MUL(zi2, zi));
+    x = FQ_CANON(FQ_MUL(a.x, zi2));
+    y = FQ_CANON(FQ_MUL(a.y, FQ_MUL(zi2, zi)));
     if (inf) { x = fe_zero<FQ>(); y = fe_zero<FQ>(); }
 }
 
@@ -482,7 +550,7 @@ __global__ void __launch_bounds__(TPB_EC) k_point_mac_verify(size_t n, const u64
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     G1 s = g1_add(g1_load(mine + 12 * i), g1_load(peer + 12 * i));
-    ok[i] = fe_is_zero(s.z) ? 1 : 0;
+    ok[i] = FQ_ISZERO(s.z) ? 1 : 0;
 }
 __global__ void __launch_bounds__(TPB_EC) k_pointshare_extract(size_t n, const u64* shares, u64* out) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
@@ -505,7 +573,7 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_to_bytes(size_t n, const u64* pts
     if (i >= n) return;
     Fe x, y; bool inf;
     g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
-    Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(fe_neg<FQ>(y));
+    Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(FQ_NEG(y));
     // y > -y  <=>  (-y) - y borrows
     u32 br = 0, bo;
 #pragma unroll
@@ -537,8 +605,8 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_from_bytes(size_t n, const unsign
     G1 r = g1_identity();
     if (valid && !inf) {
         const Fe x = fe_from_canonical<FQ>(xc);
-        const Fe three = fe_add<FQ>(fe_dbl<FQ>(fe_one<FQ>()), fe_one<FQ>());
-        const Fe rhs = fe_add<FQ>(FQ_MUL(FQ_SQR(x), x), three);
+        const Fe three = FQ_ADD(FQ_DBL(fe_one<FQ>()), fe_one<FQ>());
+        const Fe rhs = FQ_ADD(FQ_MUL(FQ_SQR(x), x), three);
         u32 e[8], cy = 1;                             // e = (q + 1) / 4
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const u64 t = (u64)P::P(k) + cy; e[k] = (u32)t; cy = (u32)(t >> 32); }
@@ -554,8 +622,8 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_from_bytes(size_t n, const unsign
                 if ((w >> bit) & 1u) y = FQ_MUL(y, rhs);
             }
         }
-        valid = fe_eq(FQ_SQR(y), rhs);
-        const Fe ny = fe_neg<FQ>(y);
+        valid = FQ_EQ(FQ_SQR(y), rhs);
+        const Fe ny = FQ_NEG(y);
         const Fe yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(ny);
         u32 b2 = 0;
 #pragma unroll
@@ -644,7 +712,7 @@ __global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* p
     // to_bytes(P): compressed encoding, as four little-endian u64 lanes (curve.rs:103-108)
     Fe x, y; bool inf;
     g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
-    Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(fe_neg<FQ>(y));
+    Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(FQ_NEG(y));
     u32 br = 0, bo;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nyc.v[k], yc.v[k], br, &bo); br = bo; }

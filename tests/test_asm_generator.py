@@ -55,3 +55,11 @@ def test_committed_header_is_current(tmp_path):
     g.emit_header(str(out))
     committed = open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "asm_kernels.inc")).read()
     assert out.read_text() == committed, "regenerate with: python tools/gen_asm_kernels.py"
+
+
+def test_montmul_block_lazy_range_bn254_fq():
+    """Inputs anywhere in [0, 2q) give an output in [0, 2q): the range the BN254 point formulas keep coordinates in."""
+    name, p = g.FIELDS[3]
+    assert name == "BN254_FQ" and g.selftest_montmul_lazy(p)
+    with pytest.raises(AssertionError):
+        g.selftest_montmul_lazy(g.FIELDS[4][1], trials=1)          # 2^255 - 19: 4q exceeds 2^256, no lazy range there

@@ -528,6 +528,27 @@ def selftest_montmul(p, trials=200, seed=3):
     return E, mp
 
 
+def selftest_montmul_lazy(p, trials=300, seed=5):
+    """The lazy range used by the BN254 point formulas: for inputs anywhere in [0, 2p) the block's output stays in [0, 2p)
+    (needs 4p < 2^256) and is congruent to a*b/R."""
+    assert 4 * p < R
+    rng = random.Random(seed)
+    E, mp = build_montmul(p)
+    Rinv = pow(R, -1, p)
+    edge = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p - 2, (1 << 255) % (2 * p)]
+    for t in range(trials):
+        x = rng.choice(edge) if t < 40 else rng.randrange(2 * p)
+        y = rng.choice(edge) if t < 20 else rng.randrange(2 * p)
+        em = Emu()
+        for i in range(8):
+            em.s[mp["a"][i]] = (x >> (32 * i)) & M32
+            em.s[mp["b"][i]] = (y >> (32 * i)) & M32
+        em.run(E.order)
+        got = sum(em.v[mp["o"][i]] << (32 * i) for i in range(8))
+        assert got < 2 * p and got % p == x * y * Rinv % p, (hex(p), t, hex(x), hex(y))
+    return True
+
+
 def selftest_finish(p, trials=40, seed=1, lds=False):
     rng = random.Random(seed)
     E, mp = build_beaver_finish(p, key_names=["s%d" % (70 + i) for i in range(8)], lds=lds)
