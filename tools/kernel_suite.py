@@ -53,6 +53,8 @@ def main():
     rec("scalar_add", lambda: e.scalar_add(n, sc_a, sc_b, out4), 96)
     rec("scalar_mul", lambda: e.scalar_mul(n, sc_a, sc_b, out4), 96)
     rec("scalar_to_bytes_be (K6)", lambda: e.scalar_to_bytes_be(n, sc_a, outb), 64)
+    rec("scalar_batch_inverse", lambda: e.scalar_batch_inverse(n, sc_a, out4), 64, reps=5)
+    rec("scalar_prefix_product", lambda: e.scalar_prefix_product(n, sc_a, out4), 64, reps=5)
     rec("share_add", lambda: e.share_add(n, sh_a, sh_b, out8), 192)
     rec("share_mul_public", lambda: e.share_mul_public(n, sh_a, sc_b, out8), 160)
     rec("share_add_public", lambda: e.share_add_public(n, 0, key, sh_a, sc_b, out8), 160)
