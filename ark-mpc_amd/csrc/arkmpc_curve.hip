@@ -427,6 +427,41 @@ __device__ __noinline__ Fe fq_inv(const Fe& a) {
     }
     return acc;
 }
+// z^-1 for a batch of points with Montgomery's trick: a thread owns K points strided by the thread count and spends ONE
+// Fermat exponentiation on them (3 + 380/K multiplications per point instead of ~390); running products go to `pre`.
+// Identities (z = 0) are skipped and get 0.  Results are in the lazy range (scratch, not ABI memory).
+__global__ void __launch_bounds__(TPB_EC) k_g1_zinv(size_t n, u32 K, size_t nthreads, const u64* pts, u64* pre, u64* zinv) {
+    const size_t t = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (t >= nthreads) return;
+    Fe run = fe_one<FQ>();
+    for (u32 j = 0; j < K; ++j) {
+        const size_t i = (size_t)j * nthreads + t;
+        if (i >= n) break;
+        const Fe z = fe_load(pts + 12 * i + 8);
+        if (!FQ_ISZERO(z)) run = FQ_MUL(run, z);
+        fe_store(pre + 4 * i, run);
+    }
+    Fe inv = fq_inv(run);
+    for (int j = (int)K - 1; j >= 0; --j) {
+        const size_t i = (size_t)j * nthreads + t;
+        if (i >= n) continue;
+        const Fe z = fe_load(pts + 12 * i + 8);
+        Fe o = fe_zero<FQ>();
+        if (!FQ_ISZERO(z)) {
+            const Fe before = (j == 0) ? fe_one<FQ>() : fe_load(pre + 4 * ((size_t)(j - 1) * nthreads + t));
+            o = FQ_MUL(inv, before);
+            inv = FQ_MUL(inv, z);
+        }
+        fe_store(zinv + 4 * i, o);
+    }
+}
+__device__ __forceinline__ void g1_to_affine_zi(const G1& a, const Fe& zi, Fe& x, Fe& y, bool& inf) {
+    inf = FQ_ISZERO(a.z);
+    Fe zi2 = FQ_SQR(zi);
+    x = FQ_CANON(FQ_MUL(a.x, zi2));
+    y = FQ_CANON(FQ_MUL(a.y, FQ_MUL(zi2, zi)));
+    if (inf) { x = fe_zero<FQ>(); y = fe_zero<FQ>(); }
+}
 __device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& inf) {
     inf = FQ_ISZERO(a.z);
     Fe zi = fq_inv(a.z);  // 0 -> 0
@@ -557,22 +592,22 @@ __global__ void __launch_bounds__(TPB_EC) k_pointshare_extract(size_t n, const u
     if (i >= n) return;
     g1_store(out + 12 * i, g1_load(shares + 24 * i));
 }
-__global__ void __launch_bounds__(TPB_EC) k_g1_to_affine(size_t n, const u64* pts, u64* out_xy, unsigned char* out_inf) {
+__global__ void __launch_bounds__(TPB_EC) k_g1_to_affine(size_t n, const u64* pts, const u64* zinv, u64* out_xy, unsigned char* out_inf) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     Fe x, y; bool inf;
-    g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
+    g1_to_affine_zi(g1_load(pts + 12 * i), fe_load(zinv + 4 * i), x, y, inf);
     fe_store(out_xy + 8 * i, x);
     fe_store(out_xy + 8 * i + 4, y);
     out_inf[i] = inf ? 1 : 0;
 }
 // CurvePoint::to_bytes (curve.rs:103-108) = ark-serialize compressed SW encoding: x little-endian,
 // bit 7 of the last byte set iff y > -y (as integers), bit 6 set (and x = 0) for the identity.
-__global__ void __launch_bounds__(TPB_EC) k_g1_to_bytes(size_t n, const u64* pts, unsigned char* out) {
+__global__ void __launch_bounds__(TPB_EC) k_g1_to_bytes(size_t n, const u64* pts, const u64* zinv, unsigned char* out) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     Fe x, y; bool inf;
-    g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
+    g1_to_affine_zi(g1_load(pts + 12 * i), fe_load(zinv + 4 * i), x, y, inf);
     Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(FQ_NEG(y));
     // y > -y  <=>  (-y) - y borrows
     u32 br = 0, bo;
@@ -706,12 +741,12 @@ __device__ __forceinline__ void keccak_f1600_dev(u64 (&a)[25]) {
 }
 __device__ __forceinline__ u64 limb64(const Fe& f, int i) { return (u64)f.v[2 * i] | ((u64)f.v[2 * i + 1] << 32); }
 
-__global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* pts, const u64* blinders, u64* out) {
+__global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* pts, const u64* zinv, const u64* blinders, u64* out) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     // to_bytes(P): compressed encoding, as four little-endian u64 lanes (curve.rs:103-108)
     Fe x, y; bool inf;
-    g1_to_affine(g1_load(pts + 12 * i), x, y, inf);
+    g1_to_affine_zi(g1_load(pts + 12 * i), fe_load(zinv + 4 * i), x, y, inf);
     Fe xc = fe_to_canonical<FQ>(x), yc = fe_to_canonical<FQ>(y), nyc = fe_to_canonical<FQ>(FQ_NEG(y));
     u32 br = 0, bo;
 #pragma unroll
@@ -765,6 +800,14 @@ static int gen_table(arkmpc_ctx* ctx, const u64** out) {
     }
     *out = g_gen_table[dev];
     return ARKMPC_OK;
+}
+
+// batched z^-1 of n points into scratch (two 32-byte columns: running products, inverses)
+static void launch_zinv(arkmpc_ctx* ctx, size_t n, const u64* pts, u64* pre, u64* zinv) {
+    size_t k = n >> 15;
+    const u32 K = (u32)(k < 8 ? 8 : (k > 64 ? 64 : k));
+    const size_t threads = (n + K - 1) / K;
+    hipLaunchKernelGGL(k_g1_zinv, dim3(blocks_for(threads, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, K, threads, pts, pre, zinv);
 }
 
 extern "C" {
@@ -926,25 +969,39 @@ int arkmpc_commit_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points,
     ENTER_EC(ctx);
     Stage st(ctx);
     int ip = st.declare_in(points, n * 96), ib = st.declare_in(blinders, n * 32), io = st.declare_out(out_commitments, n * 32);
+    int iz = st.declare_scratch(n * 64 + 64);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_commit_points, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.in<u64>(ib), st.out<u64>(io));
+    if (n) {
+        launch_zinv(ctx, n, st.in<u64>(ip), st.scratch<u64>(iz), st.scratch<u64>(iz) + 4 * n);
+        hipLaunchKernelGGL(k_commit_points, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.scratch<u64>(iz) + 4 * n,
+                           st.in<u64>(ib), st.out<u64>(io));
+    }
     return st.finish();
 }
 int arkmpc_g1_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy, uint8_t* out_inf) {
     ENTER_EC(ctx);
     Stage st(ctx);
     int ip = st.declare_in(points, n * 96), io = st.declare_out(out_xy, n * 64), ii = st.declare_out(out_inf, n);
+    int iz = st.declare_scratch(n * 64 + 64);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_g1_to_affine, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.out<u64>(io),
-                              st.out<unsigned char>(ii));
+    if (n) {
+        launch_zinv(ctx, n, st.in<u64>(ip), st.scratch<u64>(iz), st.scratch<u64>(iz) + 4 * n);
+        hipLaunchKernelGGL(k_g1_to_affine, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.scratch<u64>(iz) + 4 * n,
+                           st.out<u64>(io), st.out<unsigned char>(ii));
+    }
     return st.finish();
 }
 int arkmpc_g1_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes) {
     ENTER_EC(ctx);
     Stage st(ctx);
     int ip = st.declare_in(points, n * 96), io = st.declare_out(out_bytes, n * 32);
+    int iz = st.declare_scratch(n * 64 + 64);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_g1_to_bytes, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.out<unsigned char>(io));
+    if (n) {
+        launch_zinv(ctx, n, st.in<u64>(ip), st.scratch<u64>(iz), st.scratch<u64>(iz) + 4 * n);
+        hipLaunchKernelGGL(k_g1_to_bytes, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, st.in<u64>(ip), st.scratch<u64>(iz) + 4 * n,
+                           st.out<unsigned char>(io));
+    }
     return st.finish();
 }
 

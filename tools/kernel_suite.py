@@ -75,6 +75,14 @@ def main():
         t = timeit(lambda: e.g1_add(m, pts, outp, outp), reps=5)
         print("g1_add (K7)                  %8.3f ms  %10.3e add/s" % (t * 1e3, m / t), flush=True)
         rows.append({"op": "g1_add", "add_per_s": m / t, "ms": t * 1e3})
+        outb32 = torch.empty(32 * m, dtype=torch.uint8, device="cuda")
+        t = timeit(lambda: e.g1_to_bytes(m, outp, outb32), reps=5)
+        print("g1_to_bytes                  %8.3f ms  %10.3e points/s" % (t * 1e3, m / t), flush=True)
+        rows.append({"op": "g1_to_bytes", "points_per_s": m / t, "ms": t * 1e3})
+        bl = rnd(e, m, g); cm = torch.empty(4 * m, dtype=torch.int64, device="cuda")
+        t = timeit(lambda: e.commit_points_sha3(m, outp, bl, cm), reps=5)
+        print("commit_points_sha3 (K9)      %8.3f ms  %10.3e commitments/s" % (t * 1e3, m / t), flush=True)
+        rows.append({"op": "commit_points_sha3", "commitments_per_s": m / t, "ms": t * 1e3})
     print(json.dumps(rows))
 
 
