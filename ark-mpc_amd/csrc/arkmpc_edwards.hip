@@ -149,21 +149,42 @@ __global__ void __launch_bounds__(TPB_ED) k_edshare_add_public(size_t n, int par
     ed_store(out + 32 * i, sh);
     ed_store(out + 32 * i + 16, mac);
 }
-__global__ void __launch_bounds__(TPB_ED) k_ed_to_affine(size_t n, const u64* pts, u64* out_xy) {
+// z^-1 of a batch of points with Montgomery's trick (z is never 0 on this curve): K points per thread, strided by the thread
+// count, one Fermat exponentiation per thread; running products in `pre`
+__global__ void __launch_bounds__(TPB_ED) k_ed_zinv(size_t n, u32 K, size_t nthreads, const u64* pts, u64* pre, u64* zinv) {
+    const size_t t = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (t >= nthreads) return;
+    Fe run = fe_one<EQ>();
+    for (u32 j = 0; j < K; ++j) {
+        const size_t i = (size_t)j * nthreads + t;
+        if (i >= n) break;
+        run = EQ_MUL(run, fe_load(pts + 16 * i + 12));
+        fe_store(pre + 4 * i, run);
+    }
+    Fe inv = fe_inv_fermat<EQ>(run);
+    for (int j = (int)K - 1; j >= 0; --j) {
+        const size_t i = (size_t)j * nthreads + t;
+        if (i >= n) continue;
+        const Fe before = (j == 0) ? fe_one<EQ>() : fe_load(pre + 4 * ((size_t)(j - 1) * nthreads + t));
+        fe_store(zinv + 4 * i, EQ_MUL(inv, before));
+        inv = EQ_MUL(inv, fe_load(pts + 16 * i + 12));
+    }
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_to_affine(size_t n, const u64* pts, const u64* zinv, u64* out_xy) {
     size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
     if (i >= n) return;
     Ed p = ed_load(pts + 16 * i);
-    Fe zi = fe_inv_fermat<EQ>(p.z);
+    Fe zi = fe_load(zinv + 4 * i);
     fe_store(out_xy + 8 * i, EQ_MUL(p.x, zi));
     fe_store(out_xy + 8 * i + 4, EQ_MUL(p.y, zi));
 }
 // ark-serialize compressed twisted-Edwards encoding (CurvePoint::to_bytes, curve.rs:103-108): y little-endian, bit 7 of
 // the last byte set iff x > -x (as integers)
-__global__ void __launch_bounds__(TPB_ED) k_ed_to_bytes(size_t n, const u64* pts, unsigned char* out) {
+__global__ void __launch_bounds__(TPB_ED) k_ed_to_bytes(size_t n, const u64* pts, const u64* zinv, unsigned char* out) {
     size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
     if (i >= n) return;
     Ed p = ed_load(pts + 16 * i);
-    Fe zi = fe_inv_fermat<EQ>(p.z);
+    Fe zi = fe_load(zinv + 4 * i);
     Fe x = EQ_MUL(p.x, zi), y = EQ_MUL(p.y, zi);
     Fe xc = fe_to_canonical<EQ>(x), nxc = fe_to_canonical<EQ>(fe_neg<EQ>(x)), yc = fe_to_canonical<EQ>(y);
     u32 br = 0, bo;
@@ -333,6 +354,13 @@ static int ed_gen_table(arkmpc_ctx* ctx, const u64** out) {
     return ARKMPC_OK;
 }
 
+static void ed_launch_zinv(arkmpc_ctx* ctx, size_t n, const u64* pts, u64* pre, u64* zinv) {
+    size_t k = n >> 15;
+    const u32 K = (u32)(k < 8 ? 8 : (k > 64 ? 64 : k));
+    const size_t threads = (n + K - 1) / K;
+    hipLaunchKernelGGL(k_ed_zinv, dim3(blocks_for(threads, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, K, threads, pts, pre, zinv);
+}
+
 #define ENTER_ED(ctx)                                                                           \
     if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
     CtxGuard guard__(ctx);                                                                      \
@@ -426,9 +454,12 @@ int arkmpc_edshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uin
 int arkmpc_ed_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy) {
     ENTER_ED(ctx);
     Stage st(ctx);
-    int ip = st.declare_in(points, n * 128), io = st.declare_out(out_xy, n * 64);
+    int ip = st.declare_in(points, n * 128), io = st.declare_out(out_xy, n * 64), iz = st.declare_scratch(n * 64 + 64);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_ed_to_affine, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.out<u64>(io));
+    if (n) {
+        ed_launch_zinv(ctx, n, st.in<u64>(ip), st.scratch<u64>(iz), st.scratch<u64>(iz) + 4 * n);
+        hipLaunchKernelGGL(k_ed_to_affine, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.scratch<u64>(iz) + 4 * n, st.out<u64>(io));
+    }
     return st.finish();
 }
 int arkmpc_ed_from_bytes(arkmpc_ctx* ctx, size_t n, const uint8_t* bytes, uint64_t* out_points, uint8_t* out_ok) {
@@ -443,9 +474,13 @@ int arkmpc_ed_from_bytes(arkmpc_ctx* ctx, size_t n, const uint8_t* bytes, uint64
 int arkmpc_ed_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes) {
     ENTER_ED(ctx);
     Stage st(ctx);
-    int ip = st.declare_in(points, n * 128), io = st.declare_out(out_bytes, n * 32);
+    int ip = st.declare_in(points, n * 128), io = st.declare_out(out_bytes, n * 32), iz = st.declare_scratch(n * 64 + 64);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_ed_to_bytes, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.out<unsigned char>(io));
+    if (n) {
+        ed_launch_zinv(ctx, n, st.in<u64>(ip), st.scratch<u64>(iz), st.scratch<u64>(iz) + 4 * n);
+        hipLaunchKernelGGL(k_ed_to_bytes, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.scratch<u64>(iz) + 4 * n,
+                           st.out<unsigned char>(io));
+    }
     return st.finish();
 }
 
