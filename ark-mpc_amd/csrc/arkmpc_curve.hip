@@ -89,7 +89,7 @@ __device__ __forceinline__ bool fq_is_zero_lz(const Fe& a) {                 // 
 #define FQ_SUB(a, b) fe_sub<F_BN254_FQ>(a, b)
 #define FQ_NEG(a) fe_neg<F_BN254_FQ>(a)
 #define FQ_CANON(a) (a)
-#define FQ_ISZERO(a) FQ_ISZERO(a)
+#define FQ_ISZERO(a) fe_is_zero(a)
 #endif
 #define FQ_SQR(a) FQ_MUL(a, a)
 #define FQ_DBL(a) FQ_ADD(a, a)
