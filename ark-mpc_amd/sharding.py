@@ -16,18 +16,32 @@ def shard_sizes(n, world):
     return [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
 
 
-def gather_ordered(local, n_total, words_per_elem, group=None):
+def gather_ordered(local, n_total, words_per_elem, group=None, out=None):
     """All-gather per-rank slices (int64 limb tensors, `words_per_elem` limbs per element) into the full
-    ordered buffer on every rank.  Uneven shards are padded to the largest shard for the collective."""
+    ordered buffer on every rank.  Even shards (n_total divisible by the world size -- every BASELINE config):
+    ONE all_gather_into_tensor straight into the final buffer (rank r's slice lands at r * slice), no staging
+    copy.  Uneven shards (not a BASELINE shape): the collective needs equal pieces, so ranks exchange
+    max-sized pieces and each is copied to its place.  `out` lets the caller supply the destination (e.g.
+    the buffer the commitment hashes)."""
     world = dist.get_world_size(group)
     sizes = shard_sizes(n_total, world)
+    if local.numel() != sizes[dist.get_rank(group)] * words_per_elem:
+        raise ValueError("local slice has %d words, expected %d" % (local.numel(), sizes[dist.get_rank(group)] * words_per_elem))
+    if out is None:
+        out = torch.empty(n_total * words_per_elem, dtype=local.dtype, device=local.device)
+    if len(set(sizes)) == 1:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     mx = max(sizes) * words_per_elem
-    pad = torch.zeros(mx, dtype=local.dtype, device=local.device)
-    pad[: local.numel()] = local
-    out = torch.empty(world * mx, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    parts = [out[r * mx: r * mx + sizes[r] * words_per_elem] for r in range(world)]
-    return torch.cat(parts)
+    send = local if local.numel() == mx else torch.cat([local, local.new_zeros(mx - local.numel())])
+    recv = [torch.empty(mx, dtype=local.dtype, device=local.device) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    off = 0
+    for r in range(world):
+        cnt = sizes[r] * words_per_elem
+        out[off:off + cnt] = recv[r][:cnt]
+        off += cnt
+    return out
 
 
 def all_ok(local_ok, device, group=None):

@@ -816,3 +816,80 @@ void ora_edshare_batch_add_public(size_t n, int party, const u64 key[4], const u
         ora_ed_add(shares + 32 * i + 16, kp, out + 32 * i + 16);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Range-parallel forms of batch functions above, for the full-size parity tests (BASELINE sizes: 2^24 shares,
+ * 2^18 PointShare x Scalar): the SAME per-element functions, a static contiguous range split over pthreads.
+ * Elements are independent in the reference as well (authenticated_scalar.rs:299-311, curve/share.rs:108-114).
+ * ---------------------------------------------------------------------------------------- */
+typedef void (*range_fn)(void* ctx, size_t lo, size_t hi);
+typedef struct { range_fn fn; void* ctx; size_t lo, hi; } range_job;
+static void* range_worker(void* arg) { range_job* j = (range_job*)arg; if (j->hi > j->lo) j->fn(j->ctx, j->lo, j->hi); return 0; }
+static void par_for(size_t n, int nthreads, range_fn fn, void* ctx) {
+    init_fields();
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    if (nthreads == 1) { if (n) fn(ctx, 0, n); return; }
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+    range_job* jobs = (range_job*)malloc(sizeof(range_job) * nthreads);
+    char* started = (char*)calloc(nthreads, 1);
+    for (int t = 0; t < nthreads; ++t) {
+        range_job j = {fn, ctx, n * t / nthreads, n * (t + 1) / nthreads};
+        jobs[t] = j;
+        if (pthread_create(&th[t], 0, range_worker, &jobs[t]) == 0) started[t] = 1;
+        else range_worker(&jobs[t]);          /* could not spawn: run the range inline */
+    }
+    for (int t = 0; t < nthreads; ++t) if (started[t]) pthread_join(th[t], 0);
+    free(th); free(jobs); free(started);
+}
+
+typedef struct { int fid; const u64 *key, *shares, *peer; u64 *opened, *chk; } omc_ctx;
+static void omc_range(void* p, size_t lo, size_t hi) {
+    omc_ctx* c = (omc_ctx*)p;
+    const ora_field* f = ora_get_field(c->fid);
+    for (size_t i = lo; i < hi; ++i)                                  /* open_batch combine gate :161-171 on the `.share()` halves */
+        ora_fp_add(f, c->shares + 8 * i, c->peer + 4 * i, c->opened + 4 * i);
+    ora_mac_check_shares(c->fid, hi - lo, c->key, c->opened + 4 * lo, c->shares + 8 * lo, c->chk + 4 * lo);   /* :299-311 */
+}
+/* open_authenticated_batch, one party's local work (authenticated_scalar.rs:278-311): opened_i = share_i + peer_i,
+ * chk_i = mac_key * opened_i - mac_i */
+void ora_open_and_mac_check_mt(int fid, size_t n, const u64 key[4], const u64* shares, const u64* peer, u64* out_opened,
+                               u64* out_chk, int nthreads) {
+    omc_ctx c = {fid, key, shares, peer, out_opened, out_chk};
+    par_for(n, nthreads, omc_range, &c);
+}
+
+typedef struct { const u64 *shares, *scalars; u64* out; } psm_ctx;
+static void psm_range(void* p, size_t lo, size_t hi) {
+    psm_ctx* c = (psm_ctx*)p;
+    ora_pointshare_batch_mul_public(hi - lo, c->shares + 24 * lo, c->scalars + 4 * lo, c->out + 24 * lo);
+}
+void ora_pointshare_batch_mul_public_mt(size_t n, const u64* shares, const u64* scalars, u64* out, int nthreads) {
+    psm_ctx c = {shares, scalars, out};
+    par_for(n, nthreads, psm_range, &c);
+}
+
+typedef struct { const u64* pts; u64* xy; unsigned char* inf; } aff_ctx;
+static void aff_range(void* p, size_t lo, size_t hi) {
+    aff_ctx* c = (aff_ctx*)p;
+    ora_g1_batch_to_affine(hi - lo, c->pts + 12 * lo, c->xy + 8 * lo, c->inf + lo);
+}
+void ora_g1_batch_to_affine_mt(size_t n, const u64* pts, u64* out_xy, unsigned char* is_inf, int nthreads) {
+    aff_ctx c = {pts, out_xy, is_inf};
+    par_for(n, nthreads, aff_range, &c);
+}
+
+typedef struct { int fid; size_t n; const u64 *x, *y, *a, *b; u64* de; } bmk_ctx;
+static void bmk_range(void* p, size_t lo, size_t hi) {
+    bmk_ctx* c = (bmk_ctx*)p;
+    const ora_field* f = ora_get_field(c->fid);
+    for (size_t i = lo; i < hi; ++i) {                                /* ora_beaver_mask on a range of the full d||e buffer */
+        ora_fp_sub(f, c->x + 8 * i, c->a + 8 * i, c->de + 4 * i);
+        ora_fp_sub(f, c->y + 8 * i, c->b + 8 * i, c->de + 4 * (c->n + i));
+    }
+}
+void ora_beaver_mask_mt(int fid, size_t n, const u64* x, const u64* y, const u64* a, const u64* b, u64* out_de, int nthreads) {
+    bmk_ctx c = {fid, n, x, y, a, b, out_de};
+    par_for(n, nthreads, bmk_range, &c);
+}

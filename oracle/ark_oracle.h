@@ -157,6 +157,14 @@ void ora_dummy_triples(int field_id, int party_id, size_t n, u64* a, u64* b, u64
 void ora_dummy_local_input_masks(int field_id, int party_id, size_t n, u64* masks, u64* mask_shares);
 void ora_dummy_counterparty_input_masks(int field_id, int party_id, size_t n, u64* mask_shares);
 
+/* ---- range-parallel forms (same per-element functions, static range split over pthreads; full-size parity tests) ---- */
+void ora_beaver_mask_mt(int field_id, size_t n, const u64* x, const u64* y, const u64* a, const u64* b, u64* out_de, int nthreads);
+/* one party's local work in open_authenticated_batch (authenticated_scalar.rs:278-311) */
+void ora_open_and_mac_check_mt(int field_id, size_t n, const u64 mac_key[4], const u64* shares, const u64* peer_share_values,
+                               u64* out_opened, u64* out_chk, int nthreads);
+void ora_pointshare_batch_mul_public_mt(size_t n, const u64* shares, const u64* scalars, u64* out, int nthreads);
+void ora_g1_batch_to_affine_mt(size_t n, const u64* pts, u64* out_xy, unsigned char* is_inf, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,6 +205,48 @@ class Oracle:
         n = len(shares) // 32; out = np.zeros(32 * n, dtype=np.uint64)
         self._call("ora_edshare_batch_add_public", n, party, key, shares, pub, out); return out
 
+    # -- range-parallel forms for the full-size parity tests
+    @staticmethod
+    def host_threads():
+        return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def beaver_mask_mt(self, fid, x, y, a, b, nthreads=None):
+        n = len(x) // 8
+        out = np.zeros(2 * n * 4, dtype=np.uint64)
+        self.lib.ora_beaver_mask_mt(ctypes.c_int(fid), ctypes.c_size_t(n), self._p(x), self._p(y), self._p(a), self._p(b), self._p(out),
+                                    ctypes.c_int(nthreads or self.host_threads()))
+        return out
+
+    def batch_mul_9pass_mt(self, fid, party, key, x, y, a, b, c, peer_de, nthreads=None):
+        n = len(a) // 8
+        my_de = np.zeros(2 * n * 4, dtype=np.uint64)
+        out = np.zeros(n * 8, dtype=np.uint64)
+        rc = self.lib.ora_batch_mul_9pass_mt(ctypes.c_int(fid), ctypes.c_size_t(n), ctypes.c_int(party), self._p(key), self._p(x), self._p(y),
+                                             self._p(a), self._p(b), self._p(c), self._p(peer_de), self._p(my_de), self._p(out),
+                                             ctypes.c_int(nthreads or self.host_threads()))
+        assert rc == 0
+        return my_de, out
+
+    def open_and_mac_check_mt(self, fid, key, shares, peer, nthreads=None):
+        n = len(shares) // 8
+        opened = np.zeros(4 * n, dtype=np.uint64); chk = np.zeros(4 * n, dtype=np.uint64)
+        self.lib.ora_open_and_mac_check_mt(ctypes.c_int(fid), ctypes.c_size_t(n), self._p(key), self._p(shares), self._p(peer), self._p(opened),
+                                           self._p(chk), ctypes.c_int(nthreads or self.host_threads()))
+        return opened, chk
+
+    def pointshare_mul_public_mt(self, shares, scalars, nthreads=None):
+        n = len(shares) // 24
+        out = np.zeros(24 * n, dtype=np.uint64)
+        self.lib.ora_pointshare_batch_mul_public_mt(ctypes.c_size_t(n), self._p(shares), self._p(scalars), self._p(out),
+                                                    ctypes.c_int(nthreads or self.host_threads()))
+        return out
+
+    def g1_batch_to_affine_mt(self, pts, nthreads=None):
+        n = len(pts) // 12
+        xy = np.zeros(8 * n, dtype=np.uint64); inf = np.zeros(n, dtype=np.uint8)
+        self.lib.ora_g1_batch_to_affine_mt(ctypes.c_size_t(n), self._p(pts), self._p(xy), self._p(inf), ctypes.c_int(nthreads or self.host_threads()))
+        return xy, inf
+
     # -- PartyIDBeaverSource
     def dummy_mac_key_share(self, fid, party):
         out = np.zeros(4, dtype=np.uint64); self._call("ora_dummy_mac_key_share", fid, party, out); return out
