@@ -24,6 +24,10 @@ struct arkmpc_ctx {
     // small device word for reductions (mac_verify) + pinned mirror
     int* d_flag = nullptr;
     int* h_flag = nullptr;
+    // MAC-verify flag: ONE word of host-coherent mapped memory that failing waves store into directly (no memset / D2H per call);
+    // h_vflag is the host address, d_vflag its device alias.  Sticky between arkmpc_mac_verify_async calls.
+    int* h_vflag = nullptr;
+    int* d_vflag = nullptr;
     // pinned double buffer for the commitment pipeline
     unsigned char* h_pin[2] = {nullptr, nullptr};
     size_t h_pin_cap = 0;

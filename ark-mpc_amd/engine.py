@@ -207,6 +207,11 @@ class Engine:
         ok = ctypes.c_int(-1)
         self.call("mac_verify", ("size", n), mine, peer, ("ref", ctypes.byref(ok)))
         return bool(ok.value)
+    def mac_verify_async(self, n, mine, peer): self.call("mac_verify_async", ("size", n), mine, peer)
+    def mac_verify_result(self):
+        ok = ctypes.c_int(-1)
+        self._ck(self.lib.arkmpc_mac_verify_result(self.h, ctypes.byref(ok)))
+        return bool(ok.value)
     def commit_sha3(self, n, values, blinder):
         out = np.zeros(4, dtype=np.uint64)
         self.call("commit_sha3", ("size", n), values, ("key", blinder), out)

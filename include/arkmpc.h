@@ -156,6 +156,11 @@ int arkmpc_open_and_mac_check(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[
                               const uint64_t* peer_share_values, uint64_t* out_opened, uint64_t* out_chk);
 /* K5  all(mine_i + peer_i == 0) (:218-219).  Blocking; *out_ok = 1 or 0. */
 int arkmpc_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, int* out_ok);
+/* Non-blocking form for callers that verify several ranges (sharded batches, the two parties of a mock run): _async enqueues K5
+ * on the context's stream and returns; failures accumulate in a per-context sticky flag.  _result waits for the stream, reports
+ * 1 iff NO range verified since the last collection failed, and clears the flag.  (arkmpc_mac_verify = _async + _result.) */
+int arkmpc_mac_verify_async(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer);
+int arkmpc_mac_verify_result(arkmpc_ctx* ctx, int* out_ok);
 /* H1  HashCommitmentResult::batch_commit / HashCommitment::verify (commitment.rs:63-89, :30-43):
  *     out = from_be_bytes_mod_order(SHA3-256(BE(v_0)||...||BE(v_{n-1})||BE(blinder))).
  *     K6 runs on the GPU, the sponge on the host (sequential by definition), overlapped with D2H.

@@ -214,3 +214,119 @@ def test_msm_above_chunk_size(pkg):
     tmp = torch.empty(12 * n, dtype=torch.int64, device="cuda"); e.g1_scalar_mul(n, P, sk, tmp)
     ref = torch.empty(12, dtype=torch.int64, device="cuda"); e.g1_sum(n, tmp, ref)
     assert _affine(e, out) == _affine(e, ref)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Full BASELINE sizes against the ORACLE, every word (round-2: the algebraic properties above say the result is a valid
+# sharing of x*y; these say it is the reference's sharing, bit for bit).  The oracle's range-parallel entry points
+# (oracle/ark_oracle.c, *_mt) run the same per-element functions over the host's cores.
+# ------------------------------------------------------------------------------------------------------------------
+def _host(t):
+    return np.ascontiguousarray(t.cpu().numpy().view(np.uint64))
+
+
+@pytest.mark.parametrize("layout", ["aos", "split"])
+def test_config2_all_2p20_gates_bitexact_vs_oracle(pkg, oracle, layout):
+    """BASELINE config 2: 2^20 Beaver muls over BN254 Fr.  Both parties' d||e and result records from the HIP path
+    (hand-scheduled K2+K3 included) == the oracle's literal 9-pass batch_mul (authenticated_scalar.rs:848-879) on ALL gates."""
+    fid, n = 0, 1 << 20
+    e = _eng(pkg, fid)
+    vals, sh, key, keys = _setup(e, n, 0xA11CE002)
+    de = [torch.empty(8 * n, dtype=torch.int64, device="cuda") for _ in (0, 1)]
+    res = [torch.zeros(8 * n, dtype=torch.int64, device="cuda") for _ in (0, 1)]
+    if layout == "aos":
+        for p in (0, 1):
+            e.beaver_mask(n, sh["x"][p], sh["y"][p], sh["a"][p], sh["b"][p], de[p])
+        for p in (0, 1):
+            e.beaver_finish_fused(n, p, keys[p], de[p], de[1 - p], sh["a"][p], sh["b"][p], sh["c"][p], res[p])
+    else:
+        cols = [{k: (torch.empty(4 * n, dtype=torch.int64, device="cuda"), torch.empty(4 * n, dtype=torch.int64, device="cuda")) for k in "xyabco"} for _ in (0, 1)]
+        for p in (0, 1):
+            for k in "xyabc":
+                e.share_split(n, sh[k][p], cols[p][k][0], cols[p][k][1])
+            c = cols[p]
+            e.beaver_mask_v(n, c["x"][0], 4, c["y"][0], 4, c["a"][0], 4, c["b"][0], 4, de[p])
+        for p in (0, 1):
+            c = cols[p]
+            e.beaver_finish_fused_v(n, p, keys[p], de[p], de[1 - p], c["a"][0], c["a"][1], 4, c["b"][0], c["b"][1], 4, c["c"][0], c["c"][1], 4,
+                                    c["o"][0], c["o"][1], 4)
+            e.share_join(n, c["o"][0], c["o"][1], res[p])
+    torch.cuda.synchronize()
+    H = [{k: _host(sh[k][p]) for k in "xyabc"} for p in (0, 1)]
+    ode = [oracle.beaver_mask_mt(fid, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"]) for p in (0, 1)]
+    for p in (0, 1):
+        my_de, want = oracle.batch_mul_9pass_mt(fid, p, keys[p], H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], ode[1 - p])
+        assert np.array_equal(my_de, ode[p])
+        assert np.array_equal(_host(de[p]), ode[p]), "party %d d||e differs from the oracle" % p
+        got = _host(res[p])
+        bad = np.nonzero((got.reshape(n, 8) != want.reshape(n, 8)).any(axis=1))[0]
+        assert bad.size == 0, "party %d: %d of %d gates differ from the oracle, first at %d" % (p, bad.size, n, bad[0])
+    e.close()
+
+
+def test_config5_all_2p24_shares_bitexact_vs_oracle(pkg, oracle):
+    """BASELINE config 5 at its full size on one GPU: open + MAC-check shares over 2^24 BLS12-381 Fr shares, both parties:
+    opened values and MAC-check shares == the oracle's (authenticated_scalar.rs:161-171, :299-311) on ALL shares; the checks
+    verify; one flipped MAC limb in the last share is caught."""
+    fid, n = 1, 1 << 24
+    e = _eng(pkg, fid)
+    g = torch.Generator(device="cuda"); g.manual_seed(0xA11CE005)
+    ks = [_rnd(e, 1, g), _rnd(e, 1, g)]
+    key = torch.empty_like(ks[0]); e.scalar_add(1, ks[0], ks[1], key)
+    keys = [k.cpu().numpy().view(np.uint64).copy() for k in ks]
+    v = _rnd(e, n, g)
+    sh = _share(e, n, v, key, g)
+    mine = []
+    for p in (0, 1):
+        t = torch.empty(4 * n, dtype=torch.int64, device="cuda"); e.share_extract(n, sh[p], t); mine.append(t)
+    opened, chk = [], []
+    for p in (0, 1):
+        o = torch.empty(4 * n, dtype=torch.int64, device="cuda"); c = torch.empty_like(o)
+        e.open_and_mac_check(n, keys[p], sh[p], mine[1 - p], o, c)
+        opened.append(o); chk.append(c)
+    ok = e.mac_verify(n, chk[0], chk[1])
+    torch.cuda.synchronize()
+    assert ok and torch.equal(opened[0], v) and torch.equal(opened[1], v)
+    for p in (0, 1):
+        hs, hp = _host(sh[p]), _host(mine[1 - p])
+        assert np.array_equal(hp, np.ascontiguousarray(_host(sh[1 - p]).reshape(n, 8)[:, :4]).reshape(-1))     # the `.share()` projection
+        want_o, want_c = oracle.open_and_mac_check_mt(fid, keys[p], hs, hp)
+        assert np.array_equal(_host(opened[p]), want_o), "party %d opened values differ from the oracle" % p
+        assert np.array_equal(_host(chk[p]), want_c), "party %d MAC-check shares differ from the oracle" % p
+        del hs, hp, want_o, want_c
+    sh[0][8 * (n - 1) + 4] ^= 1
+    e.open_and_mac_check(n, keys[0], sh[0], mine[1], opened[0], chk[0])
+    assert e.mac_verify(n, chk[0], chk[1]) is False
+    e.close()
+
+
+def test_config4_all_2p18_pointshare_scalar_muls_vs_oracle(pkg, oracle):
+    """BASELINE config 4 at its full size: 2^18 PointShare x public Scalar over BN254 G1 (curve/share.rs:108-114) = 2^19
+    scalar-muls, every result compared with the oracle's double-and-add on AFFINE coordinates (the Jacobian representative
+    depends on the addition chain; arkworks' PartialEq and the wire format see the affine point).  The oracle needs ~0.8 ms per
+    scalar-mul per core, so hosts with fewer than 16 cores check a strided sample of 2^13 elements instead (logged)."""
+    n = 1 << 18
+    e = _eng(pkg, 0)
+    g = torch.Generator(device="cuda"); g.manual_seed(0xA11CE004)
+    k = _rnd(e, 2 * n, g)
+    shares = torch.empty(24 * n, dtype=torch.int64, device="cuda")
+    e.scalarshare_mul_generator(n, k, shares)                      # P_i = k_i G as PointShares (seeded discrete logs)
+    sc = _rnd(e, n, g)
+    out = torch.empty_like(shares)
+    e.pointshare_mul_public(n, shares, sc, out)
+    xy = torch.empty(8 * 2 * n, dtype=torch.int64, device="cuda"); inf = torch.empty(2 * n, dtype=torch.uint8, device="cuda")
+    e.g1_to_affine(2 * n, out, xy, inf)
+    torch.cuda.synchronize()
+    threads = oracle.host_threads()
+    idx = np.arange(n) if threads >= 16 else np.arange(0, n, n >> 13)
+    print("config 4 oracle check: %d of %d PointShares on %d host threads" % (idx.size, n, threads))
+    hs = np.ascontiguousarray(_host(shares).reshape(n, 24)[idx]).reshape(-1)
+    hk = np.ascontiguousarray(_host(sc).reshape(n, 4)[idx]).reshape(-1)
+    want = oracle.pointshare_mul_public_mt(hs, hk)
+    wxy, winf = oracle.g1_batch_to_affine_mt(want)
+    gxy = _host(xy).reshape(n, 16)[idx].reshape(-1, 8)
+    ginf = inf.cpu().numpy().reshape(n, 2)[idx].reshape(-1)
+    assert np.array_equal(ginf, winf)
+    bad = np.nonzero((gxy != wxy.reshape(-1, 8)).any(axis=1))[0]
+    assert bad.size == 0, "%d of %d scalar-muls differ from the oracle, first at %d" % (bad.size, gxy.shape[0], bad[0])
+    e.close()
