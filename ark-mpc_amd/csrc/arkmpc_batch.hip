@@ -1,0 +1,206 @@
+// arkmpc_batch.hip -- the device-batch carrier: an opaque, reference-counted handle to ONE batch value resident in HBM.
+//
+// Why: in the reference every value that flows from gate to gate is a `ResultValue<C>` (fabric/result.rs:47-64) -- a host enum
+// whose batch variants own a `Vec<Scalar>` / `Vec<CurvePoint>`.  A patched fabric that keeps gate outputs on the GPU needs a
+// variant `ResultValue::DeviceBatch(ArkBatch)` whose payload is THIS handle: element kind (which enum variant it stands for),
+// element count, layout tag (arkworks AoS records, or the engine-native split columns for ScalarShares) and the device
+// storage.  Handles are what the batch-level entry points at the bottom take, so a chain of gates (share -> mul -> mul -> open)
+// never round-trips through host vectors; `arkmpc_batch_to_host` materialises the arkworks `Vec<T>` only where the caller
+// awaits a value.  Slices (`&v[lo..hi]`, authenticated_scalar.rs batch ops over sub-ranges, sharding by index range) are views
+// that share the parent's storage and keep it alive.
+#include "arkmpc_internal.hpp"
+#include <atomic>
+
+struct arkmpc_batch {
+    std::atomic<int> refs{1};
+    arkmpc_batch* parent = nullptr;      // a slice holds a reference on the batch that owns the storage
+    int kind = 0, layout = 0, field_id = 0, device = 0;
+    size_t n = 0;
+    u32 words = 0;                       // u64 words per element in the arkworks AoS record
+    u64* base = nullptr;                 // owned allocation (nullptr for slices)
+    u64* share = nullptr;                // element i: share + stride * i   (the whole record for AoS kinds)
+    u64* mac = nullptr;                  // ScalarShare batches only: MAC half of element i at mac + stride * i
+    u32 stride = 0;                      // u64 units
+};
+
+static u32 elem_words(int kind, int field_id) {
+    const bool ed = field_id == ARKMPC_CURVE25519_FR;
+    switch (kind) {
+        case ARKMPC_KIND_SCALAR: return 4;
+        case ARKMPC_KIND_SCALAR_SHARE: return 8;
+        case ARKMPC_KIND_POINT: return ed ? 16 : 12;
+        case ARKMPC_KIND_POINT_SHARE: return ed ? 32 : 24;
+        case ARKMPC_KIND_WORDS: return 1;
+        default: return 0;
+    }
+}
+static bool kind_ok_for_ctx(int kind, int field_id) {
+    if (kind == ARKMPC_KIND_POINT || kind == ARKMPC_KIND_POINT_SHARE) return field_id == ARKMPC_BN254_FR || field_id == ARKMPC_CURVE25519_FR;
+    return elem_words(kind, field_id) != 0;
+}
+static int batch_check(arkmpc_ctx* ctx, const arkmpc_batch* b) {
+    if (!b) return ark_bad(ctx, "null batch");
+    if (b->field_id != ctx->field_id || b->device != ctx->device) return ark_bad(ctx, "batch belongs to a different field / device");
+    return ARKMPC_OK;
+}
+
+extern "C" {
+
+int arkmpc_batch_create(arkmpc_ctx* ctx, int kind, int layout, size_t n, arkmpc_batch** out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (!out) return ark_bad(ctx, "null out");
+    *out = nullptr;
+    if (ctx->host_buffers) return ark_bad(ctx, "batch handles live on device-pointer contexts");
+    if (!kind_ok_for_ctx(kind, ctx->field_id)) return ark_bad(ctx, "element kind not defined for this context");
+    if (layout != ARKMPC_LAYOUT_AOS && !(layout == ARKMPC_LAYOUT_SPLIT && kind == ARKMPC_KIND_SCALAR_SHARE))
+        return ark_bad(ctx, "split layout is defined for ScalarShare batches only");
+    const u32 w = elem_words(kind, ctx->field_id);
+    void* p = nullptr;
+    int rc = arkmpc_malloc(ctx, (n ? n : 1) * (size_t)w * 8 + 16, &p);
+    if (rc) return rc;
+    arkmpc_batch* b = new arkmpc_batch();
+    b->kind = kind; b->layout = layout; b->field_id = ctx->field_id; b->device = ctx->device; b->n = n; b->words = w;
+    b->base = (u64*)p;
+    b->share = b->base;
+    if (kind == ARKMPC_KIND_SCALAR_SHARE) {
+        if (layout == ARKMPC_LAYOUT_SPLIT) { b->stride = 4; b->mac = b->base + 4 * n; }
+        else { b->stride = 8; b->mac = b->base + 4; }
+    } else {
+        b->stride = w;
+    }
+    *out = b;
+    return ARKMPC_OK;
+}
+
+int arkmpc_batch_retain(arkmpc_batch* b) {
+    if (!b) return ARKMPC_ERR_BAD_ARG;
+    b->refs.fetch_add(1, std::memory_order_relaxed);
+    return ARKMPC_OK;
+}
+
+// Drops one reference.  The storage goes back to the pool -- stream-ordered on ctx's stream, like arkmpc_free -- when the
+// last handle (the batch itself and every slice of it) is gone.
+int arkmpc_batch_destroy(arkmpc_ctx* ctx, arkmpc_batch* b) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    int rc = ARKMPC_OK;
+    while (b && b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        arkmpc_batch* parent = b->parent;
+        if (b->base) { int r = arkmpc_free(ctx, b->base); if (r) rc = r; }
+        delete b;
+        b = parent;
+    }
+    return rc;
+}
+
+int arkmpc_batch_slice(arkmpc_ctx* ctx, arkmpc_batch* b, size_t lo, size_t count, arkmpc_batch** out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (!out) return ark_bad(ctx, "null out");
+    *out = nullptr;
+    int rc = batch_check(ctx, b);
+    if (rc) return rc;
+    if (lo > b->n || count > b->n - lo) return ark_bad(ctx, "slice out of range");
+    arkmpc_batch* s = new arkmpc_batch();
+    s->kind = b->kind; s->layout = b->layout; s->field_id = b->field_id; s->device = b->device; s->n = count; s->words = b->words;
+    s->stride = b->stride;
+    s->share = b->share + (size_t)b->stride * lo;
+    s->mac = b->mac ? b->mac + (size_t)b->stride * lo : nullptr;
+    arkmpc_batch* owner = b->parent ? b->parent : b;         // slices of slices point at the owning batch
+    owner->refs.fetch_add(1, std::memory_order_relaxed);
+    s->parent = owner;
+    *out = s;
+    return ARKMPC_OK;
+}
+
+size_t arkmpc_batch_len(const arkmpc_batch* b) { return b ? b->n : 0; }
+int arkmpc_batch_kind(const arkmpc_batch* b) { return b ? b->kind : -1; }
+int arkmpc_batch_layout(const arkmpc_batch* b) { return b ? b->layout : -1; }
+size_t arkmpc_batch_elem_words(const arkmpc_batch* b) { return b ? b->words : 0; }
+uint64_t* arkmpc_batch_data(const arkmpc_batch* b) { return b ? b->share : nullptr; }
+uint64_t* arkmpc_batch_mac_data(const arkmpc_batch* b) { return b ? b->mac : nullptr; }
+size_t arkmpc_batch_stride(const arkmpc_batch* b) { return b ? b->stride : 0; }
+
+// host Vec<T> (arkworks records, n * elem_words u64) -> a new device batch in the requested layout
+int arkmpc_batch_from_host(arkmpc_ctx* ctx, int kind, int layout, size_t n, const void* host_records, arkmpc_batch** out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (n && !host_records) return ark_bad(ctx, "null host records");
+    int rc = arkmpc_batch_create(ctx, kind, layout, n, out);
+    if (rc) return rc;
+    arkmpc_batch* b = *out;
+    const size_t bytes = n * (size_t)b->words * 8;
+    if (!n) return ARKMPC_OK;
+    if (layout == ARKMPC_LAYOUT_AOS) {
+        rc = arkmpc_memcpy_h2d(ctx, b->base, host_records, bytes);
+    } else {                                                   // upload the records, split the columns on the device
+        void* tmp = nullptr;
+        rc = arkmpc_malloc(ctx, bytes, &tmp);
+        if (!rc) rc = arkmpc_memcpy_h2d(ctx, tmp, host_records, bytes);
+        if (!rc) rc = arkmpc_share_split(ctx, n, (const u64*)tmp, b->share, b->mac);
+        if (tmp) { int r = arkmpc_free(ctx, tmp); if (!rc) rc = r; }
+    }
+    if (rc) { arkmpc_batch_destroy(ctx, b); *out = nullptr; }
+    return rc;
+}
+
+// the batch as the arkworks Vec<T> the awaiting caller expects (always AoS records); blocks until the data has landed
+int arkmpc_batch_to_host(arkmpc_ctx* ctx, const arkmpc_batch* b, void* host_records_out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    int rc = batch_check(ctx, b);
+    if (rc) return rc;
+    if (b->n && !host_records_out) return ark_bad(ctx, "null host buffer");
+    if (!b->n) return arkmpc_sync(ctx);
+    const size_t bytes = b->n * (size_t)b->words * 8;
+    if (b->layout == ARKMPC_LAYOUT_AOS) return arkmpc_memcpy_d2h(ctx, host_records_out, b->share, bytes);
+    void* tmp = nullptr;
+    rc = arkmpc_malloc(ctx, bytes, &tmp);
+    if (!rc) rc = arkmpc_share_join(ctx, b->n, b->share, b->mac, (u64*)tmp);
+    if (!rc) rc = arkmpc_memcpy_d2h(ctx, host_records_out, tmp, bytes);
+    if (tmp) { int r = arkmpc_free(ctx, tmp); if (!rc) rc = r; }
+    return rc;
+}
+
+// ---- batch-level forms of the Beaver multiplication (authenticated_scalar.rs:848-879): operands and results are handles, the
+// ---- layout tag selects the AoS or the split-column kernels, nothing leaves HBM --------------------------------------------
+static int share_batch_check(arkmpc_ctx* ctx, const arkmpc_batch* b, size_t n) {
+    int rc = batch_check(ctx, b);
+    if (rc) return rc;
+    if (b->kind != ARKMPC_KIND_SCALAR_SHARE) return ark_bad(ctx, "expected a ScalarShare batch");
+    if (b->n != n) return ark_bad(ctx, "Cannot operate on batches of different sizes");
+    return ARKMPC_OK;
+}
+// K1: out_de = a new Scalar batch of 2n elements, d then e -- the payload this party sends (:863-868, :141-145)
+int arkmpc_batch_beaver_mask(arkmpc_ctx* ctx, const arkmpc_batch* x, const arkmpc_batch* y, const arkmpc_batch* a, const arkmpc_batch* b,
+                             arkmpc_batch** out_de) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (!out_de) return ark_bad(ctx, "null out");
+    *out_de = nullptr;
+    if (!x) return ark_bad(ctx, "null batch");
+    const size_t n = x->n;
+    int rc;
+    if ((rc = share_batch_check(ctx, x, n)) || (rc = share_batch_check(ctx, y, n)) || (rc = share_batch_check(ctx, a, n)) || (rc = share_batch_check(ctx, b, n))) return rc;
+    if ((rc = arkmpc_batch_create(ctx, ARKMPC_KIND_SCALAR, ARKMPC_LAYOUT_AOS, 2 * n, out_de))) return rc;
+    rc = arkmpc_beaver_mask_v(ctx, n, x->share, x->stride, y->share, y->stride, a->share, a->stride, b->share, b->stride, (*out_de)->share);
+    if (rc) { arkmpc_batch_destroy(ctx, *out_de); *out_de = nullptr; }
+    return rc;
+}
+// K2+K3: result = a new ScalarShare batch in `out_layout`
+int arkmpc_batch_beaver_finish(arkmpc_ctx* ctx, int party_id, const uint64_t mac_key[4], const arkmpc_batch* my_de, const arkmpc_batch* peer_de,
+                               const arkmpc_batch* a, const arkmpc_batch* b, const arkmpc_batch* c, int out_layout, arkmpc_batch** out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (!out) return ark_bad(ctx, "null out");
+    *out = nullptr;
+    if (!a) return ark_bad(ctx, "null batch");
+    const size_t n = a->n;
+    int rc;
+    if ((rc = share_batch_check(ctx, a, n)) || (rc = share_batch_check(ctx, b, n)) || (rc = share_batch_check(ctx, c, n))) return rc;
+    if ((rc = batch_check(ctx, my_de)) || (rc = batch_check(ctx, peer_de))) return rc;
+    if (my_de->kind != ARKMPC_KIND_SCALAR || peer_de->kind != ARKMPC_KIND_SCALAR || my_de->n != 2 * n || peer_de->n != 2 * n)
+        return ark_bad(ctx, "d||e batches must hold 2n Scalars");          // a short peer payload is an error, never an out-of-bounds read
+    if ((rc = arkmpc_batch_create(ctx, ARKMPC_KIND_SCALAR_SHARE, out_layout, n, out))) return rc;
+    arkmpc_batch* r = *out;
+    rc = arkmpc_beaver_finish_fused_v(ctx, n, party_id, mac_key, my_de->share, peer_de->share, a->share, a->mac, a->stride, b->share, b->mac, b->stride,
+                                      c->share, c->mac, c->stride, r->share, r->mac, r->stride);
+    if (rc) { arkmpc_batch_destroy(ctx, r); *out = nullptr; }
+    return rc;
+}
+
+}  // extern "C"

@@ -563,10 +563,13 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* p
 }
 // PointShare::add_public (curve/share.rs:57-60): share += rhs iff PARTY0 ; mac += mac_key * rhs
 // (mac_key * rhs through the GLV window path: ~2.2 k instead of ~3.8 k Fq multiplications for plain double-and-add)
+// NEG: sub_public = add_public(-rhs) (curve/share.rs:63-65)
+template <bool NEG>
 __global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public(size_t n, int party, Fe key, const u64* shares, const u64* pub, u64* out, u64* table_ws) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     G1 rhs = g1_load(pub + 12 * i);
+    if (NEG) rhs = g1_neg(rhs);
     G1 sh = g1_load(shares + 24 * i), mac = g1_load(shares + 24 * i + 12);
     if (party == 0) sh = g1_add(sh, rhs);
     mac = g1_add(mac, g1_scalar_mul_glv5(rhs, key, table_ws, i, n));
@@ -706,39 +709,7 @@ __global__ void __launch_bounds__(SUM_TPB) k_g1_final_sum(const u64* partial, u3
 // Unlike the scalar batch commitment (one sequential sponge over all values), these are n independent 64-byte
 // messages = one Keccak-f[1600] each, so the whole thing runs on the GPU, one thread per commitment.
 // ---------------------------------------------------------------------------------------------
-__constant__ u64 KECCAK_RC[24] = {
-    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
-    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
-    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-
-__device__ __forceinline__ u64 rotl64(u64 x, int s) { return (x << s) | (x >> (64 - s)); }
-
-__device__ __forceinline__ void keccak_f1600_dev(u64 (&a)[25]) {
-#pragma unroll 1
-    for (int r = 0; r < 24; ++r) {
-        u64 c[5], d[5], b[25];
-#pragma unroll
-        for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-#pragma unroll
-        for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
-#pragma unroll
-        for (int i = 0; i < 25; ++i) a[i] ^= d[i % 5];
-        // rho + pi: b[y + 5*((2x+3y)%5)] = rot(a[x + 5y], R[x][y])
-        b[0] = a[0];
-        b[10] = rotl64(a[1], 1);   b[20] = rotl64(a[2], 62);  b[5] = rotl64(a[3], 28);   b[15] = rotl64(a[4], 27);
-        b[16] = rotl64(a[5], 36);  b[1] = rotl64(a[6], 44);   b[11] = rotl64(a[7], 6);   b[21] = rotl64(a[8], 55);  b[6] = rotl64(a[9], 20);
-        b[7] = rotl64(a[10], 3);   b[17] = rotl64(a[11], 10); b[2] = rotl64(a[12], 43);  b[12] = rotl64(a[13], 25); b[22] = rotl64(a[14], 39);
-        b[23] = rotl64(a[15], 41); b[8] = rotl64(a[16], 45);  b[18] = rotl64(a[17], 15); b[3] = rotl64(a[18], 21);  b[13] = rotl64(a[19], 8);
-        b[14] = rotl64(a[20], 18); b[24] = rotl64(a[21], 2);  b[9] = rotl64(a[22], 61);  b[19] = rotl64(a[23], 56); b[4] = rotl64(a[24], 14);
-#pragma unroll
-        for (int y = 0; y < 5; ++y)
-#pragma unroll
-            for (int x = 0; x < 5; ++x) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-        a[0] ^= KECCAK_RC[r];
-    }
-}
+#include "keccak_device.inc"
 __device__ __forceinline__ u64 limb64(const Fe& f, int i) { return (u64)f.v[2 * i] | ((u64)f.v[2 * i + 1] << 32); }
 
 __global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* pts, const u64* zinv, const u64* blinders, u64* out) {
@@ -901,8 +872,8 @@ int arkmpc_scalarshare_mul_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scal
     return smul_impl(ctx, 2 * n, points, n, 12, 2, scalar_shares, n * 64, 4, 1, out);
 }
 
-int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
-                                 const uint64_t* pub_points, uint64_t* out) {
+static int pointshare_addsub_public(arkmpc_ctx* ctx, bool sub, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                                    const uint64_t* pub_points, uint64_t* out) {
     ENTER_EC(ctx);
     if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
     if (!mac_key) return ark_bad(ctx, "null mac_key");
@@ -913,10 +884,21 @@ int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const 
     if (st.commit()) return st.rc;
     for (size_t lo = 0; lo < n; lo += chunk) {
         const size_t cnt = (n - lo < chunk) ? (n - lo) : chunk;
-        hipLaunchKernelGGL(k_pointshare_add_public, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, party_id, fe_from_host(mac_key),
-                           st.in<u64>(is) + 24 * lo, st.in<u64>(ip) + 12 * lo, st.out<u64>(io) + 24 * lo, st.scratch<u64>(iw));
+        const dim3 g(blocks_for(cnt, TPB_EC)), t(TPB_EC);
+        if (sub) hipLaunchKernelGGL(k_pointshare_add_public<true>, g, t, 0, ctx->stream, cnt, party_id, fe_from_host(mac_key),
+                                    st.in<u64>(is) + 24 * lo, st.in<u64>(ip) + 12 * lo, st.out<u64>(io) + 24 * lo, st.scratch<u64>(iw));
+        else hipLaunchKernelGGL(k_pointshare_add_public<false>, g, t, 0, ctx->stream, cnt, party_id, fe_from_host(mac_key),
+                                st.in<u64>(is) + 24 * lo, st.in<u64>(ip) + 12 * lo, st.out<u64>(io) + 24 * lo, st.scratch<u64>(iw));
     }
     return st.finish();
+}
+int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                                 const uint64_t* pub_points, uint64_t* out) {
+    return pointshare_addsub_public(ctx, false, n, party_id, mac_key, shares, pub_points, out);
+}
+int arkmpc_pointshare_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                                 const uint64_t* pub_points, uint64_t* out) {
+    return pointshare_addsub_public(ctx, true, n, party_id, mac_key, shares, pub_points, out);
 }
 int arkmpc_pointshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points) {
     ENTER_EC(ctx);

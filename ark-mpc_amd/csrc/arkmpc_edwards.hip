@@ -139,15 +139,61 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_scalar_mul(size_t n, const u64* p
     Fe s = fe_load(scalars + (size_t)s_stride * (i / s_div));
     ed_store(out + 16 * i, ed_scalar_mul_w4(p, s, table_ws, i, n));
 }
-// PointShare::add_public (curve/share.rs:57-60)
+// PointShare::add_public / sub_public (curve/share.rs:57-65): sub_public = add_public(-rhs)
+template <bool NEG>
 __global__ void __launch_bounds__(TPB_ED) k_edshare_add_public(size_t n, int party, Fe key, const u64* shares, const u64* pub, u64* out) {
     size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
     if (i >= n) return;
     Ed rhs = ed_load(pub + 16 * i), sh = ed_load(shares + 32 * i), mac = ed_load(shares + 32 * i + 16);
+    if (NEG) rhs = ed_neg(rhs);
     if (party == 0) sh = ed_add(sh, rhs);
     mac = ed_add(mac, ed_scalar_mul_plain(rhs, key));
     ed_store(out + 32 * i, sh);
     ed_store(out + 32 * i + 16, mac);
+}
+// the `.share()` projection of AuthenticatedPointResult::open_batch (authenticated_curve.rs:74-89)
+__global__ void __launch_bounds__(TPB_ED) k_edshare_extract(size_t n, const u64* shares, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    ed_store(out + 16 * i, ed_load(shares + 32 * i));
+}
+// value * mac_key - share.mac()  (authenticated_curve.rs:215-220)
+__global__ void __launch_bounds__(TPB_ED) k_ed_mac_check(size_t n, Fe key, const u64* opened, const u64* shares, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed v = ed_load(opened + 16 * i), mac = ed_load(shares + 32 * i + 16);
+    ed_store(out + 16 * i, ed_add(ed_scalar_mul_plain(v, key), ed_neg(mac)));
+}
+// my + peer == identity (authenticated_curve.rs:127-131), per element.  Identity in extended coordinates: x = 0 and y = z
+// ((0, -1), the point of order 2, has y = -z).
+__global__ void __launch_bounds__(TPB_ED) k_ed_mac_verify(size_t n, const u64* mine, const u64* peer, unsigned char* ok) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed s = ed_add(ed_load(mine + 16 * i), ed_load(peer + 16 * i));
+    ok[i] = (fe_is_zero(s.x) && fe_eq(s.y, s.z)) ? 1 : 0;
+}
+// Point sums (PointShare::sum, curve/share.rs:85-92; the reduction gate of AuthenticatedPointResult::msm,
+// authenticated_curve.rs:796-805): strided per-thread fold, then one LDS tree; blockIdx.y selects the share / MAC column.
+#define ED_SUM_TPB 256
+__global__ void __launch_bounds__(ED_SUM_TPB) k_ed_partial_sum(size_t n, const u64* pts, u32 stride, u32 lane_off, u64* partial, u32 nthreads) {
+    const u32 lane = blockIdx.y, t = blockIdx.x * ED_SUM_TPB + threadIdx.x;
+    if (t >= nthreads) return;
+    Ed acc = ed_identity();
+    for (size_t i = t; i < n; i += nthreads) acc = ed_add(acc, ed_load(pts + (size_t)stride * i + (size_t)lane_off * lane));
+    ed_store(partial + ((size_t)lane * nthreads + t) * 16, acc);
+}
+__global__ void __launch_bounds__(ED_SUM_TPB) k_ed_final_sum(const u64* partial, u32 nthreads, u64* out) {
+    __shared__ u64 sm[ED_SUM_TPB * 16];
+    const u32 lane = blockIdx.y, t = threadIdx.x;
+    Ed acc = ed_identity();
+    for (u32 i = t; i < nthreads; i += ED_SUM_TPB) acc = ed_add(acc, ed_load(partial + ((size_t)lane * nthreads + i) * 16));
+    ed_store(sm + 16 * t, acc);
+    __syncthreads();
+    for (u32 s = ED_SUM_TPB / 2; s > 0; s >>= 1) {
+        if (t < s) ed_store(sm + 16 * t, ed_add(ed_load(sm + 16 * t), ed_load(sm + 16 * (t + s))));
+        __syncthreads();
+    }
+    if (t == 0) ed_store(out + 16 * lane, ed_load(sm));
 }
 // z^-1 of a batch of points with Montgomery's trick (z is never 0 on this curve): K points per thread, strided by the thread
 // count, one Fermat exponentiation per thread; running products in `pre`
@@ -195,6 +241,38 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_to_bytes(size_t n, const u64* pts
     uint4* q = reinterpret_cast<uint4*>(out + 32 * i);
     q[0] = make_uint4(yc.v[0], yc.v[1], yc.v[2], yc.v[3]);
     q[1] = make_uint4(yc.v[4], yc.v[5], yc.v[6], top);
+}
+
+// K9 on this curve: out_i = from_be_bytes_mod_order(SHA3-256(to_bytes(P_i) || to_bytes_be(blinder_i))) with the twisted-Edwards
+// compressed encoding (authenticated_curve.rs:227 -> commitment.rs:58-89).  One Keccak-f[1600] per element, all on the GPU.
+#include "keccak_device.inc"
+__global__ void __launch_bounds__(TPB_ED) k_ed_commit_points(size_t n, const u64* pts, const u64* zinv, const u64* blinders, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed p = ed_load(pts + 16 * i);
+    Fe zi = fe_load(zinv + 4 * i);
+    Fe x = EQ_MUL(p.x, zi), y = EQ_MUL(p.y, zi);
+    Fe xc = fe_to_canonical<EQ>(x), nxc = fe_to_canonical<EQ>(fe_neg<EQ>(x)), yc = fe_to_canonical<EQ>(y);
+    u32 br = 0, bo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nxc.v[k], xc.v[k], br, &bo); br = bo; }   // borrow <=> x > -x
+    if (br) yc.v[7] |= 0x80000000u;
+    Fe bc = fe_to_canonical<ER>(fe_load(blinders + 4 * i));
+    u64 a[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) a[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = (u64)yc.v[2 * k] | ((u64)yc.v[2 * k + 1] << 32);
+        a[4 + k] = __builtin_bswap64((u64)bc.v[2 * (3 - k)] | ((u64)bc.v[2 * (3 - k) + 1] << 32));
+    }
+    a[8] ^= 0x06ULL;                    // SHA3 domain separation + first pad bit at byte 64
+    a[16] ^= 0x8000000000000000ULL;     // last pad bit at byte 135 (rate = 136)
+    keccak_f1600_dev(a);
+    Fe v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { u64 w = __builtin_bswap64(a[3 - k]); v.v[2 * k] = (u32)w; v.v[2 * k + 1] = (u32)(w >> 32); }
+    fe_store(out + 4 * i, fe_from_canonical<ER>(fe_reduce_once_loop<ER>(v)));
 }
 
 // CurvePoint::from_bytes on this curve (curve.rs:110-114 -> ark-ec twisted-Edwards deserialize_compressed with validation),
@@ -439,18 +517,87 @@ int arkmpc_edshare_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* shares,
 int arkmpc_scalarshare_mul_ed_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out) {
     return ed_smul_impl(ctx, 2 * n, nullptr, 0, 0, 1, scalar_shares, n * 64, 4, 1, out);
 }
-int arkmpc_edshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
-                              const uint64_t* pub_points, uint64_t* out) {
+static int edshare_addsub_public(arkmpc_ctx* ctx, bool sub, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                                 const uint64_t* pub_points, uint64_t* out) {
     ENTER_ED(ctx);
     if (party_id != 0 && party_id != 1) return ark_bad(ctx, "party_id must be 0 or 1");
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int is = st.declare_in(shares, n * 256), ip = st.declare_in(pub_points, n * 128), io = st.declare_out(out, n * 256);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_edshare_add_public, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, party_id, fe_from_host(mac_key),
-                              st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
+    const dim3 g(blocks_for(n, TPB_ED)), t(TPB_ED);
+    if (n && sub) hipLaunchKernelGGL(k_edshare_add_public<true>, g, t, 0, ctx->stream, n, party_id, fe_from_host(mac_key), st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
+    else if (n) hipLaunchKernelGGL(k_edshare_add_public<false>, g, t, 0, ctx->stream, n, party_id, fe_from_host(mac_key), st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
     return st.finish();
 }
+int arkmpc_edshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                              const uint64_t* pub_points, uint64_t* out) {
+    return edshare_addsub_public(ctx, false, n, party_id, mac_key, shares, pub_points, out);
+}
+int arkmpc_edshare_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                              const uint64_t* pub_points, uint64_t* out) {
+    return edshare_addsub_public(ctx, true, n, party_id, mac_key, shares, pub_points, out);
+}
+// ScalarShare * CurvePoint on this curve (curve.rs:483-517): output point j = points[j / 2] * scalar_shares_as_scalars[j]
+int arkmpc_scalarshare_mul_ed_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, const uint64_t* points, uint64_t* out) {
+    if (n && !points) return ctx ? ark_bad(ctx, "null points") : ARKMPC_ERR_BAD_ARG;
+    return ed_smul_impl(ctx, 2 * n, points, n, 16, 2, scalar_shares, n * 64, 4, 1, out);
+}
+int arkmpc_edshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int is = st.declare_in(shares, n * 256), io = st.declare_out(out_points, n * 128);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_edshare_extract, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(is), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_ed_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* opened_points, const uint64_t* shares,
+                               uint64_t* out_chk_points) {
+    ENTER_ED(ctx);
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    Stage st(ctx);
+    int iv = st.declare_in(opened_points, n * 128), is = st.declare_in(shares, n * 256), io = st.declare_out(out_chk_points, n * 128);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_ed_mac_check, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, fe_from_host(mac_key), st.in<u64>(iv),
+                              st.in<u64>(is), st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_ed_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int im = st.declare_in(mine, n * 128), ip = st.declare_in(peer, n * 128), io = st.declare_out(out_ok, n);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_ed_mac_verify, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(im), st.in<u64>(ip),
+                              st.out<unsigned char>(io));
+    return st.finish();
+}
+int arkmpc_commit_ed_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* blinders, uint64_t* out_commitments) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(points, n * 128), ib = st.declare_in(blinders, n * 32), io = st.declare_out(out_commitments, n * 32);
+    int iz = st.declare_scratch(n * 64 + 64);
+    if (st.commit()) return st.rc;
+    if (n) {
+        ed_launch_zinv(ctx, n, st.in<u64>(ip), st.scratch<u64>(iz), st.scratch<u64>(iz) + 4 * n);
+        hipLaunchKernelGGL(k_ed_commit_points, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<u64>(ip), st.scratch<u64>(iz) + 4 * n,
+                           st.in<u64>(ib), st.out<u64>(io));
+    }
+    return st.finish();
+}
+static int ed_sum_impl(arkmpc_ctx* ctx, size_t n, const uint64_t* pts, u32 stride, u32 lanes, uint64_t* out) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ip = st.declare_in(pts, n * stride * 8), io = st.declare_out(out, (size_t)lanes * 128);
+    const u32 nthreads = (u32)(n < 65536 ? (n ? n : 1) : 65536);
+    int iw = st.declare_scratch((size_t)lanes * nthreads * 128);
+    if (st.commit()) return st.rc;
+    hipLaunchKernelGGL(k_ed_partial_sum, dim3(blocks_for(nthreads, ED_SUM_TPB), lanes), dim3(ED_SUM_TPB), 0, ctx->stream, n, st.in<u64>(ip), stride, 16u,
+                       st.scratch<u64>(iw), nthreads);
+    hipLaunchKernelGGL(k_ed_final_sum, dim3(1, lanes), dim3(ED_SUM_TPB), 0, ctx->stream, st.scratch<u64>(iw), nthreads, st.out<u64>(io));
+    return st.finish();
+}
+int arkmpc_ed_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_point) { return ed_sum_impl(ctx, n, points, 16, 1, out_point); }
+int arkmpc_edshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share) { return ed_sum_impl(ctx, n, shares, 32, 2, out_share); }
 int arkmpc_ed_to_affine(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_xy) {
     ENTER_ED(ctx);
     Stage st(ctx);

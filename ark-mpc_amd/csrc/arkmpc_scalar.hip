@@ -386,7 +386,9 @@ template <int F>
 static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& k, const u64* my_de, const u64* peer_de, Col a_s, Col a_m,
                                 Col b_s, Col b_m, Col c_s, Col c_m, ColOut o_s, ColOut o_m) {
     if constexpr (HasAsmFinish<F>::value) {
-        if (use_asm_path() && a_s.stride == b_s.stride && a_s.stride == c_s.stride) {
+        // the hand-scheduled body addresses with 32-bit byte offsets inside a chunk of 2^25 gates: (2^25 - 1) * stride * 8 fits only
+        // for strides up to 16 u64 (AoS = 8, split = 4); wider views take the 64-bit C++ kernel below
+        if (use_asm_path() && a_s.stride == b_s.stride && a_s.stride == c_s.stride && a_s.stride <= 16 && o_s.stride <= 16) {
             const size_t CH = (size_t)1 << 25;
             const u32 mask = party == 0 ? 0xffffffffu : 0u;
             for (size_t lo = 0; lo < n; lo += CH) {
@@ -595,7 +597,14 @@ int arkmpc_kernel_timer_ms(arkmpc_ctx* ctx, int slot, float* out_ms) {
     return ARKMPC_OK;
 }
 
-const char* arkmpc_last_error(arkmpc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// The message is copied under the context lock into a per-thread buffer: a concurrent call on the same context may be
+// rewriting ctx->err (std::string reallocation) while this thread reads it.
+const char* arkmpc_last_error(arkmpc_ctx* ctx) {
+    if (!ctx) return "null context";
+    static thread_local std::string snapshot;
+    { std::lock_guard<std::mutex> lk(ctx->mu); snapshot = ctx->err; }
+    return snapshot.c_str();
+}
 
 int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
     ENTER(ctx);

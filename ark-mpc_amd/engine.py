@@ -231,6 +231,8 @@ class Engine:
     def pointshare_mul_public(self, n, shares, scalars, out): self.call("pointshare_mul_public", ("size", n), shares, scalars, out)
     def pointshare_add_public(self, n, party, key, shares, pub, out):
         self.call("pointshare_add_public", ("size", n), ("int", party), ("key", key), shares, pub, out)
+    def pointshare_sub_public(self, n, party, key, shares, pub, out):
+        self.call("pointshare_sub_public", ("size", n), ("int", party), ("key", key), shares, pub, out)
     def scalarshare_mul_generator(self, n, ss, out): self.call("scalarshare_mul_generator", ("size", n), ss, out)
     def scalarshare_mul_point(self, n, ss, pts, out): self.call("scalarshare_mul_point", ("size", n), ss, pts, out)
     def pointshare_extract(self, n, shares, out): self.call("pointshare_extract", ("size", n), shares, out)
@@ -285,6 +287,14 @@ class Engine:
     def edshare_mul_public(self, n, sh, sc, out): self.call("edshare_mul_public", ("size", n), sh, sc, out)
     def edshare_add_public(self, n, party, key, sh, pub, out): self.call("edshare_add_public", ("size", n), ("int", party), ("key", key), sh, pub, out)
     def scalarshare_mul_ed_generator(self, n, ss, out): self.call("scalarshare_mul_ed_generator", ("size", n), ss, out)
+    def edshare_sub_public(self, n, party, key, sh, pub, out): self.call("edshare_sub_public", ("size", n), ("int", party), ("key", key), sh, pub, out)
+    def scalarshare_mul_ed_point(self, n, ss, pts, out): self.call("scalarshare_mul_ed_point", ("size", n), ss, pts, out)
+    def edshare_extract(self, n, shares, out): self.call("edshare_extract", ("size", n), shares, out)
+    def ed_mac_check_shares(self, n, key, opened, shares, out): self.call("ed_mac_check_shares", ("size", n), ("key", key), opened, shares, out)
+    def ed_mac_verify(self, n, mine, peer, out_ok): self.call("ed_mac_verify", ("size", n), mine, peer, out_ok)
+    def commit_ed_points_sha3(self, n, pts, blinders, out): self.call("commit_ed_points_sha3", ("size", n), pts, blinders, out)
+    def ed_sum(self, n, pts, out): self.call("ed_sum", ("size", n), pts, out)
+    def edshare_sum(self, n, shares, out): self.call("edshare_sum", ("size", n), shares, out)
 
 
 def sha3_256(data: bytes) -> bytes:

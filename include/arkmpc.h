@@ -68,7 +68,7 @@ int arkmpc_ctx_set_stream(arkmpc_ctx* ctx, void* hip_stream);
 int arkmpc_ctx_set_host_buffers(arkmpc_ctx* ctx, int enabled);
 int arkmpc_sync(arkmpc_ctx* ctx);
 const char* arkmpc_last_error(arkmpc_ctx* ctx);
-/* Kernel timer: arm slot s (0..63) and the NEXT Beaver kernel launch (K1 or K2+K3) on this context gets HIP events bound to
+/* Kernel timer: arm slot s (0..63) and the NEXT K1 / K2+K3 / K5 launch on this context gets HIP events bound to
  * its dispatch (hipExtLaunchKernelGGL start/stop events): arkmpc_kernel_timer_ms then returns that kernel's own duration
  * (it blocks until the kernel has finished).  Unlike marker events recorded between launches this excludes the dispatch gap. */
 int arkmpc_kernel_timer_arm(arkmpc_ctx* ctx, int slot);
@@ -83,6 +83,51 @@ int arkmpc_free(arkmpc_ctx* ctx, void* dptr);
 int arkmpc_memcpy_h2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int arkmpc_memcpy_d2h(arkmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int arkmpc_memcpy_d2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* asynchronous on the context's stream */
+
+/* ---- device-batch carrier: what a `ResultValue::DeviceBatch` variant holds (fabric/result.rs:47-64) -------------------------
+ * An opaque, reference-counted handle to ONE batch value resident in HBM: element kind (the ResultValue variant it stands
+ * for), element count, layout tag and storage.  Gate outputs stay on the GPU between gates as handles; the arkworks Vec<T> is
+ * materialised only where a caller awaits the value (arkmpc_batch_to_host).  Handles belong to (field, device) of the creating
+ * context; any context of that pair may use them.  Batch contexts take device pointers (not arkmpc_ctx_set_host_buffers). */
+typedef struct arkmpc_batch arkmpc_batch;
+typedef enum {
+    ARKMPC_KIND_SCALAR = 0,        /* ResultValue::ScalarBatch  -- Vec<Scalar<C>>,      4 x u64 per element            */
+    ARKMPC_KIND_SCALAR_SHARE = 1,  /* Vec of ResultValue::ScalarShare -- ScalarShare<C>, 8 x u64                         */
+    ARKMPC_KIND_POINT = 2,         /* ResultValue::PointBatch   -- Vec<CurvePoint<C>>, 12 (BN254 G1) / 16 (Curve25519)  */
+    ARKMPC_KIND_POINT_SHARE = 3,   /* Vec of ResultValue::PointShare -- PointShare<C>,  24 / 32 x u64                    */
+    ARKMPC_KIND_WORDS = 4          /* ResultValue::Bytes and engine scratch: n raw u64 words                            */
+} arkmpc_kind;
+typedef enum {
+    ARKMPC_LAYOUT_AOS = 0,         /* arkworks records as a Rust Vec<T> holds them                                      */
+    ARKMPC_LAYOUT_SPLIT = 1        /* ScalarShare batches only: n shares, then n MACs (the engine-native columns)       */
+} arkmpc_layout;
+int arkmpc_batch_create(arkmpc_ctx* ctx, int kind, int layout, size_t n, arkmpc_batch** out_batch);   /* uninitialised storage */
+/* upload a host Vec<T> (n arkworks records); with ARKMPC_LAYOUT_SPLIT the columns are separated on the device */
+int arkmpc_batch_from_host(arkmpc_ctx* ctx, int kind, int layout, size_t n, const void* host_records, arkmpc_batch** out_batch);
+/* the batch as n arkworks records in host memory, whatever its device layout; blocks */
+int arkmpc_batch_to_host(arkmpc_ctx* ctx, const arkmpc_batch* batch, void* host_records_out);
+/* &v[lo .. lo+count] as a new handle that SHARES the storage (and keeps it alive): index-range sharding, sub-batches */
+int arkmpc_batch_slice(arkmpc_ctx* ctx, arkmpc_batch* batch, size_t lo, size_t count, arkmpc_batch** out_batch);
+int arkmpc_batch_retain(arkmpc_batch* batch);                      /* Clone of the handle: one more reference */
+/* Drop of one handle; the storage returns to the pool (ordered on ctx's stream, like arkmpc_free) with the last reference */
+int arkmpc_batch_destroy(arkmpc_ctx* ctx, arkmpc_batch* batch);
+size_t arkmpc_batch_len(const arkmpc_batch* batch);
+int arkmpc_batch_kind(const arkmpc_batch* batch);
+int arkmpc_batch_layout(const arkmpc_batch* batch);
+size_t arkmpc_batch_elem_words(const arkmpc_batch* batch);         /* u64 words of one arkworks record */
+/* device addresses for the pointer-level entry points below: element i starts at data + stride * i (u64 units); for
+ * ScalarShare batches `data` addresses the share half and `mac_data` the MAC half (NULL for other kinds) */
+uint64_t* arkmpc_batch_data(const arkmpc_batch* batch);
+uint64_t* arkmpc_batch_mac_data(const arkmpc_batch* batch);
+size_t arkmpc_batch_stride(const arkmpc_batch* batch);
+/* Beaver multiplication on handles (authenticated_scalar.rs:848-879): K1 returns this party's d||e payload as a new Scalar
+ * batch of 2n elements; K2+K3 returns the product shares as a new ScalarShare batch in `out_layout`.  Operand layouts may be
+ * mixed; a d||e batch of the wrong length is ARKMPC_ERR_BAD_ARG. */
+int arkmpc_batch_beaver_mask(arkmpc_ctx* ctx, const arkmpc_batch* x, const arkmpc_batch* y, const arkmpc_batch* a,
+                             const arkmpc_batch* b, arkmpc_batch** out_de);
+int arkmpc_batch_beaver_finish(arkmpc_ctx* ctx, int party_id, const uint64_t mac_key[4], const arkmpc_batch* my_de,
+                               const arkmpc_batch* peer_de, const arkmpc_batch* a, const arkmpc_batch* b, const arkmpc_batch* c,
+                               int out_layout, arkmpc_batch** out_batch);
 
 /* ---- Scalar<C> vectors: scalar.rs:210-267, scalar_result.rs:24-278 ------------------------- */
 int arkmpc_scalar_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);
@@ -194,6 +239,10 @@ int arkmpc_pointshare_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* shar
                                  uint64_t* out);                                                                     /* :718-751 */
 int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
                                  const uint64_t* shares, const uint64_t* pub_points, uint64_t* out);                 /* :429-463 */
+/* PointShare::sub_public = add_public(-rhs) (curve/share.rs:63-65; the `AuthenticatedPointResult - CurvePointResult` operators,
+ * authenticated_curve.rs:553-575) */
+int arkmpc_pointshare_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
+                                 const uint64_t* shares, const uint64_t* pub_points, uint64_t* out);
 int arkmpc_scalarshare_mul_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out);      /* :754-780 */
 int arkmpc_scalarshare_mul_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, const uint64_t* points,
                                  uint64_t* out);                                                                     /* curve.rs:483-517 */
@@ -246,7 +295,22 @@ int arkmpc_edshare_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* o
 int arkmpc_edshare_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, const uint64_t* scalars, uint64_t* out);
 int arkmpc_edshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
                               const uint64_t* pub_points, uint64_t* out);
+int arkmpc_edshare_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* shares,
+                              const uint64_t* pub_points, uint64_t* out);                                        /* curve/share.rs:63-65 */
 int arkmpc_scalarshare_mul_ed_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out);
+int arkmpc_scalarshare_mul_ed_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, const uint64_t* points,
+                                    uint64_t* out);                                                                /* curve.rs:483-517 */
+/* The authenticated-point protocol pieces on Curve25519 (the reference is generic over C: authenticated_curve.rs:66-283, 682-806),
+ * same semantics as arkmpc_pointshare_extract / point_mac_check_shares / point_mac_verify / commit_points_sha3 / g1_sum /
+ * pointshare_sum above, on 16 / 32 x u64 elements and the twisted-Edwards compressed encoding. */
+int arkmpc_edshare_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_points);
+int arkmpc_ed_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* opened_points,
+                               const uint64_t* shares, uint64_t* out_chk_points);
+int arkmpc_ed_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok);
+int arkmpc_commit_ed_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* blinders,
+                                 uint64_t* out_commitments);
+int arkmpc_ed_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_point);
+int arkmpc_edshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Wire format of the batches that cross the party-to-party link (csrc/arkmpc_wire.hip).

@@ -817,6 +817,34 @@ void ora_edshare_batch_add_public(size_t n, int party, const u64 key[4], const u
     }
 }
 
+/* curve/share.rs:63-65: sub_public = add_public(-rhs) */
+void ora_edshare_batch_sub_public(size_t n, int party, const u64 key[4], const u64* shares, const u64* pub, u64* out) {
+    for (size_t i = 0; i < n; ++i) { u64 np_[16]; ora_ed_neg(pub + 16 * i, np_); ora_edshare_batch_add_public(1, party, key, shares + 32 * i, np_, out + 32 * i); }
+}
+void ora_pointshare_batch_sub_public(size_t n, int party, const u64 key[4], const u64* shares, const u64* pub, u64* out) {
+    for (size_t i = 0; i < n; ++i) { u64 np_[12]; ora_g1_neg(pub + 12 * i, np_); ora_pointshare_batch_add_public(1, party, key, shares + 24 * i, np_, out + 24 * i); }
+}
+/* authenticated_curve.rs:215-220: value * mac_key - share.mac(), per element */
+void ora_point_mac_check_shares(size_t n, const u64 key[4], const u64* opened, const u64* shares, u64* out) {
+    for (size_t i = 0; i < n; ++i) { u64 kv[12], nm[12]; ora_g1_scalar_mul(opened + 12 * i, key, kv); ora_g1_neg(shares + 24 * i + 12, nm); ora_g1_add(kv, nm, out + 12 * i); }
+}
+void ora_ed_mac_check_shares(size_t n, const u64 key[4], const u64* opened, const u64* shares, u64* out) {
+    for (size_t i = 0; i < n; ++i) { u64 kv[16], nm[16]; ora_ed_scalar_mul(opened + 16 * i, key, kv); ora_ed_neg(shares + 32 * i + 16, nm); ora_ed_add(kv, nm, out + 16 * i); }
+}
+/* curve/share.rs:85-92 / authenticated_curve.rs:796-805: fold with the group law, starting from the identity */
+void ora_ed_sum(size_t n, const u64* pts, size_t stride, u64 out[16]) {
+    u64 acc[16]; ora_ed_identity(acc);
+    for (size_t i = 0; i < n; ++i) { u64 t[16]; ora_ed_add(acc, pts + stride * i, t); memcpy(acc, t, 128); }
+    memcpy(out, acc, 128);
+}
+/* authenticated_curve.rs:127-131: my + peer == identity; returns 1 when it is.  Compared on affine coordinates (0, 1). */
+int ora_ed_is_identity_sum(const u64 a[16], const u64 b[16]) {
+    u64 s[16], xy[8], one[4];
+    ora_ed_add(a, b, s); ora_ed_to_affine(s, xy);
+    memcpy(one, ora_get_field(ORA_CURVE25519_FQ)->r, 32);
+    return is_zero4(xy) && memcmp(xy + 4, one, 32) == 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Range-parallel forms of batch functions above, for the full-size parity tests (BASELINE sizes: 2^24 shares,
  * 2^18 PointShare x Scalar): the SAME per-element functions, a static contiguous range split over pthreads.

@@ -157,6 +157,14 @@ void ora_dummy_triples(int field_id, int party_id, size_t n, u64* a, u64* b, u64
 void ora_dummy_local_input_masks(int field_id, int party_id, size_t n, u64* masks, u64* mask_shares);
 void ora_dummy_counterparty_input_masks(int field_id, int party_id, size_t n, u64* mask_shares);
 
+/* ---- sub_public, point MAC check, Edwards sums (curve/share.rs:63-65, 85-92; authenticated_curve.rs:127-131, 215-220) ---- */
+void ora_edshare_batch_sub_public(size_t n, int party_id, const u64 mac_key[4], const u64* shares, const u64* pub, u64* out);
+void ora_pointshare_batch_sub_public(size_t n, int party_id, const u64 mac_key[4], const u64* shares, const u64* pub, u64* out);
+void ora_point_mac_check_shares(size_t n, const u64 mac_key[4], const u64* opened, const u64* shares, u64* out);
+void ora_ed_mac_check_shares(size_t n, const u64 mac_key[4], const u64* opened, const u64* shares, u64* out);
+void ora_ed_sum(size_t n, const u64* pts, size_t stride_u64, u64 out[16]);
+int ora_ed_is_identity_sum(const u64 a[16], const u64 b[16]);
+
 /* ---- range-parallel forms (same per-element functions, static range split over pthreads; full-size parity tests) ---- */
 void ora_beaver_mask_mt(int field_id, size_t n, const u64* x, const u64* y, const u64* a, const u64* b, u64* out_de, int nthreads);
 /* one party's local work in open_authenticated_batch (authenticated_scalar.rs:278-311) */

@@ -205,6 +205,25 @@ class Oracle:
         n = len(shares) // 32; out = np.zeros(32 * n, dtype=np.uint64)
         self._call("ora_edshare_batch_add_public", n, party, key, shares, pub, out); return out
 
+    def edshare_sub_public(self, party, key, shares, pub):
+        n = len(shares) // 32; out = np.zeros(32 * n, dtype=np.uint64)
+        self._call("ora_edshare_batch_sub_public", n, party, key, shares, pub, out); return out
+    def pointshare_sub_public(self, party, key, shares, pub):
+        n = len(shares) // 24; out = np.zeros(24 * n, dtype=np.uint64)
+        self._call("ora_pointshare_batch_sub_public", n, party, key, shares, pub, out); return out
+    def point_mac_check_shares(self, key, opened, shares):
+        n = len(opened) // 12; out = np.zeros(12 * n, dtype=np.uint64)
+        self._call("ora_point_mac_check_shares", n, key, opened, shares, out); return out
+    def ed_mac_check_shares(self, key, opened, shares):
+        n = len(opened) // 16; out = np.zeros(16 * n, dtype=np.uint64)
+        self._call("ora_ed_mac_check_shares", n, key, opened, shares, out); return out
+    def ed_sum(self, pts, stride=16, off=0):
+        n = len(pts) // stride; out = np.zeros(16, dtype=np.uint64)
+        self.lib.ora_ed_sum(ctypes.c_size_t(n), ctypes.c_void_p(pts.ctypes.data + 8 * off), ctypes.c_size_t(stride), self._p(out)); return out
+    def ed_is_identity_sum(self, a, b):
+        self.lib.ora_ed_is_identity_sum.restype = ctypes.c_int
+        return bool(self.lib.ora_ed_is_identity_sum(self._p(np.ascontiguousarray(a)), self._p(np.ascontiguousarray(b))))
+
     # -- range-parallel forms for the full-size parity tests
     @staticmethod
     def host_threads():

@@ -45,12 +45,12 @@ def test_host_sha3_matches_hashlib(pkg):
         assert eng.sha3_256(data) == hashlib.sha3_256(data).digest()
 
 
-def _build_c_smoke(tmp_path):
+def _build_c_smoke(tmp_path, name="abi_smoke"):
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "abi_smoke")
+    exe = str(tmp_path / name)
     lib = os.path.join(root, "ark-mpc_amd", "lib")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", name + ".c"),
                            "-o", exe, "-L", lib, "-larkmpc_hip", "-Wl,-rpath," + lib])
     return exe
 
@@ -72,3 +72,25 @@ def test_c_caller_on_gpu(tmp_path):
     import subprocess
     r = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0 and "d = 5 e = 2" in r.stdout, r.stdout + r.stderr
+
+
+def test_batch_carrier_c_caller_builds_and_fails_loudly_without_gpu(tmp_path):
+    """tests/c/batch_carrier.c (the device-batch carrier of include/arkmpc.h driven from C99) compiles with -Werror -pedantic
+    and links; without a GPU it reports ARKMPC_ERR_NO_DEVICE."""
+    import subprocess
+    import torch
+    exe = _build_c_smoke(tmp_path, "batch_carrier")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "batch carrier ok" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_batch_carrier_on_gpu(tmp_path):
+    """Beaver multiplication on handles in both layouts == the pointer-level entry points, slices outlive their parent, misuse
+    is a status code (tests/c/batch_carrier.c)."""
+    import subprocess
+    r = subprocess.run([_build_c_smoke(tmp_path, "batch_carrier")], capture_output=True, text=True)
+    assert r.returncode == 0 and "batch carrier ok" in r.stdout, r.stdout + r.stderr

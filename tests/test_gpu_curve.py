@@ -85,6 +85,11 @@ def test_pointshare_ops(hip, oracle, party):
     assert affine_equal(hip, oracle, hip.pointshare_neg(A), oracle.pointshare_neg(A))
     assert affine_equal(hip, oracle, hip.pointshare_mul_public(A, S), oracle.pointshare_mul_public(A, S))
     assert affine_equal(hip, oracle, hip.pointshare_add_public(party, key, A, PUB), oracle.pointshare_add_public(party, key, A, PUB))
+    o = np.zeros(24 * n, dtype=np.uint64); hip.eng(0).pointshare_sub_public(n, party, key, A, PUB, o)      # curve/share.rs:63-65
+    assert affine_equal(hip, oracle, o, oracle.pointshare_sub_public(party, key, A, PUB))
+    assert affine_equal(hip, oracle, o, oracle.pointshare_add_public(party, key, A, oracle.g1_neg(PUB)))
+    chk = np.zeros(12 * n, dtype=np.uint64); hip.eng(0).point_mac_check_shares(n, key, PUB, A, chk)         # authenticated_curve.rs:215-220
+    assert affine_equal(hip, oracle, chk, oracle.point_mac_check_shares(key, PUB, A))
     assert affine_equal(hip, oracle, hip.scalarshare_mul_generator(SS), oracle.scalarshare_mul_generator(SS))
     assert affine_equal(hip, oracle, hip.scalarshare_mul_point(SS, PUB), oracle.scalarshare_mul_point(SS, PUB))
     o = np.zeros(12 * n, dtype=np.uint64); hip.eng(0).pointshare_extract(n, A, o)

@@ -106,3 +106,77 @@ def test_from_bytes(eng, oracle):
     assert np.array_equal(ok, want_ok) and np.array_equal(out, want)
     assert ok[:n].all() and not ok[n:].any()
     assert aff_equal(eng, oracle, out[:16 * n], P)
+
+
+# ---- round 2: the authenticated-point protocol pieces on Curve25519 (authenticated_curve.rs:66-283, 682-806 are generic over C) ----
+@pytest.mark.parametrize("party", [0, 1])
+def test_edshare_sub_public_and_scalarshare_mul_point(eng, oracle, party):
+    n = 9
+    _, A = rand_points(2 * n, 15)
+    _, PUB = rand_points(n, 17)
+    key = mont_array(2, rand_values(2, 1, 19))
+    SS = mont_array(2, [0, 1] + rand_values(2, 2 * n - 2, 20))
+    o = np.zeros(32 * n, dtype=np.uint64)
+    eng.edshare_sub_public(n, party, key, A, PUB, o)                    # curve/share.rs:63-65
+    assert aff_equal(eng, oracle, o, oracle.edshare_sub_public(party, key, A, PUB))
+    assert aff_equal(eng, oracle, o, oracle.edshare_add_public(party, key, A, oracle.ed_batch_neg(PUB)))
+    eng.scalarshare_mul_ed_point(n, SS, PUB, o)                         # curve.rs:483-517: point j = PUB[j // 2] * SS[j]
+    assert aff_equal(eng, oracle, o, oracle.ed_batch_scalar_mul(PUB, SS, n=2 * n, p_div=2))
+
+
+def test_ed_open_mac_check_commit_verify(eng, oracle):
+    """open_authenticated_batch's local steps on Curve25519: `.share()` extraction, value*key - mac, per-element commitments over
+    the compressed encoding, my + peer == identity -- against the oracle, hashlib, and a corrupted MAC."""
+    import hashlib
+    n = 12
+    k0, k1 = rand_values(2, 2, 31)
+    key = (k0 + k1) % pyref.EL
+    vals = rand_values(2, n, 32)
+    s0 = rand_values(2, n, 33); s1 = [(v - a) % pyref.EL for v, a in zip(vals, s0)]
+    m0 = rand_values(2, n, 34); m1 = [(key * v - a) % pyref.EL for v, a in zip(vals, m0)]
+    G = ext([pyref.ED_B], [1])
+    mk = lambda ks, seed: ext([pyref.ed_mul(pyref.ED_B, k) for k in ks], [2 + (seed + 3 * i) % 89 for i in range(len(ks))])
+    sh = []
+    for sv, mv, seed in ((s0, m0, 1), (s1, m1, 2)):
+        S, M = mk(sv, seed).reshape(n, 16), mk(mv, seed + 7).reshape(n, 16)
+        sh.append(np.ascontiguousarray(np.concatenate([S, M], axis=1).reshape(-1)))
+    keys = [mont_array(2, [k0]), mont_array(2, [k1])]
+    mine = []
+    for p in (0, 1):
+        o = np.zeros(16 * n, dtype=np.uint64); eng.edshare_extract(n, sh[p], o)
+        assert np.array_equal(o, np.ascontiguousarray(sh[p].reshape(n, 32)[:, :16]).reshape(-1))
+        mine.append(o)
+    opened = np.zeros(16 * n, dtype=np.uint64); eng.ed_add(n, mine[0], mine[1], opened)
+    assert aff_equal(eng, oracle, opened, mk(vals, 5))                 # open == value * G
+    chk = []
+    for p in (0, 1):
+        c = np.zeros(16 * n, dtype=np.uint64); eng.ed_mac_check_shares(n, keys[p], opened, sh[p], c)
+        assert aff_equal(eng, oracle, c, oracle.ed_mac_check_shares(keys[p], opened, sh[p]))
+        chk.append(c)
+    ok = np.zeros(n, dtype=np.uint8); eng.ed_mac_verify(n, chk[0], chk[1], ok)
+    assert ok.all() and all(oracle.ed_is_identity_sum(chk[0][16 * i:16 * i + 16], chk[1][16 * i:16 * i + 16]) for i in range(n))
+    # commitments: SHA3-256(compressed point || BE(blinder)) reduced mod l
+    bl = rand_values(2, n, 40); BL = mont_array(2, bl)
+    comm = np.zeros(4 * n, dtype=np.uint64); eng.commit_ed_points_sha3(n, chk[0], BL, comm)
+    data = np.zeros(32 * n, dtype=np.uint8); eng.ed_to_bytes(n, chk[0], data)
+    assert np.array_equal(data, oracle.ed_to_bytes(chk[0]))
+    for i in range(n):
+        msg = data[32 * i:32 * i + 32].tobytes() + int(bl[i]).to_bytes(32, "big")
+        want = int.from_bytes(hashlib.sha3_256(msg).digest(), "big") % pyref.EL
+        assert pyref.from_mont(2, limbs_to_ints(comm[4 * i:4 * i + 4])[0]) == want
+        assert np.array_equal(comm[4 * i:4 * i + 4], oracle.commit_bytes(2, data[32 * i:32 * i + 32].tobytes(), BL[4 * i:4 * i + 4].copy()))
+    # a corrupted MAC share is caught at exactly that element (authenticated_curve.rs:1127-1155 modify_mac)
+    bad = sh[0].copy(); bad[32 * 3 + 16: 32 * 3 + 32] = ext([pyref.ed_mul(pyref.ED_B, 12345)], [1])
+    c = np.zeros(16 * n, dtype=np.uint64); eng.ed_mac_check_shares(n, keys[0], opened, bad, c)
+    eng.ed_mac_verify(n, c, chk[1], ok)
+    assert ok.tolist() == [1, 1, 1, 0] + [1] * (n - 4)
+
+
+def test_ed_sums(eng, oracle):
+    for n in (0, 1, 7, 300):
+        _, A = rand_points(2 * n, 60 + n) if n else (None, np.zeros(0, dtype=np.uint64))
+        o = np.zeros(32, dtype=np.uint64); eng.edshare_sum(n, A, o)
+        want = np.concatenate([oracle.ed_sum(A, 32, 0), oracle.ed_sum(A, 32, 16)]) if n else np.concatenate([oracle.ed_identity()] * 2)
+        assert aff_equal(eng, oracle, o, want)
+        o1 = np.zeros(16, dtype=np.uint64); eng.ed_sum(2 * n, A, o1)
+        assert aff_equal(eng, oracle, o1, oracle.ed_sum(A) if n else oracle.ed_identity())
