@@ -92,37 +92,41 @@ class Engine {
     arkmpc_ctx* host_ = nullptr;
 };
 
-// RAII device allocation of `words` u64
+// RAII owner of ONE device batch = the carrier handle of the C ABI (arkmpc_batch, what a ResultValue::DeviceBatch holds,
+// fabric/result.rs:47-64): element kind + count + storage.  Typed batches (ScalarBatch, AuthenticatedScalarBatch, PointBatch ...)
+// are created with their kind; engine scratch and byte payloads use ARKMPC_KIND_WORDS (n raw u64 words).
 class DeviceBuf {
   public:
     DeviceBuf() = default;
-    DeviceBuf(std::shared_ptr<Engine> e, size_t words) : e_(std::move(e)), words_(words) {
-        void* p = nullptr;
-        check(e_->dev(), arkmpc_malloc(e_->dev(), words * 8, &p), "malloc");
-        p_ = static_cast<uint64_t*>(p);
+    DeviceBuf(std::shared_ptr<Engine> e, size_t words) : DeviceBuf(std::move(e), ARKMPC_KIND_WORDS, words) {}
+    DeviceBuf(std::shared_ptr<Engine> e, int kind, size_t n) : e_(std::move(e)) {
+        check(e_->dev(), arkmpc_batch_create(e_->dev(), kind, ARKMPC_LAYOUT_AOS, n, &b_), "batch_create");
+        words_ = n * arkmpc_batch_elem_words(b_);
     }
-    ~DeviceBuf() { if (p_) arkmpc_free(e_->dev(), p_); }
+    ~DeviceBuf() { if (b_) arkmpc_batch_destroy(e_->dev(), b_); }
     DeviceBuf(DeviceBuf&& o) noexcept { *this = std::move(o); }
     DeviceBuf& operator=(DeviceBuf&& o) noexcept {
-        if (this != &o) { if (p_) arkmpc_free(e_->dev(), p_); e_ = std::move(o.e_); p_ = o.p_; words_ = o.words_; o.p_ = nullptr; o.words_ = 0; }
+        if (this != &o) { if (b_) arkmpc_batch_destroy(e_->dev(), b_); e_ = std::move(o.e_); b_ = o.b_; words_ = o.words_; o.b_ = nullptr; o.words_ = 0; }
         return *this;
     }
     DeviceBuf(const DeviceBuf&) = delete;
-    uint64_t* ptr() const { return p_; }
+    uint64_t* ptr() const { return arkmpc_batch_data(b_); }
+    arkmpc_batch* handle() const { return b_; }
+    int kind() const { return arkmpc_batch_kind(b_); }
     size_t words() const { return words_; }
     void set_words(size_t w) { words_ = w; }          // logical length of a buffer allocated with slack
-    // a batch handed over by the peer party: from now on this engine's stream uses it, so this engine frees it (arkmpc_free is
-    // ordered on the freeing context's stream)
+    // a batch handed over by the peer party: from now on this engine's stream uses it, so this engine drops it (the storage
+    // returns to the pool ordered on the dropping context's stream)
     void rebind(std::shared_ptr<Engine> e) { e_ = std::move(e); }
-    void upload(const void* host, size_t bytes) { if (bytes) check(e_->dev(), arkmpc_memcpy_h2d(e_->dev(), p_, host, bytes), "h2d"); }
+    void upload(const void* host, size_t bytes) { if (bytes) check(e_->dev(), arkmpc_memcpy_h2d(e_->dev(), ptr(), host, bytes), "h2d"); }
     void download(void* host, size_t bytes) const {
         check(e_->dev(), arkmpc_sync(e_->dev()), "sync");
-        if (bytes) check(e_->dev(), arkmpc_memcpy_d2h(e_->dev(), host, p_, bytes), "d2h");
+        if (bytes) check(e_->dev(), arkmpc_memcpy_d2h(e_->dev(), host, ptr(), bytes), "d2h");
     }
 
   private:
     std::shared_ptr<Engine> e_;
-    uint64_t* p_ = nullptr;
+    arkmpc_batch* b_ = nullptr;
     size_t words_ = 0;
 };
 
@@ -201,6 +205,7 @@ class PreprocessingPhase {
     virtual std::pair<std::vector<Scalar>, std::vector<ScalarShare>> next_local_input_mask_batch(size_t n) = 0;
     virtual std::vector<ScalarShare> next_counterparty_input_mask_batch(size_t n) = 0;
     virtual void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) = 0;
+    virtual std::vector<ScalarShare> next_shared_bit_batch(size_t n) = 0;                         // offline_prep.rs:39-44
     virtual std::vector<ScalarShare> next_shared_value_batch(size_t n) = 0;                       // offline_prep.rs:45-50
     virtual void next_shared_inverse_pair_batch(size_t n, std::vector<ScalarShare>& l, std::vector<ScalarShare>& r) = 0;   // :54-60
     // Optional: a source whose batches are n copies of one value (the dummy source below) may describe them by that value;
@@ -244,6 +249,9 @@ class PartyIDBeaverSource : public PreprocessingPhase {
         return true;
     }
 
+    std::vector<ScalarShare> next_shared_bit_batch(size_t n) override {                         // :131-135: "simply output partyID"
+        return std::vector<ScalarShare>(n, ScalarShare{s_[party_], s_[party_]});
+    }
     std::vector<ScalarShare> next_shared_value_batch(size_t n) override {                       // :166-168: (party_id, party_id)
         return std::vector<ScalarShare>(n, ScalarShare{s_[party_], s_[party_]});
     }
@@ -254,6 +262,77 @@ class PartyIDBeaverSource : public PreprocessingPhase {
   private:
     PartyId party_;
     Scalar s_[7];
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Curve traits: the reference is generic over `C: CurveGroup` (authenticated_curve.rs, curve.rs); the C ABI has one set of
+// entry points per curve.  A traits struct binds the point-side API of the mirror to one of them.
+// ---------------------------------------------------------------------------------------------------------------
+struct Bn254G1 {                      // ark_bn254::G1Projective: short-Weierstrass Jacobian {x, y, z}
+    static constexpr size_t PW = 12;  // u64 words per CurvePoint
+    static constexpr int FIELD = ARKMPC_BN254_FR;
+    static int add(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_g1_add(c, n, a, b, o); }
+    static int sub(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_g1_sub(c, n, a, b, o); }
+    static int scalar_mul(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) { return arkmpc_g1_scalar_mul(c, n, p, s, o); }
+    static int generator_mul(arkmpc_ctx* c, size_t n, const uint64_t* s, uint64_t* o) { return arkmpc_g1_generator_mul(c, n, s, o); }
+    static int to_bytes(arkmpc_ctx* c, size_t n, const uint64_t* p, uint8_t* o) { return arkmpc_g1_to_bytes(c, n, p, o); }
+    static int from_bytes(arkmpc_ctx* c, size_t n, const uint8_t* b, uint64_t* o, uint8_t* ok) { return arkmpc_g1_from_bytes(c, n, b, o, ok); }
+    static int share_add(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_pointshare_add(c, n, a, b, o); }
+    static int share_sub(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_pointshare_sub(c, n, a, b, o); }
+    static int share_neg(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_pointshare_neg(c, n, a, o); }
+    static int share_add_public(arkmpc_ctx* c, size_t n, int party, const uint64_t* k, const uint64_t* a, const uint64_t* p, uint64_t* o) { return arkmpc_pointshare_add_public(c, n, party, k, a, p, o); }
+    static int share_sub_public(arkmpc_ctx* c, size_t n, int party, const uint64_t* k, const uint64_t* a, const uint64_t* p, uint64_t* o) { return arkmpc_pointshare_sub_public(c, n, party, k, a, p, o); }
+    static int share_mul_public(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* s, uint64_t* o) { return arkmpc_pointshare_mul_public(c, n, a, s, o); }
+    static int scalarshare_mul_generator(arkmpc_ctx* c, size_t n, const uint64_t* ss, uint64_t* o) { return arkmpc_scalarshare_mul_generator(c, n, ss, o); }
+    static int scalarshare_mul_point(arkmpc_ctx* c, size_t n, const uint64_t* ss, const uint64_t* p, uint64_t* o) { return arkmpc_scalarshare_mul_point(c, n, ss, p, o); }
+    static int share_extract(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_pointshare_extract(c, n, a, o); }
+    static int mac_check_shares(arkmpc_ctx* c, size_t n, const uint64_t* k, const uint64_t* v, const uint64_t* a, uint64_t* o) { return arkmpc_point_mac_check_shares(c, n, k, v, a, o); }
+    static int commit_points(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* bl, uint64_t* o) { return arkmpc_commit_points_sha3(c, n, p, bl, o); }
+    static int mac_verify(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint8_t* ok) { return arkmpc_point_mac_verify(c, n, a, b, ok); }
+    static int share_sum(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_pointshare_sum(c, n, a, o); }
+    // CurvePoint::msm / msm_authenticated (curve.rs:549-560, :618-642): the bucket method on the GPU
+    static int msm(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) { return arkmpc_g1_msm(c, n, p, s, o); }
+    static int msm_authenticated(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* ss, uint64_t* o) { return arkmpc_g1_msm_authenticated(c, n, p, ss, o); }
+};
+struct Curve25519 {                   // ark_curve25519::EdwardsProjective (README.md:24): extended twisted Edwards {x, y, t, z}
+    static constexpr size_t PW = 16;
+    static constexpr int FIELD = ARKMPC_CURVE25519_FR;
+    static int add(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_ed_add(c, n, a, b, o); }
+    static int sub(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_ed_sub(c, n, a, b, o); }
+    static int scalar_mul(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) { return arkmpc_ed_scalar_mul(c, n, p, s, o); }
+    static int generator_mul(arkmpc_ctx* c, size_t n, const uint64_t* s, uint64_t* o) { return arkmpc_ed_generator_mul(c, n, s, o); }
+    static int to_bytes(arkmpc_ctx* c, size_t n, const uint64_t* p, uint8_t* o) { return arkmpc_ed_to_bytes(c, n, p, o); }
+    static int from_bytes(arkmpc_ctx* c, size_t n, const uint8_t* b, uint64_t* o, uint8_t* ok) { return arkmpc_ed_from_bytes(c, n, b, o, ok); }
+    static int share_add(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_edshare_add(c, n, a, b, o); }
+    static int share_sub(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* o) { return arkmpc_edshare_sub(c, n, a, b, o); }
+    static int share_neg(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_edshare_neg(c, n, a, o); }
+    static int share_add_public(arkmpc_ctx* c, size_t n, int party, const uint64_t* k, const uint64_t* a, const uint64_t* p, uint64_t* o) { return arkmpc_edshare_add_public(c, n, party, k, a, p, o); }
+    static int share_sub_public(arkmpc_ctx* c, size_t n, int party, const uint64_t* k, const uint64_t* a, const uint64_t* p, uint64_t* o) { return arkmpc_edshare_sub_public(c, n, party, k, a, p, o); }
+    static int share_mul_public(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* s, uint64_t* o) { return arkmpc_edshare_mul_public(c, n, a, s, o); }
+    static int scalarshare_mul_generator(arkmpc_ctx* c, size_t n, const uint64_t* ss, uint64_t* o) { return arkmpc_scalarshare_mul_ed_generator(c, n, ss, o); }
+    static int scalarshare_mul_point(arkmpc_ctx* c, size_t n, const uint64_t* ss, const uint64_t* p, uint64_t* o) { return arkmpc_scalarshare_mul_ed_point(c, n, ss, p, o); }
+    static int share_extract(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_edshare_extract(c, n, a, o); }
+    static int mac_check_shares(arkmpc_ctx* c, size_t n, const uint64_t* k, const uint64_t* v, const uint64_t* a, uint64_t* o) { return arkmpc_ed_mac_check_shares(c, n, k, v, a, o); }
+    static int commit_points(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* bl, uint64_t* o) { return arkmpc_commit_ed_points_sha3(c, n, p, bl, o); }
+    static int mac_verify(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint8_t* ok) { return arkmpc_ed_mac_verify(c, n, a, b, ok); }
+    static int share_sum(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_edshare_sum(c, n, a, o); }
+    // no bucket-method MSM on this curve: CurvePoint::msm as n scalar-muls + one sum (the definition, curve.rs:549-560)
+    static int msm(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) {
+        void* t = nullptr;
+        int rc = arkmpc_malloc(c, (n ? n : 1) * PW * 8, &t);
+        if (!rc && n) rc = arkmpc_ed_scalar_mul(c, n, p, s, (uint64_t*)t);
+        if (!rc) rc = arkmpc_ed_sum(c, n, (const uint64_t*)t, o);
+        if (t) arkmpc_free(c, t);
+        return rc;
+    }
+    static int msm_authenticated(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* ss, uint64_t* o) {
+        void* t = nullptr;
+        int rc = arkmpc_malloc(c, (n ? n : 1) * 2 * PW * 8, &t);
+        if (!rc && n) rc = arkmpc_scalarshare_mul_ed_point(c, n, ss, p, (uint64_t*)t);
+        if (!rc) rc = arkmpc_edshare_sum(c, n, (const uint64_t*)t, o);
+        if (t) arkmpc_free(c, t);
+        return rc;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -286,7 +365,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     arkmpc_ctx* ctx() const { return eng_->dev(); }
 
     ScalarBatch allocate_scalars(const std::vector<Scalar>& mont) {                               // fabric.rs:652-668
-        ScalarBatch b; b.n = mont.size(); b.buf = DeviceBuf(eng_, 4 * (mont.size() ? mont.size() : 1)); b.buf.upload(mont.data(), mont.size() * 32);
+        ScalarBatch b; b.n = mont.size(); b.buf = DeviceBuf(eng_, ARKMPC_KIND_SCALAR, mont.size()); b.buf.upload(mont.data(), mont.size() * 32);
         return b;
     }
     // Wire mode: every batch crosses the mock link as the serde_json frame the QUIC transport would carry, so the
@@ -321,16 +400,30 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         check(ctx(), arkmpc_sync(ctx()), "sync");
         net_->send(NetworkOutbound{next_id_++, {}, {}, std::move(copy)});
     }
-    ScalarBatch receive_values() {
+    // `expect` = the element count the protocol step requires.  What arrives is the PEER's choice (a short, empty or oversized
+    // payload would otherwise be read out of bounds by the kernels launched with the local n), so a mismatch is a network
+    // error here, before any kernel sees the buffer (the reference's `.into()` casts panic on a malformed value,
+    // fabric/result.rs:127-233).  kAnyCount: the caller checks.
+    static constexpr size_t kAnyCount = ~(size_t)0;
+    ScalarBatch receive_values(size_t expect = kAnyCount) {
+        ScalarBatch b = receive_values_unchecked();
+        if (expect != kAnyCount && b.n != expect)
+            throw std::runtime_error("MpcNetworkError: peer sent " + std::to_string(b.n) + " scalars where " + std::to_string(expect) + " were expected");
+        return b;
+    }
+    ScalarBatch receive_values_unchecked() {
         NetworkOutbound m = net_->receive();
         const uint64_t id = next_id_++;
-        if (link_ == LinkMode::Device) { ScalarBatch b; b.n = m.dev->words() / 4; b.buf = std::move(*m.dev); b.buf.rebind(eng_); return b; }
+        if (link_ == LinkMode::Device) {
+            if (!m.dev) throw std::runtime_error("MpcNetworkError: device link message without a buffer");
+            ScalarBatch b; b.n = m.dev->words() / 4; b.buf = std::move(*m.dev); b.buf.rebind(eng_); return b;
+        }
         if (!wire_) return allocate_scalars(m.payload);
         // the element count is only known after parsing: a scalar's text is at least 66 bytes ("[0,0,...,0]," )
         const size_t max_n = m.frame.size() / 66 + 1;
         DeviceBuf fr(eng_, m.frame.size() / 8 + 2);
         fr.upload(m.frame.data(), m.frame.size());
-        ScalarBatch b; b.buf = DeviceBuf(eng_, 4 * max_n);
+        ScalarBatch b; b.buf = DeviceBuf(eng_, ARKMPC_KIND_SCALAR, max_n);
         size_t n = 0; uint64_t rid = 0;
         check(ctx(), arkmpc_wire_decode_scalar_batch(ctx(), reinterpret_cast<const uint8_t*>(fr.ptr()), m.frame.size(), max_n, b.buf.ptr(), &n, &rid),
               "wire_decode_scalar_batch");
@@ -338,31 +431,33 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         b.n = n;
         return b;
     }
+    // both parties send a batch of the same length (every exchange on this path is symmetric): the peer's must match
     ScalarBatch exchange_values(const ScalarBatch& mine) {
-        if (party_ == PARTY0) { send_values(mine); return receive_values(); }
-        ScalarBatch peer = receive_values(); send_values(mine); return peer;
+        if (party_ == PARTY0) { send_values(mine); return receive_values(mine.n); }
+        ScalarBatch peer = receive_values(mine.n); send_values(mine); return peer;
     }
     // batch_share_plaintext (fabric.rs:602-620): the sender's values become public on both sides
     ScalarBatch batch_share_plaintext(const std::vector<Scalar>& mont, size_t n, PartyId sender) {
         if (party_ == sender) { ScalarBatch b = allocate_scalars(mont); send_values(b); return b; }
-        (void)n; return receive_values();
+        return receive_values(n);
     }
     // Point batches (NetworkPayload::PointBatch, network.rs:45-60).  Mock mode: 12 x u64 Jacobian limbs per point packed
     // into the payload vector.  Wire mode: compressed points (CurvePoint::to_bytes, curve.rs:50-55) as serde_json text; the
     // receiver decompresses with validation (CurvePoint::from_bytes, :57-63).
     template <class PB> void send_points(const PB& mine) {
+        using Cv = typename PB::Curve;
         const size_t n = mine.n;
-        if (link_ == LinkMode::Device) { send_device(mine.buf, 12 * n); return; }
+        if (link_ == LinkMode::Device) { send_device(mine.buf, Cv::PW * n); return; }
         const uint64_t id = next_id_++;
         if (!wire_) {
             std::vector<uint64_t> h = mine.to_host();
-            std::vector<Scalar> pay(3 * n);
+            std::vector<Scalar> pay((Cv::PW * n + 3) / 4);
             std::memcpy(pay.data(), h.data(), h.size() * 8);
             net_->send(NetworkOutbound{id, std::move(pay), {}, {}});
             return;
         }
         DeviceBuf bytes(eng_, 4 * (n ? n : 1));
-        if (n) check(ctx(), arkmpc_g1_to_bytes(ctx(), n, mine.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "g1_to_bytes");
+        if (n) check(ctx(), Cv::to_bytes(ctx(), n, mine.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "point to_bytes");
         size_t cap = 0, len = 0;
         arkmpc_wire_frame_bound(n, &cap);
         DeviceBuf fr(eng_, cap / 8 + 1);
@@ -373,12 +468,21 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         frames_sent()++;
         net_->send(std::move(m));
     }
+    // n = the point count the protocol step requires; a payload of any other size is a network error (never read past)
     template <class PB> PB receive_points(size_t n) {
+        using Cv = typename PB::Curve;
         NetworkOutbound m = net_->receive();
         const uint64_t id = next_id_++;
-        if (link_ == LinkMode::Device) { PB r; r.n = n; r.buf = std::move(*m.dev); r.buf.rebind(eng_); return r; }
-        PB r; r.n = n; r.buf = DeviceBuf(eng_, 12 * (n ? n : 1));
-        if (!wire_) { r.buf.upload(m.payload.data(), n * 96); return r; }
+        if (link_ == LinkMode::Device) {
+            if (!m.dev || m.dev->words() != Cv::PW * n) throw std::runtime_error("MpcNetworkError: unexpected point payload size");
+            PB r; r.n = n; r.buf = std::move(*m.dev); r.buf.rebind(eng_); return r;
+        }
+        PB r; r.n = n; r.buf = DeviceBuf(eng_, ARKMPC_KIND_POINT, n);
+        if (!wire_) {
+            if (m.payload.size() * 4 < Cv::PW * n || m.payload.size() * 4 >= Cv::PW * n + 4) throw std::runtime_error("MpcNetworkError: unexpected point payload size");
+            r.buf.upload(m.payload.data(), n * Cv::PW * 8);
+            return r;
+        }
         DeviceBuf fr(eng_, m.frame.size() / 8 + 2);
         fr.upload(m.frame.data(), m.frame.size());
         DeviceBuf bytes(eng_, 4 * (n ? n : 1));
@@ -387,8 +491,8 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
                                                 reinterpret_cast<uint8_t*>(bytes.ptr()), &cnt, &rid, &kind), "wire_decode_bytes32");
         if (rid != id || cnt != n || kind != ARKMPC_WIRE_POINT_BATCH) throw std::runtime_error("MpcNetworkError: unexpected point frame");
         DeviceBuf okd(eng_, (n + 7) / 8 + 1);
-        if (n) check(ctx(), arkmpc_g1_from_bytes(ctx(), n, reinterpret_cast<const uint8_t*>(bytes.ptr()), r.buf.ptr(), reinterpret_cast<uint8_t*>(okd.ptr())),
-                     "g1_from_bytes");
+        if (n) check(ctx(), Cv::from_bytes(ctx(), n, reinterpret_cast<const uint8_t*>(bytes.ptr()), r.buf.ptr(), reinterpret_cast<uint8_t*>(okd.ptr())),
+                     "point from_bytes");
         std::vector<uint8_t> ok(n);
         okd.download(ok.data(), n);
         for (auto b : ok) if (!b) throw std::runtime_error("MpcNetworkError::SerializationError: invalid point encoding");
@@ -400,6 +504,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     }
     void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c);  // fabric.rs:894-915
     AuthenticatedScalarBatch random_shared_scalars(size_t n);                                    // fabric.rs:917-928
+    AuthenticatedScalarBatch random_shared_bits(size_t n);                                       // fabric.rs:961-984
     void random_inverse_pairs(size_t n, AuthenticatedScalarBatch& l, AuthenticatedScalarBatch& r);  // fabric.rs:942-958
     // fabric.rs:578-600
     AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
@@ -427,7 +532,7 @@ class AuthenticatedScalarBatch {
     std::shared_ptr<MpcFabric> fabric;
 
     static AuthenticatedScalarBatch alloc(const std::shared_ptr<MpcFabric>& f, size_t n) {
-        AuthenticatedScalarBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), 8 * (n ? n : 1)); return r;
+        AuthenticatedScalarBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR_SHARE, n); return r;
     }
     std::vector<ScalarShare> to_host() const { std::vector<ScalarShare> v(n); buf.download(v.data(), n * 64); return v; }
 
@@ -472,10 +577,9 @@ class AuthenticatedScalarBatch {
         AuthenticatedScalarBatch ta, tb, tc;
         f->next_triple_batch(n, ta, tb, tc);                                                  // :859
         // masked_lhs = a - beaver_a, masked_rhs = b - beaver_b, all_masks = lhs || rhs; open_batch sends `.share()` (:863-868, :141-145)
-        ScalarBatch my_de; my_de.n = 2 * n; my_de.buf = DeviceBuf(f->engine(), 8 * n);
+        ScalarBatch my_de; my_de.n = 2 * n; my_de.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, 2 * n);
         check(f->ctx(), arkmpc_beaver_mask(f->ctx(), n, a.buf.ptr(), b.buf.ptr(), ta.buf.ptr(), tb.buf.ptr(), my_de.buf.ptr()), "beaver_mask");
-        ScalarBatch peer_de = f->exchange_values(my_de);                                      // the one network round
-        if (peer_de.n != 2 * n) throw std::runtime_error("MpcNetworkError: unexpected payload size");
+        ScalarBatch peer_de = f->exchange_values(my_de);                                      // the one network round (length-checked: 2n)
         auto r = alloc(f, n);                                                                 // combine (:161-171) + de + d[b] + e[a] + [c] (:871-878)
         check(f->ctx(), arkmpc_beaver_finish_fused(f->ctx(), n, (int)f->party_id(), f->mac_key().l, my_de.buf.ptr(), peer_de.buf.ptr(),
                                                    ta.buf.ptr(), tb.buf.ptr(), tc.buf.ptr(), r.buf.ptr()), "beaver_finish_fused");
@@ -489,7 +593,7 @@ class AuthenticatedScalarBatch {
         AuthenticatedScalarBatch masked = batch_mul(values, r);                                    // step 2: m_i = r_i * x_i
         AuthenticatedOpenResult opened = masked.open_authenticated_batch(blinder);
         if (err) *err = opened.err;
-        ScalarBatch inv; inv.n = values.n; inv.buf = DeviceBuf(f->engine(), 4 * values.n);         // step 3: ScalarResult::batch_inverse
+        ScalarBatch inv; inv.n = values.n; inv.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, values.n);         // step 3: ScalarResult::batch_inverse
         check(f->ctx(), arkmpc_scalar_batch_inverse(f->ctx(), values.n, opened.value.buf.ptr(), inv.buf.ptr()), "scalar_batch_inverse");
         return batch_mul_public(r, inv);                                                           // step 4: m_i^-1 * r_i = x_i^-1
     }
@@ -500,11 +604,11 @@ class AuthenticatedScalarBatch {
     }
     // ---- opening (:129-172, :278-354) -----------------------------------------------------------------------
     ScalarBatch open_batch() const {
-        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(fabric->engine(), 4 * (n ? n : 1));
+        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(fabric->engine(), ARKMPC_KIND_SCALAR, n);
         if (n == 0) return mine;
         check(fabric->ctx(), arkmpc_share_extract(fabric->ctx(), n, buf.ptr(), mine.buf.ptr()), "share_extract");
         ScalarBatch peer = fabric->exchange_values(mine);
-        ScalarBatch out; out.n = n; out.buf = DeviceBuf(fabric->engine(), 4 * n);
+        ScalarBatch out; out.n = n; out.buf = DeviceBuf(fabric->engine(), ARKMPC_KIND_SCALAR, n);
         check(fabric->ctx(), arkmpc_open_combine(fabric->ctx(), n, mine.buf.ptr(), peer.buf.ptr(), out.buf.ptr()), "open_combine");
         return out;
     }
@@ -514,11 +618,11 @@ class AuthenticatedScalarBatch {
         auto f = fabric;
         if (n == 0) return res;                                                                   // :279-281
         arkmpc_ctx* c = f->ctx();
-        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(f->engine(), 4 * n);
+        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
         check(c, arkmpc_share_extract(c, n, buf.ptr(), mine.buf.ptr()), "share_extract");
         ScalarBatch peer = f->exchange_values(mine);                                              // round 1: open_batch
-        ScalarBatch opened; opened.n = n; opened.buf = DeviceBuf(f->engine(), 4 * n);
-        ScalarBatch chk; chk.n = n; chk.buf = DeviceBuf(f->engine(), 4 * n);
+        ScalarBatch opened; opened.n = n; opened.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
+        ScalarBatch chk; chk.n = n; chk.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
         check(c, arkmpc_open_and_mac_check(c, n, f->mac_key().l, buf.ptr(), peer.buf.ptr(), opened.buf.ptr(), chk.buf.ptr()), "open_and_mac_check");   // :161-171 + :299-311
         Scalar my_comm;
         check(c, arkmpc_commit_sha3(c, n, chk.buf.ptr(), blinder.l, my_comm.l), "commit_sha3");  // batch_commit (commitment.rs:63-89)
@@ -564,67 +668,78 @@ class AuthenticatedScalarBatch {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Points: CurvePointResult batches and AuthenticatedPointResult batches (BN254 G1, 12 / 24 x u64 per element)
+// Points: CurvePointResult batches and AuthenticatedPointResult batches, generic over the curve like the reference
+// (`C: CurveGroup`): PointBatchT<Bn254G1> = 12 / 24 x u64 per element, PointBatchT<Curve25519> = 16 / 32.
 // ---------------------------------------------------------------------------------------------------------------
-struct PointBatch {   // Vec<CurvePointResult<C>>: n public Jacobian points on the GPU
+template <class Cv> struct PointBatchT {   // Vec<CurvePointResult<C>>: n public points on the GPU
+    using Curve = Cv;
     size_t n = 0;
     DeviceBuf buf;
-    std::vector<uint64_t> to_host() const { std::vector<uint64_t> v(12 * n); buf.download(v.data(), n * 96); return v; }
+    std::vector<uint64_t> to_host() const { std::vector<uint64_t> v(Cv::PW * n); buf.download(v.data(), n * Cv::PW * 8); return v; }
 };
-struct PointOpenResult {   // AuthenticatedPointOpenResult (authenticated_curve.rs:286-322), one MAC-check flag per element
+template <class Cv> struct PointOpenResultT {   // AuthenticatedPointOpenResult (authenticated_curve.rs:286-322), one MAC-check flag per element
     std::vector<uint8_t> ok;     // 1 = commitment opened correctly and MAC shares sum to the identity
-    PointBatch value;
+    PointBatchT<Cv> value;
     MpcError err() const { for (auto b : ok) if (!b) return MpcError::AuthenticationError; return MpcError::None; }
 };
 
-class AuthenticatedPointBatch {
+template <class Cv> class AuthenticatedPointBatchT {
   public:
+    using Curve = Cv;
+    using PointBatch = PointBatchT<Cv>;
+    using PointOpenResult = PointOpenResultT<Cv>;
+    using Self = AuthenticatedPointBatchT<Cv>;
     size_t n = 0;
     DeviceBuf buf;
     std::shared_ptr<MpcFabric> fabric;
-    static AuthenticatedPointBatch alloc(const std::shared_ptr<MpcFabric>& f, size_t n) {
-        AuthenticatedPointBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), 24 * (n ? n : 1)); return r;
+    static Self alloc(const std::shared_ptr<MpcFabric>& f, size_t n) {
+        Self r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), ARKMPC_KIND_POINT_SHARE, n); return r;
     }
     static PointBatch alloc_points(const std::shared_ptr<MpcFabric>& f, size_t n) {
-        PointBatch r; r.n = n; r.buf = DeviceBuf(f->engine(), 12 * (n ? n : 1)); return r;
+        PointBatch r; r.n = n; r.buf = DeviceBuf(f->engine(), ARKMPC_KIND_POINT, n); return r;
     }
     // ---- linear ops (authenticated_curve.rs:396-621) ----
-    static AuthenticatedPointBatch batch_add(const AuthenticatedPointBatch& a, const AuthenticatedPointBatch& b) {   // :396-426
-        auto r = alloc(a.fabric, a.n); check(c(a), arkmpc_pointshare_add(c(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_add"); return r;
+    static Self batch_add(const Self& a, const Self& b) {                                                            // :396-426
+        same(a.n, b.n); auto r = alloc(a.fabric, a.n); check(c(a), Cv::share_add(c(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_add"); return r;
     }
-    static AuthenticatedPointBatch batch_sub(const AuthenticatedPointBatch& a, const AuthenticatedPointBatch& b) {   // :520-550
-        auto r = alloc(a.fabric, a.n); check(c(a), arkmpc_pointshare_sub(c(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_sub"); return r;
+    static Self batch_sub(const Self& a, const Self& b) {                                                            // :520-550
+        same(a.n, b.n); auto r = alloc(a.fabric, a.n); check(c(a), Cv::share_sub(c(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_sub"); return r;
     }
-    static AuthenticatedPointBatch batch_neg(const AuthenticatedPointBatch& a) {                                     // :604-621
-        auto r = alloc(a.fabric, a.n); check(c(a), arkmpc_pointshare_neg(c(a), a.n, a.buf.ptr(), r.buf.ptr()), "pointshare_neg"); return r;
+    static Self batch_neg(const Self& a) {                                                                           // :604-621
+        auto r = alloc(a.fabric, a.n); check(c(a), Cv::share_neg(c(a), a.n, a.buf.ptr(), r.buf.ptr()), "pointshare_neg"); return r;
     }
-    static AuthenticatedPointBatch batch_add_public(const AuthenticatedPointBatch& a, const PointBatch& b) {         // :429-463
-        auto r = alloc(a.fabric, a.n);
-        check(c(a), arkmpc_pointshare_add_public(c(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_add_public");
+    static Self batch_add_public(const Self& a, const PointBatch& b) {                                               // :429-463
+        same(a.n, b.n); auto r = alloc(a.fabric, a.n);
+        check(c(a), Cv::share_add_public(c(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_add_public");
         return r;
     }
-    static AuthenticatedPointBatch batch_mul_public(const ScalarBatch& s, const AuthenticatedPointBatch& b) {        // :718-751
-        auto r = alloc(b.fabric, b.n); check(c(b), arkmpc_pointshare_mul_public(c(b), b.n, b.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "pointshare_mul_public"); return r;
+    static Self batch_sub_public(const Self& a, const PointBatch& b) {                                               // :553-575 (curve/share.rs:63-65)
+        same(a.n, b.n); auto r = alloc(a.fabric, a.n);
+        check(c(a), Cv::share_sub_public(c(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "pointshare_sub_public");
+        return r;
     }
-    static AuthenticatedPointBatch batch_mul_generator(const AuthenticatedScalarBatch& a) {                           // :754-780
-        auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), arkmpc_scalarshare_mul_generator(a.fabric->ctx(), a.n, a.buf.ptr(), r.buf.ptr()), "mul_generator"); return r;
+    static Self batch_mul_public(const ScalarBatch& s, const Self& b) {                                              // :718-751
+        same(s.n, b.n); auto r = alloc(b.fabric, b.n); check(c(b), Cv::share_mul_public(c(b), b.n, b.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "pointshare_mul_public"); return r;
+    }
+    static Self batch_mul_generator(const AuthenticatedScalarBatch& a) {                                              // :754-780
+        auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), Cv::scalarshare_mul_generator(a.fabric->ctx(), a.n, a.buf.ptr(), r.buf.ptr()), "mul_generator"); return r;
     }
     // CurvePointResult::batch_mul (curve.rs:459-479) and batch_mul_authenticated (curve.rs:483-517)
     static PointBatch point_batch_mul(const std::shared_ptr<MpcFabric>& f, const ScalarBatch& s, const PointBatch& p) {
-        auto r = alloc_points(f, p.n); check(f->ctx(), arkmpc_g1_scalar_mul(f->ctx(), p.n, p.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "g1_scalar_mul"); return r;
+        same(s.n, p.n); auto r = alloc_points(f, p.n); check(f->ctx(), Cv::scalar_mul(f->ctx(), p.n, p.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "scalar_mul"); return r;
     }
-    static AuthenticatedPointBatch batch_mul_authenticated(const AuthenticatedScalarBatch& a, const PointBatch& p) {
-        auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), arkmpc_scalarshare_mul_point(a.fabric->ctx(), a.n, a.buf.ptr(), p.buf.ptr(), r.buf.ptr()), "scalarshare_mul_point"); return r;
+    static Self batch_mul_authenticated(const AuthenticatedScalarBatch& a, const PointBatch& p) {
+        same(a.n, p.n); auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), Cv::scalarshare_mul_point(a.fabric->ctx(), a.n, a.buf.ptr(), p.buf.ptr(), r.buf.ptr()), "scalarshare_mul_point"); return r;
     }
     // ---- opening (:66-109) ----
     PointBatch open_batch() const {
         auto f = fabric;
         PointBatch mine = alloc_points(f, n);
         if (n == 0) return mine;
-        check(f->ctx(), arkmpc_pointshare_extract(f->ctx(), n, buf.ptr(), mine.buf.ptr()), "pointshare_extract");
+        check(f->ctx(), Cv::share_extract(f->ctx(), n, buf.ptr(), mine.buf.ptr()), "pointshare_extract");
         PointBatch peer = f->exchange_points(mine);
         PointBatch out = alloc_points(f, n);
-        check(f->ctx(), arkmpc_g1_add(f->ctx(), n, mine.buf.ptr(), peer.buf.ptr(), out.buf.ptr()), "g1_add");
+        check(f->ctx(), Cv::add(f->ctx(), n, mine.buf.ptr(), peer.buf.ptr(), out.buf.ptr()), "point add");
         return out;
     }
     // :190-283 -- per-element commitments (n separate SHA3 commits, :227), three exchanges, per-element verification
@@ -632,20 +747,21 @@ class AuthenticatedPointBatch {
         PointOpenResult res;
         auto f = fabric;
         if (n == 0) return res;
+        if (blinders_mont.size() != n) throw std::invalid_argument("one blinder per element");
         arkmpc_ctx* cx = f->ctx();
         PointBatch opened = open_batch();
         PointBatch chk = alloc_points(f, n);                                                       // value*mac_key - mac (:215-220)
-        check(cx, arkmpc_point_mac_check_shares(cx, n, f->mac_key().l, opened.buf.ptr(), buf.ptr(), chk.buf.ptr()), "point_mac_check_shares");
+        check(cx, Cv::mac_check_shares(cx, n, f->mac_key().l, opened.buf.ptr(), buf.ptr(), chk.buf.ptr()), "point_mac_check_shares");
         ScalarBatch bl = f->allocate_scalars(blinders_mont);
-        ScalarBatch comm; comm.n = n; comm.buf = DeviceBuf(f->engine(), 4 * n);
-        check(cx, arkmpc_commit_points_sha3(cx, n, chk.buf.ptr(), bl.buf.ptr(), comm.buf.ptr()), "commit_points_sha3");
-        ScalarBatch peer_comm = f->exchange_values(comm);                                          // commitments
+        ScalarBatch comm; comm.n = n; comm.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
+        check(cx, Cv::commit_points(cx, n, chk.buf.ptr(), bl.buf.ptr(), comm.buf.ptr()), "commit_points_sha3");
+        ScalarBatch peer_comm = f->exchange_values(comm);                                          // commitments   (length-checked: n)
         PointBatch peer_chk = f->exchange_points(chk);                                             // MAC-check points
         ScalarBatch peer_bl = f->exchange_values(bl);                                              // blinders
-        ScalarBatch recomputed; recomputed.n = n; recomputed.buf = DeviceBuf(f->engine(), 4 * n);
-        check(cx, arkmpc_commit_points_sha3(cx, n, peer_chk.buf.ptr(), peer_bl.buf.ptr(), recomputed.buf.ptr()), "commit_points_sha3(verify)");
+        ScalarBatch recomputed; recomputed.n = n; recomputed.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
+        check(cx, Cv::commit_points(cx, n, peer_chk.buf.ptr(), peer_bl.buf.ptr(), recomputed.buf.ptr()), "commit_points_sha3(verify)");
         DeviceBuf okd(f->engine(), (n + 7) / 8 + 1);
-        check(cx, arkmpc_point_mac_verify(cx, n, chk.buf.ptr(), peer_chk.buf.ptr(), reinterpret_cast<uint8_t*>(okd.ptr())), "point_mac_verify");
+        check(cx, Cv::mac_verify(cx, n, chk.buf.ptr(), peer_chk.buf.ptr(), reinterpret_cast<uint8_t*>(okd.ptr())), "point_mac_verify");
         res.ok.resize(n);
         okd.download(res.ok.data(), n);
         std::vector<Scalar> rc = recomputed.to_host(), pc = peer_comm.to_host();
@@ -654,75 +770,85 @@ class AuthenticatedPointBatch {
         return res;
     }
     // ---- Beaver point x shared-scalar multiplication (:682-714): [x * yG] = deG + d[bG] + [a]eG + [c]G ----
-    static AuthenticatedPointBatch batch_mul(const AuthenticatedScalarBatch& a, const AuthenticatedPointBatch& b) {
+    static Self batch_mul(const AuthenticatedScalarBatch& a, const Self& b) {
+        same(a.n, b.n);
         const size_t n = a.n;
         auto f = a.fabric;
         if (n == 0) return alloc(f, 0);
         AuthenticatedScalarBatch ta, tb, tc;
         f->next_triple_batch(n, ta, tb, tc);
-        AuthenticatedPointBatch beaver_b_gen = batch_mul_generator(tb);                           // :696
+        Self beaver_b_gen = batch_mul_generator(tb);                                               // :696
         AuthenticatedScalarBatch masked_rhs = AuthenticatedScalarBatch::batch_sub(a, ta);          // :698
-        AuthenticatedPointBatch masked_lhs = batch_sub(b, beaver_b_gen);                           // :699
+        Self masked_lhs = batch_sub(b, beaver_b_gen);                                              // :699
         PointBatch eG_open = masked_lhs.open_batch();                                              // :701
         ScalarBatch d_open = masked_rhs.open_batch();                                              // :702
         PointBatch deG = point_batch_mul(f, d_open, eG_open);                                      // :705
-        AuthenticatedPointBatch dbG = batch_mul_public(d_open, beaver_b_gen);                      // :706
-        AuthenticatedPointBatch aeG = batch_mul_authenticated(ta, eG_open);                        // :707
-        AuthenticatedPointBatch cG = batch_mul_generator(tc);                                      // :708
-        AuthenticatedPointBatch de_db_G = batch_add_public(dbG, deG);                              // :710
-        AuthenticatedPointBatch ae_c_G = batch_add(aeG, cG);                                       // :711
+        Self dbG = batch_mul_public(d_open, beaver_b_gen);                                         // :706
+        Self aeG = batch_mul_authenticated(ta, eG_open);                                           // :707
+        Self cG = batch_mul_generator(tc);                                                         // :708
+        Self de_db_G = batch_add_public(dbG, deG);                                                 // :710
+        Self ae_c_G = batch_add(aeG, cG);                                                          // :711
         return batch_add(de_db_G, ae_c_G);                                                         // :713
     }
 
     // ---- multiscalar multiplication (:787-806): batch_mul, then one gate summing the PointShares ----
-    static AuthenticatedPointBatch msm(const AuthenticatedScalarBatch& scalars, const AuthenticatedPointBatch& points) {
+    static Self msm(const AuthenticatedScalarBatch& scalars, const Self& points) {
         if (scalars.n != points.n) throw std::invalid_argument("multiscalar_mul requires equal length vectors");
         if (scalars.n == 0) throw std::invalid_argument("multiscalar_mul requires non-empty vectors");
-        AuthenticatedPointBatch prod = batch_mul(scalars, points);
-        AuthenticatedPointBatch r = alloc(points.fabric, 1);
-        check(c(points), arkmpc_pointshare_sum(c(points), prod.n, prod.buf.ptr(), r.buf.ptr()), "pointshare_sum");
+        Self prod = batch_mul(scalars, points);
+        Self r = alloc(points.fabric, 1);
+        check(c(points), Cv::share_sum(c(points), prod.n, prod.buf.ptr(), r.buf.ptr()), "pointshare_sum");
         return r;
     }
     // CurvePoint::msm / CurvePointResult::msm_results (curve.rs:549-560, :588-603): public scalars x public points -> one point
     static PointBatch point_msm(const std::shared_ptr<MpcFabric>& f, const ScalarBatch& scalars, const PointBatch& points) {
         if (scalars.n != points.n) throw std::invalid_argument("msm cannot compute on vectors of unequal length");
         auto r = alloc_points(f, 1);
-        check(f->ctx(), arkmpc_g1_msm(f->ctx(), points.n, points.buf.ptr(), scalars.buf.ptr(), r.buf.ptr()), "g1_msm");
+        check(f->ctx(), Cv::msm(f->ctx(), points.n, points.buf.ptr(), scalars.buf.ptr(), r.buf.ptr()), "msm");
         return r;
     }
     // CurvePointResult::msm_authenticated (curve.rs:618-642 / :701-731): authenticated scalars x public points; a local
-    // gate -- PointShare(msm(shares, P), msm(macs, P)) -- both columns in one bucket-method pass on the GPU
-    static AuthenticatedPointBatch msm_authenticated(const AuthenticatedScalarBatch& scalars, const PointBatch& points) {
+    // gate -- PointShare(msm(shares, P), msm(macs, P))
+    static Self msm_authenticated(const AuthenticatedScalarBatch& scalars, const PointBatch& points) {
         if (scalars.n != points.n) throw std::invalid_argument("msm cannot compute on vectors of unequal length");
         auto r = alloc(scalars.fabric, 1);
-        check(scalars.fabric->ctx(),
-              arkmpc_g1_msm_authenticated(scalars.fabric->ctx(), points.n, points.buf.ptr(), scalars.buf.ptr(), r.buf.ptr()), "g1_msm_authenticated");
+        check(scalars.fabric->ctx(), Cv::msm_authenticated(scalars.fabric->ctx(), points.n, points.buf.ptr(), scalars.buf.ptr(), r.buf.ptr()), "msm_authenticated");
         return r;
     }
 
   private:
-    static arkmpc_ctx* c(const AuthenticatedPointBatch& a) { return a.fabric->ctx(); }
+    static arkmpc_ctx* c(const Self& a) { return a.fabric->ctx(); }
+    static void same(size_t a, size_t b) { if (a != b) throw std::invalid_argument("Cannot operate on batches of different sizes"); }
 };
+using PointBatch = PointBatchT<Bn254G1>;
+using PointOpenResult = PointOpenResultT<Bn254G1>;
+using AuthenticatedPointBatch = AuthenticatedPointBatchT<Bn254G1>;
+using EdPointBatch = PointBatchT<Curve25519>;
+using EdPointOpenResult = PointOpenResultT<Curve25519>;
+using AuthenticatedEdPointBatch = AuthenticatedPointBatchT<Curve25519>;
 
 // fabric.rs:622-649: the sender broadcasts val - mask*G; both sides compute mask_share*G + masked (batch_mul_generator, batch_add_public)
 template <class APB>
 inline APB MpcFabric::batch_share_point(const std::vector<uint64_t>& points, size_t n, PartyId sender) {
+    using Cv = typename APB::Curve;
+    using PB = typename APB::PointBatch;
     auto self = shared_from_this();
-    PointBatch masked;
+    PB masked;
     std::vector<ScalarShare> mask_shares;
     if (party_ == sender) {
+        if (points.size() != Cv::PW * n) throw std::invalid_argument("batch_share_point: n points expected");
         auto lm = prep_->next_local_input_mask_batch(n);
         ScalarBatch masks = allocate_scalars(lm.first);
-        PointBatch mg = APB::alloc_points(self, n), vals = APB::alloc_points(self, n);
-        vals.buf.upload(points.data(), n * 96);
-        if (n) check(ctx(), arkmpc_g1_generator_mul(ctx(), n, masks.buf.ptr(), mg.buf.ptr()), "g1_generator_mul");
+        PB mg = APB::alloc_points(self, n), vals = APB::alloc_points(self, n);
+        vals.buf.upload(points.data(), n * Cv::PW * 8);
+        if (n) check(ctx(), Cv::generator_mul(ctx(), n, masks.buf.ptr(), mg.buf.ptr()), "generator_mul");
         masked = APB::alloc_points(self, n);
-        if (n) check(ctx(), arkmpc_g1_sub(ctx(), n, vals.buf.ptr(), mg.buf.ptr(), masked.buf.ptr()), "g1_sub");
+        if (n) check(ctx(), Cv::sub(ctx(), n, vals.buf.ptr(), mg.buf.ptr(), masked.buf.ptr()), "point sub");
         send_points(masked);                                // plaintext broadcast of the masked points (batch_share_plaintext)
         mask_shares = std::move(lm.second);
     } else {
         mask_shares = prep_->next_counterparty_input_mask_batch(n);
-        masked = receive_points<PointBatch>(n);
+        masked = receive_points<PB>(n);
     }
     AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
     APB masks_g = APB::batch_mul_generator(shares);
@@ -758,6 +884,12 @@ inline void MpcFabric::random_inverse_pairs(size_t n, AuthenticatedScalarBatch& 
     next_id_ += 2 * n;
     l = allocate_scalar_shares(hl); r = allocate_scalar_shares(hr);
 }
+inline AuthenticatedScalarBatch MpcFabric::random_shared_bits(size_t n) {
+    std::vector<ScalarShare> v = prep_->next_shared_bit_batch(n);
+    if (v.size() != n) throw std::runtime_error("preprocessing exhausted");
+    next_id_ += n;
+    return allocate_scalar_shares(v);
+}
 inline AuthenticatedScalarBatch MpcFabric::random_shared_scalars(size_t n) {
     std::vector<ScalarShare> v = prep_->next_shared_value_batch(n);
     next_id_ += n;
@@ -771,26 +903,26 @@ inline AuthenticatedScalarBatch MpcFabric::batch_share_scalar(const std::vector<
     if (prep_->constant_input_masks(cv, cl, cc)) {            // masks described by one value: filled on the GPU
         if (party_ == sender) {
             ScalarBatch vals = allocate_scalars(vals_mont), masks;
-            masks.n = n; masks.buf = DeviceBuf(eng_, 4 * (n ? n : 1));
+            masks.n = n; masks.buf = DeviceBuf(eng_, ARKMPC_KIND_SCALAR, n);
             check(ctx(), arkmpc_fill(ctx(), n, 4, cv.l, masks.buf.ptr()), "fill");
-            masked.n = n; masked.buf = DeviceBuf(eng_, 4 * (n ? n : 1));
+            masked.n = n; masked.buf = DeviceBuf(eng_, ARKMPC_KIND_SCALAR, n);
             if (n) check(ctx(), arkmpc_scalar_sub(ctx(), n, vals.buf.ptr(), masks.buf.ptr(), masked.buf.ptr()), "scalar_sub");
             send_values(masked);
         } else {
-            masked = receive_values();
+            masked = receive_values(n);
         }
         return AuthenticatedScalarBatch::batch_add_public(fill_scalar_shares(party_ == sender ? cl : cc, n), masked);
     }
     if (party_ == sender) {
         auto lm = prep_->next_local_input_mask_batch(n);
         ScalarBatch vals = allocate_scalars(vals_mont), masks = allocate_scalars(lm.first);
-        masked.n = n; masked.buf = DeviceBuf(eng_, 4 * (n ? n : 1));
+        masked.n = n; masked.buf = DeviceBuf(eng_, ARKMPC_KIND_SCALAR, n);
         if (n) check(ctx(), arkmpc_scalar_sub(ctx(), n, vals.buf.ptr(), masks.buf.ptr(), masked.buf.ptr()), "scalar_sub");
         send_values(masked);
         mask_shares = std::move(lm.second);
     } else {
         mask_shares = prep_->next_counterparty_input_mask_batch(n);
-        masked = receive_values();
+        masked = receive_values(n);
     }
     AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
     return AuthenticatedScalarBatch::batch_add_public(shares, masked);
@@ -806,7 +938,7 @@ inline AuthenticatedScalarBatch prefix_product(const AuthenticatedScalarBatch& v
     AuthenticatedScalarBatch blinded = AuthenticatedScalarBatch::batch_mul(partial_blind, b.slice(1, n));           // :114
     AuthenticatedOpenResult opened = blinded.open_authenticated_batch(blinder);                           // :117-120
     if (err) *err = opened.err;
-    ScalarBatch prefixes; prefixes.n = n; prefixes.buf = DeviceBuf(f->engine(), 4 * (n ? n : 1));          // :131-137
+    ScalarBatch prefixes; prefixes.n = n; prefixes.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);          // :131-137
     check(f->ctx(), arkmpc_scalar_prefix_product(f->ctx(), n, opened.value.buf.ptr(), prefixes.buf.ptr()), "scalar_prefix_product");
     AuthenticatedScalarBatch partial_unblind = AuthenticatedScalarBatch::batch_mul_public(b.repeat(0, n), prefixes);  // :146
     return AuthenticatedScalarBatch::batch_mul(partial_unblind, b_inv.slice(1, n));                       // :147

@@ -21,6 +21,60 @@ struct PartyOut {
     std::vector<Scalar> opened;   // canonical
 };
 
+// Point-side scenarios, generic over the curve like the reference's tests (BN254 G1 for field 0, Curve25519 for field 2).
+// Output: number of failed per-element MAC checks, then the opened points in the compressed encoding (32 bytes each).
+template <class APB>
+static PartyOut point_scenario(std::shared_ptr<MpcFabric> fabric, const std::string& scenario, size_t n, const std::vector<Scalar>& a_m,
+                               const std::vector<Scalar>& b_m, bool bad_mac) {
+    using Cv = typename APB::Curve;
+    using PB = typename APB::PointBatch;
+    const Engine& eng = *fabric->engine();
+    auto gen_mul = [&](const std::vector<Scalar>& s_m) {          // [s_i]G as a public batch
+        ScalarBatch sc = fabric->allocate_scalars(s_m);
+        PB pg = APB::alloc_points(fabric, s_m.size());
+        if (!s_m.empty()) check(fabric->ctx(), Cv::generator_mul(fabric->ctx(), s_m.size(), sc.buf.ptr(), pg.buf.ptr()), "generator_mul");
+        return pg;
+    };
+    APB Z;
+    if (scenario == "share_point") {
+        // batch_share_point (fabric.rs:622-649): party 0 shares P_i = [a_i]G; open_authenticated must return P_i
+        std::vector<uint64_t> pts = gen_mul(a_m).to_host();       // both parties can compute it here; only the sender's copy is used
+        Z = fabric->batch_share_point<APB>(pts, n, PARTY0);
+    } else if (scenario == "point_sub_public") {
+        // AuthenticatedPointResult - CurvePointResult (authenticated_curve.rs:553-575 -> PointShare::sub_public, curve/share.rs:63-65):
+        // share [a_i]G, subtract the public [b_i]G: opens to [(a_i - b_i)]G with a valid MAC
+        std::vector<uint64_t> pts = gen_mul(a_m).to_host();
+        APB A = fabric->batch_share_point<APB>(pts, n, PARTY1);
+        Z = APB::batch_sub_public(A, gen_mul(b_m));
+    } else {
+        // AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714, test :1222-1244): share x, share y,
+        // Y = [y]G, Z = batch_mul(x, Y), open_authenticated; out = compressed points of Z  (expected (x*y) G)
+        auto x = fabric->batch_share_scalar(a_m, n, PARTY0);
+        auto y = fabric->batch_share_scalar(b_m, n, PARTY1);
+        auto Y = APB::batch_mul_generator(y);
+        if (scenario == "msm_public_points") Z = APB::msm_authenticated(x, gen_mul(b_m));     // curve.rs:618-642: bases [b_i]G public
+        else Z = (scenario == "msm") ? APB::msm(x, Y) : APB::batch_mul(x, Y);
+    }
+    const size_t zn = Z.n;    // msm collapses the batch to one point
+    if (fabric->party_id() == PARTY0 && zn && bad_mac) {          // corrupt one MAC point: make it the share point
+        std::vector<uint64_t> h(2 * Cv::PW * zn); Z.buf.download(h.data(), h.size() * 8);
+        std::memcpy(&h[2 * Cv::PW * (zn / 2) + Cv::PW], &h[2 * Cv::PW * (zn / 2)], Cv::PW * 8);
+        Z.buf.upload(h.data(), h.size() * 8);
+    }
+    std::vector<Scalar> bl(zn);
+    for (size_t i = 0; i < zn; ++i) bl[i] = eng.from_u64(1000 + 7 * i + fabric->party_id());
+    auto o = Z.open_authenticated_batch(bl);
+    PartyOut out;
+    for (size_t i = 0; i < zn; ++i) if (!o.ok[i]) out.err += 1;          // number of failed MAC checks
+    out.opened.resize(zn);
+    if (zn) {
+        DeviceBuf bytes(fabric->engine(), 4 * zn);
+        check(fabric->ctx(), Cv::to_bytes(fabric->ctx(), zn, o.value.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "to_bytes");
+        bytes.download(out.opened.data(), zn * 32);
+    }
+    return out;
+}
+
 int main(int argc, char** argv) {
     if (argc < 6) { std::fprintf(stderr, "usage: %s <scenario> <field_id> <n> <in_file> <out_file> [--bad-mac|--bad-share]\n", argv[0]); return 2; }
     const std::string scenario = argv[1];
@@ -78,63 +132,19 @@ int main(int argc, char** argv) {
                 // AuthenticatedScalarResult::batch_inverse (authenticated_scalar.rs:55-82, test :1640-1660): open(inverse(x)) == x^-1
                 auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
                 res = AuthenticatedScalarBatch::batch_inverse(a, eng.from_u64(777 + fabric->party_id()));
-            } else if (scenario == "share_point") {
-                // batch_share_point (fabric.rs:622-649): party 0 shares P_i = [a_i]G; open_authenticated must return P_i
-                std::vector<uint64_t> pts(12 * n);
-                {
-                    ScalarBatch sa = fabric->allocate_scalars(a_m);
-                    PointBatch pg = AuthenticatedPointBatch::alloc_points(fabric, n);
-                    if (n) check(fabric->ctx(), arkmpc_g1_generator_mul(fabric->ctx(), n, sa.buf.ptr(), pg.buf.ptr()), "g1_generator_mul");
-                    pts = pg.to_host();          // both parties can compute it here; only the sender's copy is used
-                }
-                auto Z = fabric->batch_share_point<AuthenticatedPointBatch>(pts, n, PARTY0);
-                std::vector<Scalar> bl(n);
-                for (size_t i = 0; i < n; ++i) bl[i] = eng.from_u64(31 + i + fabric->party_id());
-                PointOpenResult o = Z.open_authenticated_batch(bl);
-                PartyOut out;
-                for (size_t i = 0; i < n; ++i) if (!o.ok[i]) out.err += 1;
-                out.opened.resize(n);
-                if (n) {
-                    DeviceBuf bytes(fabric->engine(), 4 * n);
-                    check(fabric->ctx(), arkmpc_g1_to_bytes(fabric->ctx(), n, o.value.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "g1_to_bytes");
-                    bytes.download(out.opened.data(), n * 32);
-                }
-                return out;
-            } else if (scenario == "point_mul" || scenario == "msm" || scenario == "msm_public_points") {
-                // AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714, test :1222-1244): share x, share y,
-                // Y = [y]G, Z = batch_mul(x, Y), open_authenticated; out = compressed points of Z  (expected (x*y) G)
-                auto x = fabric->batch_share_scalar(a_m, n, PARTY0);
-                auto y = fabric->batch_share_scalar(b_m, n, PARTY1);
-                auto Y = AuthenticatedPointBatch::batch_mul_generator(y);
-                AuthenticatedPointBatch Z;
-                if (scenario == "msm_public_points") {
-                    // msm_authenticated (curve.rs:618-642): x authenticated, bases P_i = [b_i]G public (both parties hold b)
-                    ScalarBatch pub_b = fabric->allocate_scalars(b_m);
-                    PointBatch P = AuthenticatedPointBatch::alloc_points(fabric, n);
-                    if (n) check(fabric->ctx(), arkmpc_g1_generator_mul(fabric->ctx(), n, pub_b.buf.ptr(), P.buf.ptr()), "g1_generator_mul");
-                    Z = AuthenticatedPointBatch::msm_authenticated(x, P);
-                } else {
-                    Z = (scenario == "msm") ? AuthenticatedPointBatch::msm(x, Y) : AuthenticatedPointBatch::batch_mul(x, Y);
-                }
-                const size_t zn = Z.n;    // msm collapses the batch to one point
-                if (fabric->party_id() == PARTY0 && zn && bad_mac) {          // corrupt one MAC point: make it the share point
-                    std::vector<uint64_t> h(24 * zn); Z.buf.download(h.data(), zn * 192);
-                    std::memcpy(&h[24 * (zn / 2) + 12], &h[24 * (zn / 2)], 96);
-                    Z.buf.upload(h.data(), zn * 192);
-                }
-                std::vector<Scalar> bl(zn);
-                for (size_t i = 0; i < zn; ++i) bl[i] = eng.from_u64(1000 + 7 * i + fabric->party_id());
-                PointOpenResult o = Z.open_authenticated_batch(bl);
-                PartyOut out;
-                out.err = 0;
-                for (size_t i = 0; i < zn; ++i) if (!o.ok[i]) out.err += 1;          // number of failed MAC checks
-                out.opened.resize(zn);
-                if (zn) {
-                    DeviceBuf bytes(fabric->engine(), 4 * zn);
-                    check(fabric->ctx(), arkmpc_g1_to_bytes(fabric->ctx(), zn, o.value.buf.ptr(), reinterpret_cast<uint8_t*>(bytes.ptr())), "g1_to_bytes");
-                    bytes.download(out.opened.data(), zn * 32);
-                }
-                return out;
+            } else if (scenario == "short_peer") {
+                // a peer that sends one element fewer than the protocol step requires: must surface as a network error on the
+                // honest side before any kernel reads the short buffer (never an out-of-bounds read)
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                res = (fabric->party_id() == PARTY1 && n) ? a.slice(0, n - 1) : std::move(a);
+            } else if (scenario == "shared_bits") {
+                // fabric.rs:961-984 random_shared_bits over PreprocessingPhase::next_shared_bit_batch (offline_prep.rs:39-44): the
+                // dummy source's "bit" is the party id, so the authenticated open gives 0 + 1 = 1 for every element
+                res = fabric->random_shared_bits(n);
+            } else if (scenario == "share_point" || scenario == "point_mul" || scenario == "msm" || scenario == "msm_public_points" ||
+                       scenario == "point_sub_public") {
+                return field_id == ARKMPC_CURVE25519_FR ? point_scenario<AuthenticatedEdPointBatch>(fabric, scenario, n, a_m, b_m, bad_mac)
+                                                        : point_scenario<AuthenticatedPointBatch>(fabric, scenario, n, a_m, b_m, bad_mac);
             } else {
                 throw std::invalid_argument("unknown scenario " + scenario);
             }

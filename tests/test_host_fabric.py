@@ -222,3 +222,84 @@ def test_prefix_product_gadget(tmp_path):
     for v in a:
         run_ = run_ * v % p; want.append(run_)
     assert res[0] == (0, want) and res[1] == (0, want)
+
+
+# ---- round 2: the point-side protocols are curve-generic (BN254 G1 for field 0, Curve25519 for field 2, the reference's
+# ---- README curve), sub_public, shared bits, and a peer that sends a short batch ----------------------------------------
+def _curve(fid):
+    if fid == 0:
+        return pyref.RORD, (lambda k: pyref.g1_compress(pyref.g1_mul(pyref.G, k)))
+    return pyref.EL, (lambda k: pyref.ed_compress(pyref.ed_mul(pyref.ED_B, k)))
+
+
+def _run_points(tmp_path, scenario, fid, a, b, *flags):
+    n = len(a)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(ints_to_limbs(a).tobytes() + ints_to_limbs(b).tobytes())
+    rr = subprocess.run([EXE, scenario, str(fid), str(n), str(inp), str(outp), *flags], capture_output=True, text=True, timeout=900)
+    assert rr.returncode == 0, rr.stderr
+    raw = outp.read_bytes()
+    per = (len(raw) - 16) // 2
+    return [(struct.unpack_from("<Q", raw, k * (8 + per))[0], raw[k * (8 + per) + 8: (k + 1) * (8 + per)]) for k in range(2)]
+
+
+@pytest.mark.gpu
+def test_curve25519_point_beaver_mul_and_authenticated_open(tmp_path):
+    """AuthenticatedPointResult::batch_mul + open_authenticated_batch (authenticated_curve.rs:682-714, :190-283) over
+    Curve25519 -- the curve of BASELINE config 1 / README.md:24: open == (x*y) B for both parties, MAC checks pass, and a
+    corrupted MAC point is caught for exactly one element."""
+    fid, n = 2, 10
+    l, comp = _curve(fid)
+    x, y = [0, 1, l - 1] + rand_values(fid, n - 3, 141), [5, 7, 2] + rand_values(fid, n - 3, 142)
+    want = b"".join(comp((u * v) % l) for u, v in zip(x, y))
+    for flags, fails in (((), 0), (("--bad-mac",), 1)):
+        for nfail, got in _run_points(tmp_path, "point_mul", fid, x, y, *flags):
+            assert nfail == fails and got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fid", [0, 2])
+def test_point_sub_public_and_share_point(tmp_path, fid):
+    """PointShare::sub_public (curve/share.rs:63-65) through the mirror on both curves: share [a]G, subtract public [b]G,
+    authenticated open gives [(a-b)]G; and batch_share_point round trip on Curve25519 (BN254 is covered above)."""
+    n = 7
+    l, comp = _curve(fid)
+    a, b = [0, 1, l - 1] + rand_values(fid, n - 3, 151), [1, 1, 5] + rand_values(fid, n - 3, 152)
+    want = b"".join(comp((u - v) % l) for u, v in zip(a, b))
+    for nfail, got in _run_points(tmp_path, "point_sub_public", fid, a, b):
+        assert nfail == 0 and got == want
+    want = b"".join(comp(u) for u in a)
+    for nfail, got in _run_points(tmp_path, "share_point", fid, a, a):
+        assert nfail == 0 and got == want
+
+
+@pytest.mark.gpu
+def test_curve25519_authenticated_msm(tmp_path):
+    """AuthenticatedPointResult::msm and CurvePointResult::msm_authenticated on Curve25519 (scalar-muls + point sums)."""
+    fid, n = 2, 24
+    l, comp = _curve(fid)
+    x, y = rand_values(fid, n, 161), rand_values(fid, n, 162)
+    want = comp(sum(u * v for u, v in zip(x, y)) % l)
+    for scen in ("msm", "msm_public_points"):
+        for nfail, got in _run_points(tmp_path, scen, fid, x, y):
+            assert nfail == 0 and got == want
+
+
+@pytest.mark.gpu
+def test_random_shared_bits(tmp_path):
+    """fabric.rs:961-984 over PreprocessingPhase::next_shared_bit_batch (offline_prep.rs:39-44): the dummy source hands out
+    (party_id, party_id), so every bit opens to 0 + 1 = 1 under MAC key 1."""
+    res = run(tmp_path, "shared_bits", 0, [0] * 33, [0] * 33)
+    assert res[0] == (0, [1] * 33) and res[1] == (0, [1] * 33)
+
+
+@pytest.mark.gpu
+def test_short_peer_batch_is_a_network_error(tmp_path):
+    """A peer whose batch is one element short must be rejected before any kernel is launched on it (the kernels run with the
+    LOCAL n): both sides end with MpcNetworkError, no out-of-bounds read, no hang."""
+    n = 50
+    a = rand_values(0, n, 171)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(ints_to_limbs(a).tobytes() + ints_to_limbs(a).tobytes())
+    rr = subprocess.run([EXE, "short_peer", "0", str(n), str(inp), str(outp)], capture_output=True, text=True, timeout=300)
+    assert rr.returncode == 1 and "MpcNetworkError" in rr.stderr, rr.stderr
