@@ -28,6 +28,7 @@ struct arkmpc_ctx {
     // h_vflag is the host address, d_vflag its device alias.  Sticky between arkmpc_mac_verify_async calls.
     int* h_vflag = nullptr;
     int* d_vflag = nullptr;
+    int* d_vgate = nullptr;     // device word: admits one host store per failed verification
     // pinned double buffer for the commitment pipeline
     unsigned char* h_pin[2] = {nullptr, nullptr};
     size_t h_pin_cap = 0;

@@ -382,3 +382,34 @@ def test_one_context_shared_by_many_threads(pkg, oracle):
     for t in ts: t.start()
     for t in ts: t.join()
     assert not errs, errs[:3]
+
+
+@pytest.mark.parametrize("host_mode", [True, False])
+def test_mac_verify_async_is_sticky_until_collected(pkg, host_mode):
+    """arkmpc_mac_verify_async / _result: several ranges verified with ONE synchronisation; a failure anywhere is reported by
+    the next collection (and only that one), whichever range it was in and however many elements failed."""
+    fid, n = 0, 3000
+    e = pkg.Engine(fid, device=0, host_buffers=host_mode)
+    mine = mont_array(fid, rand_values(fid, n, 901))
+    peer = np.zeros_like(mine)
+    eh = e if host_mode else pkg.Engine(fid, device=0, host_buffers=True)
+    eh.scalar_neg(n, mine, peer)                                  # mine + peer == 0 everywhere
+    if host_mode:
+        A, B = mine, peer
+    else:
+        import torch
+        A, B = torch.from_numpy(mine.view(np.int64)).cuda(), torch.from_numpy(peer.view(np.int64)).cuda()
+    for _ in range(3):
+        e.mac_verify_async(n, A, B)
+    assert e.mac_verify_result() is True
+    bad = peer.copy(); bad[4 * 1234] ^= np.uint64(1)
+    Bb = bad if host_mode else torch.from_numpy(bad.view(np.int64)).cuda()
+    e.mac_verify_async(n, A, B); e.mac_verify_async(n, A, Bb); e.mac_verify_async(n, A, B)
+    assert e.mac_verify_result() is False                          # the middle range failed
+    assert e.mac_verify_result() is True                           # collected: the flag is clear again
+    all_bad = mont_array(fid, rand_values(fid, n, 902))
+    Ba = all_bad if host_mode else torch.from_numpy(all_bad.view(np.int64)).cuda()
+    assert e.mac_verify(n, A, Ba) is False                         # every element fails: one gate-admitted store
+    assert e.mac_verify(n, A, Bb) is False                         # the gate re-opened after the failure was collected
+    assert e.mac_verify(n, A, B) is True
+    e.close()

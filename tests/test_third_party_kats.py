@@ -1,0 +1,210 @@
+"""Third-party known-answer vectors (tests/golden/third_party_kats.json; sources in tests/golden/README.md): EIP-196
+ecAdd / ecMul cases, RFC 8032 public keys, NIST SHA3-256 examples, and a serde_json frame written out by hand -- against the
+CPU oracle (runs everywhere) and against the HIP engine through the C ABI (marked gpu).  None of the expected values was
+produced by code in this repo."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import pyref
+from helpers import mont_array, limbs_to_ints, EngineAdapter
+
+KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "third_party_kats.json")))
+H = lambda s: int(s, 16)
+R = pyref.RORD
+
+
+@pytest.fixture(scope="module", params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, oracle, pkg):
+    return oracle if request.param == "oracle" else EngineAdapter(pkg)
+
+
+def jac(points, zs):
+    return np.array(sum((pyref.g1_jacobian_mont(p, z) for p, z in zip(points, zs)), []), dtype=np.uint64)
+
+
+def affine_ints(backend, pts):
+    xy, inf = backend.g1_batch_to_affine(np.ascontiguousarray(pts))
+    v = [pyref.from_mont(3, m) for m in limbs_to_ints(xy)]
+    return [None if inf[i] else (v[2 * i], v[2 * i + 1]) for i in range(len(inf))]
+
+
+def test_eip196_ecadd(backend):
+    cases = KAT["eip196_ecadd"]["cases"]
+    A = [(H(c["a"][0]), H(c["a"][1])) for c in cases]
+    B = [(H(c["b"][0]), H(c["b"][1])) for c in cases]
+    want = [(H(c["out"][0]), H(c["out"][1])) for c in cases]
+    for zs in ([1] * len(cases), [3 + 5 * i for i in range(len(cases))]):           # any Jacobian representative of the inputs
+        got = affine_ints(backend, backend.g1_batch_add(jac(A, zs), jac(B, zs[::-1])))
+        assert got == want
+    # the compressed encoding of the published sums round-trips through from_bytes (x, sign of y)
+    if hasattr(backend, "g1_from_bytes"):
+        data = np.frombuffer(b"".join(pyref.g1_compress(p) for p in want), dtype=np.uint8).copy()
+        pts, ok = backend.g1_from_bytes(data)
+        assert ok.all() and affine_ints(backend, pts) == want
+
+
+def test_eip196_ecmul(backend):
+    cases = KAT["eip196_ecmul"]["cases"]
+    P = [(H(c["p"][0]), H(c["p"][1])) for c in cases]
+    ks = [H(c["k"]) % R for c in cases]                  # the precompile reduces the 256-bit scalar by the group order
+    want = [(H(c["out"][0]), H(c["out"][1])) for c in cases]
+    pts = jac(P, [1 + 2 * i for i in range(len(cases))])
+    got = affine_ints(backend, backend.g1_batch_scalar_mul(pts, mont_array(0, ks)))
+    assert got == want
+    # PointShare x Scalar (curve/share.rs:108-114) on the same vectors: (share, mac) = (P_i, P_{i+1}) times k_i
+    sh = np.ascontiguousarray(np.concatenate([pts.reshape(-1, 12), np.roll(pts.reshape(-1, 12), -1, axis=0)], axis=1).reshape(-1))
+    out = backend.pointshare_mul_public(sh, mont_array(0, ks))
+    got = affine_ints(backend, out)
+    assert got[0::2] == want and got[1::2] == [pyref.g1_mul(P[(i + 1) % len(P)], ks[i]) for i in range(len(P))]
+
+
+@pytest.mark.gpu
+def test_eip196_ecmul_through_msm_and_fixed_base(pkg):
+    """The same published products through the bucket-method MSM (sum of all six) and, for k*G, the fixed-base table path."""
+    hip = EngineAdapter(pkg)
+    cases = KAT["eip196_ecmul"]["cases"]
+    P = [(H(c["p"][0]), H(c["p"][1])) for c in cases]
+    ks = [H(c["k"]) % R for c in cases]
+    want = None
+    for c in cases:
+        want = pyref.g1_add(want, (H(c["out"][0]), H(c["out"][1])))     # sum of the PUBLISHED outputs
+    got = affine_ints(hip, hip.g1_msm(jac(P, [1] * len(P)), mont_array(0, ks)))
+    assert got == [want]
+    e = hip.eng(0)
+    o = np.zeros(12, dtype=np.uint64); e.g1_generator_mul(1, mont_array(0, [2]), o)
+    assert affine_ints(hip, o) == [(H(KAT["eip196_ecadd"]["cases"][2]["out"][0]), H(KAT["eip196_ecadd"]["cases"][2]["out"][1]))]     # 2G, EIP-196
+
+
+def _rfc8032_scalar(secret_hex):
+    h = hashlib.sha512(bytes.fromhex(secret_hex)).digest()
+    s = int.from_bytes(h[:32], "little")
+    s &= (1 << 254) - 8
+    s |= 1 << 254
+    return s % pyref.EL                                    # B has order l
+
+
+def _check_rfc8032(affine_xy, to_bytes):
+    for i, c in enumerate(KAT["rfc8032_public_keys"]["cases"]):
+        pk = bytes.fromhex(c["public"])
+        y_pub = int.from_bytes(pk, "little") & ((1 << 255) - 1)
+        x, y = affine_xy[i]
+        assert y == y_pub and (x & 1) == pk[31] >> 7, c["name"]            # RFC 8032: y and the parity of x
+        enc = to_bytes[32 * i:32 * i + 32]
+        assert int.from_bytes(enc, "little") & ((1 << 255) - 1) == y_pub   # arkworks encodes the same y ...
+        assert enc[31] >> 7 == (1 if x > pyref.EQ - x else 0)              # ... with its own sign convention for x
+
+
+def test_rfc8032_public_keys_oracle(oracle):
+    ks = [_rfc8032_scalar(c["secret"]) for c in KAT["rfc8032_public_keys"]["cases"]]
+    n = len(ks)
+    G = np.tile(oracle.ed_generator(), n)
+    pts = oracle.ed_batch_scalar_mul(G, mont_array(2, ks))
+    xy = [pyref.from_mont(4, m) for m in limbs_to_ints(oracle.ed_batch_to_affine(pts))]
+    _check_rfc8032([(xy[2 * i], xy[2 * i + 1]) for i in range(n)], oracle.ed_to_bytes(pts).tobytes())
+
+
+@pytest.mark.gpu
+def test_rfc8032_public_keys_hip(pkg):
+    e = pkg.Engine("curve25519_fr", device=0, host_buffers=True)
+    ks = [_rfc8032_scalar(c["secret"]) for c in KAT["rfc8032_public_keys"]["cases"]]
+    n = len(ks)
+    S = mont_array(2, ks)
+    G = np.array(pyref.ed_extended_mont(pyref.ED_B, 7) * n, dtype=np.uint64)
+    for via in ("fixed_base", "variable_base"):
+        pts = np.zeros(16 * n, dtype=np.uint64)
+        e.ed_generator_mul(n, S, pts) if via == "fixed_base" else e.ed_scalar_mul(n, G, S, pts)
+        xy = np.zeros(8 * n, dtype=np.uint64); e.ed_to_affine(n, pts, xy)
+        v = [pyref.from_mont(4, m) for m in limbs_to_ints(xy)]
+        b = np.zeros(32 * n, dtype=np.uint8); e.ed_to_bytes(n, pts, b)
+        _check_rfc8032([(v[2 * i], v[2 * i + 1]) for i in range(n)], b.tobytes())
+        back = np.zeros(16 * n, dtype=np.uint64); ok = np.zeros(n, dtype=np.uint8)
+        e.ed_from_bytes(n, b, back, ok)                                       # prime-order subgroup check included
+        xy2 = np.zeros(8 * n, dtype=np.uint64); e.ed_to_affine(n, back, xy2)
+        assert ok.all() and np.array_equal(xy, xy2)
+    e.close()
+
+
+def test_nist_sha3_256_examples_oracle(oracle):
+    for c in KAT["nist_sha3_256"]["cases"]:
+        if c["repeat"] > 1000000:
+            continue                                                           # the 2^30-byte message runs on the GPU box
+        msg = c["msg_ascii"].encode() * c["repeat"]
+        assert oracle.sha3_256(msg).hex() == c["digest"]
+
+
+def _commit_kat(case):
+    """A NIST message made of 32-byte big-endian words that are all below the BLS12-381 scalar modulus IS the byte stream of a
+    HashCommitment over BLS12-381 Fr (commitment.rs:36-40): values = all words but the last, blinder = the last word;
+    commitment = digest as a big-endian integer mod p.  Returns (distinct words as ints, total word count, expected scalar)."""
+    unit = c_bytes = case["msg_ascii"].encode()
+    while len(unit) % 32:
+        unit += c_bytes
+    words = [int.from_bytes(unit[i:i + 32], "big") for i in range(0, len(unit), 32)]
+    total = len(c_bytes) * case["repeat"]
+    assert total % 32 == 0 and all(w < pyref.P[1] for w in words)
+    return words, total // 32, int(case["digest"], 16) % pyref.P[1]
+
+
+def test_nist_one_million_a_through_the_commitment_path(backend):
+    words, count, want = _commit_kat(KAT["nist_sha3_256"]["cases"][4])
+    assert count == 31250 and len(words) == 1
+    vals = np.tile(mont_array(1, words), count - 1)
+    got = backend.commit_scalars(1, vals, mont_array(1, words))
+    assert pyref.from_mont(1, limbs_to_ints(got)[0]) == want
+
+
+@pytest.mark.gpu
+def test_nist_sha3_host_and_extremely_long_message_through_commit_pipeline(pkg):
+    """Engine host SHA3 on the short NIST examples, and the 2^30-byte NIST message as a 2^25-word HashCommitment: K6 on the GPU
+    in 128 chunks, pinned double-buffered D2H, pipelined host sponge -- against NIST's published digest."""
+    import importlib
+    import torch
+    eng_mod = importlib.import_module("ark-mpc_amd.engine")
+    for c in KAT["nist_sha3_256"]["cases"][:5]:
+        assert eng_mod.sha3_256(c["msg_ascii"].encode() * c["repeat"]).hex() == c["digest"]
+    words, count, want = _commit_kat(KAT["nist_sha3_256"]["cases"][5])
+    assert count == 1 << 25 and len(words) == 2
+    e = pkg.Engine(1, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    pair = torch.from_numpy(mont_array(1, words).view(np.int64)).cuda()
+    vals = pair.repeat(count // 2)                                               # 2^25 words: w0, w1, w0, w1, ...
+    got = e.commit_sha3(count - 1, vals, mont_array(1, [words[1]]))              # the last word is the blinder
+    assert pyref.from_mont(1, limbs_to_ints(got)[0]) == want
+    e.close()
+
+
+# ---- serde_json frame, written out by hand -------------------------------------------------------------------------------
+# network.rs:33-60: struct NetworkOutbound { result_id, payload }, enum NetworkPayload externally tagged => {"ScalarBatch":[...]};
+# scalar.rs:186-192: a Scalar is serialize_bytes(32 canonical little-endian bytes), which serde_json writes as an array of
+# numbers; serde_json::to_vec is the compact form (no whitespace); quic.rs:303-306 prefixes the u64 little-endian byte length.
+HAND_FRAME_TEXT = (b'{"result_id":1234,"payload":{"ScalarBatch":['
+                   b'[1,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0],'
+                   b'[1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32],'
+                   b'[0,0,0,240,147,245,225,67,145,112,185,121,72,232,51,40,93,88,129,129,182,69,80,184,41,160,49,225,114,78,100,48]]}}')
+HAND_FRAME_VALUES = [1, int.from_bytes(bytes(range(1, 33)), "little"), pyref.P[0] - 1]      # the last row is p - 1 for BN254 Fr
+
+
+def test_hand_written_frame_matches_model():
+    assert HAND_FRAME_VALUES[2].to_bytes(32, "little") == bytes([0, 0, 0, 240, 147, 245, 225, 67, 145, 112, 185, 121, 72, 232, 51, 40, 93, 88, 129, 129, 182,
+                                                                 69, 80, 184, 41, 160, 49, 225, 114, 78, 100, 48])
+    assert json.loads(HAND_FRAME_TEXT)["payload"]["ScalarBatch"][1] == list(range(1, 33))          # it is the JSON it claims to be
+    frame = struct.pack("<Q", len(HAND_FRAME_TEXT)) + HAND_FRAME_TEXT
+    assert pyref.wire_frame("ScalarBatch", 1234, pyref.wire_scalar_records(0, HAND_FRAME_VALUES)) == frame
+
+
+@pytest.mark.gpu
+def test_hand_written_frame_hip_encoder_and_decoder(pkg):
+    hip = EngineAdapter(pkg)
+    e = hip.eng(0)
+    frame = struct.pack("<Q", len(HAND_FRAME_TEXT)) + HAND_FRAME_TEXT
+    cap = e.wire_frame_bound(3)
+    buf = np.zeros(cap, dtype=np.uint8)
+    ln = e.wire_encode_scalar_batch(1234, 3, mont_array(0, HAND_FRAME_VALUES), buf, cap)
+    assert buf[:ln].tobytes() == frame
+    out = np.zeros(12, dtype=np.uint64)
+    cnt, rid = e.wire_decode_scalar_batch(np.frombuffer(frame, dtype=np.uint8).copy(), len(frame), 3, out)
+    assert (cnt, rid) == (3, 1234) and np.array_equal(out, mont_array(0, HAND_FRAME_VALUES))

@@ -60,7 +60,13 @@ def main():
     rec("share_add_public", lambda: e.share_add_public(n, 0, key, sh_a, sc_b, out8), 160)
     rec("open_and_mac_check (K2+K4)", lambda: e.open_and_mac_check(n, key, sh_a, sc_b, out4, out4b), 160)
     rec("mac_check_shares (K4)", lambda: e.mac_check_shares(n, key, sc_a, sh_a, out4), 128)
-    rec("mac_verify (K5)", lambda: e.mac_verify(n, sc_a, sc_b), 64, reps=10)
+    sc_neg = torch.empty_like(sc_a); e.scalar_neg(n, sc_a, sc_neg)       # a verifying pair: mine + peer == 0 everywhere
+    assert e.mac_verify(n, sc_a, sc_neg) is True
+    rec("mac_verify (K5), blocking", lambda: e.mac_verify(n, sc_a, sc_neg), 64, reps=10)
+    rec("mac_verify_async (K5)", lambda: e.mac_verify_async(n, sc_a, sc_neg), 64, reps=10)
+    assert e.mac_verify_result() is True
+    rec("mac_verify (K5), all elements failing", lambda: e.mac_verify(n, sc_a, sc_b), 64, reps=10)
+    assert e.mac_verify(n, sc_a, sc_b) is False and e.mac_verify(n, sc_a, sc_neg) is True
     t0 = time.perf_counter(); e.commit_sha3(n, sc_a, key); t_commit = time.perf_counter() - t0
     print("commit_sha3 (K6 + host SHA3)  %8.1f ms  %6.1f MB/s hashed" % (t_commit * 1e3, 32 * n / t_commit / 1e6), flush=True)
     rows.append({"op": "commit_sha3", "ms": t_commit * 1e3, "hash_MBps": 32 * n / t_commit / 1e6})
