@@ -561,6 +561,117 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* p
     else r = g1_scalar_mul_w4(p, s, table_ws, i, n);
     g1_store(out + 12 * i, r);
 }
+// ---------------------------------------------------------------------------------------------
+// K8, hand-scheduled form: prep -> window loop (one asm stream, ec_asm_kernels.inc / tools/gen_ec_asm.py) -> finish.
+//   prep    per scalar-mul: GLV split + signed 5-bit recoding -> 55 digit records (27 windows x 2 halves + the final step);
+//           the 16 multiples of P, rescaled to ONE common Z (Zc = product of their z's: x_k' = X_k c_k^2, y_k' = Y_k c_k^3 with
+//           c_k = Zc / z_k from prefix / suffix products, 111 multiplications) -- on the isomorphic curve y^2 = x^3 + 3 Zc^6 they
+//           are AFFINE, so the loop adds with madd-2007-bl (11 multiplications, not 16); entries 16 / 17 = the blinding point R0
+//           and -(2^130 R0) mapped to that curve ((x Zc^2, y Zc^3)).
+//   loop    acc = R0'; 26 x 5 doublings, 54 mixed additions of +-T[d] / +-phi(T[d]), then - 2^130 R0'.  No infinity and no
+//           branches on data; lanes that hit H = 0 (P + P, P - P) only raise a flag.
+//   finish  Z = Z' * Zc maps back to the curve; canonical store.  Flagged lanes (the identity as input or result, zero scalar,
+//           crafted collisions with R0) are recomputed by the compiled window path, so every input gets the exact group-law result.
+// Measured (config 4, 2^19 scalar-muls): see DESIGN.md section 3.
+// ---------------------------------------------------------------------------------------------
+#include "ec_asm_kernels.inc"
+#define TPB_LOOP 256
+struct G1AsmWs {
+    u64* jtab;      // [16][n] Jacobian multiples (scratch of prep; window table of the fallback in finish)
+    u64* tab;       // [18][n] affine entries on the isomorphic curve, 64 B each
+    u32* dig;       // [55][n] step records: bits 0-4 table index, bit 5 negate, bit 6 digit non-zero
+    u64* res;       // [n] raw result of the loop (X', Y', Z'), lazy range
+    u64* zc;        // [n] common Z
+    u32* exc0;      // [n] prep: input point is the identity
+    u32* exc1;      // [n] loop: exceptional addition
+};
+__device__ __forceinline__ Fe fq_const(const u32 (&c)[8]) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = c[i];
+    return r;
+}
+__global__ void __launch_bounds__(TPB_EC) k_g1_smul_prep(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride,
+                                                          u32 s_div, G1AsmWs ws) {
+    const u32 i = blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    const G1 p = points ? g1_load(points + (size_t)p_stride * (i / p_div)) : g1_generator();
+    const Fe s = fe_to_canonical<FR>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
+    // ---- digit records
+    GlvHalf h1, h2;
+    glv_decompose(s, h1, h2);
+    const GlvDigits D1 = glv_recode5(h1.mag), D2 = glv_recode5(h2.mag);
+    for (int w = GLV5_WINDOWS - 1; w >= 0; --w) {
+        const u32 e1 = glv_digit(D1, w), e2 = glv_digit(D2, w);
+        const u32 m1 = e1 & 31u, m2 = e2 & 31u;
+        const u32 r1 = (m1 ? m1 - 1 : 0u) | ((((e1 >> 5) & 1u) ^ (u32)h1.neg) << 5) | ((m1 != 0) << 6);
+        const u32 r2 = (m2 ? m2 - 1 : 0u) | ((((e2 >> 5) & 1u) ^ (u32)h2.neg) << 5) | ((m2 != 0) << 6);
+        const u32 step = 2u * (GLV5_WINDOWS - 1 - w);
+        ws.dig[(size_t)step * n + i] = r1;
+        ws.dig[(size_t)(step + 1) * n + i] = r2;
+    }
+    ws.dig[(size_t)(G1_ASM_STEPS - 1) * n + i] = 17u | (1u << 6);            // the final step: + (-(2^130 R0))'
+    ws.exc0[i] = FQ_ISZERO(p.z) ? 1u : 0u;
+    // ---- Jacobian multiples 1..16 (as the compiled path builds them), then one common Z
+    g1_build_table(p, ws.jtab, i, n, 16);
+    Fe run = fe_one<FQ>();
+    for (int k = 0; k < 16; ++k) {                                           // prefix products of the z's, parked in the x slots
+        run = FQ_MUL(run, fe_load(ws.jtab + ((size_t)k * n + i) * 12 + 8));
+        fe_store(ws.tab + ((size_t)k * n + i) * 8, FQ_CANON(run));
+    }
+    const Fe zc = FQ_CANON(run);
+    fe_store(ws.zc + 4 * (size_t)i, zc);
+    Fe suf = fe_one<FQ>();                                                   // z_{k+1} ... z_16
+    for (int k = 15; k >= 0; --k) {
+        const u64* jp = ws.jtab + ((size_t)k * n + i) * 12;
+        const Fe pre = k ? fe_load(ws.tab + ((size_t)(k - 1) * n + i) * 8) : fe_one<FQ>();
+        const Fe c = FQ_MUL(pre, suf);                                       // Zc / z_k
+        const Fe c2 = FQ_SQR(c);
+        u64* op = ws.tab + ((size_t)k * n + i) * 8;
+        fe_store(op, FQ_CANON(FQ_MUL(fe_load(jp), c2)));
+        fe_store(op + 4, FQ_CANON(FQ_MUL(fe_load(jp + 4), FQ_MUL(c2, c))));
+        suf = FQ_MUL(suf, fe_load(jp + 8));
+    }
+    const Fe z2 = FQ_SQR(zc), z3 = FQ_MUL(z2, zc);                           // R0 and -(2^130 R0) on the isomorphic curve
+    u64* o16 = ws.tab + ((size_t)16 * n + i) * 8;
+    u64* o17 = ws.tab + ((size_t)17 * n + i) * 8;
+    fe_store(o16, FQ_CANON(FQ_MUL(fq_const(G1_ASM_R0X), z2)));
+    fe_store(o16 + 4, FQ_CANON(FQ_MUL(fq_const(G1_ASM_R0Y), z3)));
+    fe_store(o17, FQ_CANON(FQ_MUL(fq_const(G1_ASM_NCX), z2)));
+    fe_store(o17 + 4, FQ_CANON(FQ_MUL(fq_const(G1_ASM_NCY), z3)));
+}
+__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_loop(u32 n, const u64* tab, const u32* dig, u64* res, u32* exc) {
+    const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
+    if (i >= n) return;
+    g1_smul_loop_asm(i, n, tab, dig, res, exc);
+}
+__global__ void __launch_bounds__(TPB_EC) k_g1_smul_finish(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride,
+                                                            u32 s_div, G1AsmWs ws, u64* out) {
+    const u32 i = blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    if (ws.exc0[i] | ws.exc1[i]) {                                           // rare: exact recomputation on the compiled path
+        const G1 p = points ? g1_load(points + (size_t)p_stride * (i / p_div)) : g1_generator();
+        const Fe s = fe_load(scalars + (size_t)s_stride * (i / s_div));
+        g1_store(out + 12 * (size_t)i, g1_scalar_mul_glv5(p, s, ws.jtab, i, n));
+        return;
+    }
+    G1 r = g1_load(ws.res + 12 * (size_t)i);
+    r.z = FQ_MUL(r.z, fe_load(ws.zc + 4 * (size_t)i));
+    g1_store(out + 12 * (size_t)i, r);
+}
+#define G1_ASM_WS_BYTES (16 * 96 + G1_ASM_TABLE * 64 + G1_ASM_STEPS * 4 + 96 + 32 + 8)
+static inline G1AsmWs g1_asm_carve(char* base, size_t n) {
+    G1AsmWs w;
+    w.jtab = (u64*)base; base += n * 16 * 96;
+    w.tab = (u64*)base; base += n * G1_ASM_TABLE * 64;
+    w.res = (u64*)base; base += n * 96;
+    w.zc = (u64*)base; base += n * 32;
+    w.dig = (u32*)base; base += n * G1_ASM_STEPS * 4;
+    w.exc0 = (u32*)base; base += n * 4;
+    w.exc1 = (u32*)base;
+    return w;
+}
+
 // PointShare::add_public (curve/share.rs:57-60): share += rhs iff PARTY0 ; mac += mac_key * rhs
 // (mac_key * rhs through the GLV window path: ~2.2 k instead of ~3.8 k Fq multiplications for plain double-and-add)
 // NEG: sub_public = add_public(-rhs) (curve/share.rs:63-65)
@@ -823,7 +934,12 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
     const size_t CH = (size_t)1 << 20;
     const size_t chunk = m < CH ? m : CH;
     static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
-    int iw = (points || !fixed_base) ? st.declare_scratch(chunk * 16 * 96) : -1;     // window tables of the variable-base path
+    // variable-base path: the hand-scheduled window loop (prep / loop / finish kernels) unless ARKMPC_EC_ASM=0
+    static const bool asm_loop = !(getenv("ARKMPC_EC_ASM") && getenv("ARKMPC_EC_ASM")[0] == '0');
+    const size_t ACH = (size_t)1 << 19;                       // scalar-muls per launch of the loop: 1.6 GB of tables / records
+    const size_t achunk = m < ACH ? m : ACH;
+    int iw = -1;
+    if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(achunk * G1_ASM_WS_BYTES + 256) : st.declare_scratch(chunk * 16 * 96);
     if (st.commit()) return st.rc;
     if (m && !points && fixed_base) {          // multiplication by the generator: tabulated multiples, no doublings
         const u64* table = nullptr;
@@ -831,6 +947,19 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
         if (rc) return rc;
         hipLaunchKernelGGL(k_g1_generator_mul_fixed, dim3(blocks_for(m, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, m, st.in<u64>(is), s_stride, s_div, table,
                            st.out<u64>(io));
+        return st.finish();
+    }
+    if (m && asm_loop) {
+        for (size_t lo = 0; lo < m; lo += achunk) {           // chunk boundaries are even: the point / scalar divisors (1 or 2) stay aligned
+            const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
+            const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
+            const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
+            const G1AsmWs ws = g1_asm_carve(st.scratch<char>(iw), cnt);
+            hipLaunchKernelGGL(k_g1_smul_prep, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+            hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res, ws.exc1);
+            hipLaunchKernelGGL(k_g1_smul_finish, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws,
+                               st.out<u64>(io) + 12 * lo);
+        }
         return st.finish();
     }
     if (m) {
