@@ -640,6 +640,31 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_smul_prep(u32 n, const u64* point
     fe_store(o17, FQ_CANON(FQ_MUL(fq_const(G1_ASM_NCX), z2)));
     fe_store(o17 + 4, FQ_CANON(FQ_MUL(fq_const(G1_ASM_NCY), z3)));
 }
+// prep, hand-scheduled form = two kernels: the digit records (integer work only: light, compiled) and the table (g1_smul_table_asm:
+// the loop's own double / mixed-add bodies on the curve where P is affine, then the common-Z rescaling, all in one asm stream)
+__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_digits(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride,
+                                                              u32 s_div, u32* dig, u32* exc0) {
+    const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
+    if (i >= n) return;
+    const Fe s = fe_to_canonical<FR>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
+    GlvHalf h1, h2;
+    glv_decompose(s, h1, h2);
+    const GlvDigits D1 = glv_recode5(h1.mag), D2 = glv_recode5(h2.mag);
+    for (int w = GLV5_WINDOWS - 1; w >= 0; --w) {
+        const u32 e1 = glv_digit(D1, w), e2 = glv_digit(D2, w);
+        const u32 m1 = e1 & 31u, m2 = e2 & 31u;
+        const u32 step = 2u * (GLV5_WINDOWS - 1 - w);
+        dig[(size_t)step * n + i] = (m1 ? m1 - 1 : 0u) | ((((e1 >> 5) & 1u) ^ (u32)h1.neg) << 5) | ((m1 != 0) << 6);
+        dig[(size_t)(step + 1) * n + i] = (m2 ? m2 - 1 : 0u) | ((((e2 >> 5) & 1u) ^ (u32)h2.neg) << 5) | ((m2 != 0) << 6);
+    }
+    dig[(size_t)(G1_ASM_STEPS - 1) * n + i] = 17u | (1u << 6);
+    exc0[i] = fe_is_zero(fe_load(points + (size_t)p_stride * (i / p_div) + 8)) ? 1u : 0u;     // the identity: recomputed (trivially) by finish
+}
+__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_table(u32 n, const u64* points, u32 p_stride, u32 p_div, u64* jtab, u64* tab, u64* zc) {
+    const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
+    if (i >= n) return;
+    g1_smul_table_asm(i, p_stride * 8u * (i / p_div), n, points, jtab, tab, zc);
+}
 __global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_loop(u32 n, const u64* tab, const u32* dig, u64* res, u32* exc) {
     const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
     if (i >= n) return;
@@ -955,7 +980,14 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
             const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
             const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
             const G1AsmWs ws = g1_asm_carve(st.scratch<char>(iw), cnt);
-            hipLaunchKernelGGL(k_g1_smul_prep, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+            static const bool asm_prep = !(getenv("ARKMPC_EC_ASM_PREP") && getenv("ARKMPC_EC_ASM_PREP")[0] == '0');
+            if (pp && asm_prep) {
+                hipLaunchKernelGGL(k_g1_smul_digits, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div,
+                                   ws.dig, ws.exc0);
+                hipLaunchKernelGGL(k_g1_smul_table, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, ws.jtab, ws.tab, ws.zc);
+            } else {
+                hipLaunchKernelGGL(k_g1_smul_prep, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+            }
             hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res, ws.exc1);
             hipLaunchKernelGGL(k_g1_smul_finish, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws,
                                st.out<u64>(io) + 12 * lo);

@@ -113,19 +113,22 @@ BETA = None             # filled in main() from glv_consts (cube root of unity i
 class RegMap:
     """Fixed VGPR allocation of the loop (v8 upwards; v0-v7 stay with the compiler for the kernel's own few values)."""
 
-    def __init__(self, first=8):
+    def __init__(self, first=8, table_kernel=False):
         rg = G.Regs(first)
         self.TWOQ = rg.vec(8)
         self.X1, self.Y1, self.Z1 = rg.vec(8, 4), rg.vec(8, 4), rg.vec(8, 4)      # accumulator (Jacobian on the isomorphic curve)
         self.X2, self.Y2 = rg.vec(8, 4), rg.vec(8, 4)                              # table entry (affine)
-        self.SX, self.SY, self.SZ = rg.vec(8), rg.vec(8), rg.vec(8)                # accumulator saved across the addition
-        self.T0, self.T1, self.T2 = rg.vec(8), rg.vec(8), rg.vec(8)
-        self.D2 = rg.vec(8)                                                        # 2a for the squaring rows
+        self.SX, self.SY, self.SZ = rg.vec(8, 4), rg.vec(8, 4), rg.vec(8, 4)       # accumulator saved across the addition
+        self.T0, self.T1, self.T2 = rg.vec(8, 4), rg.vec(8, 4), rg.vec(8, 4)
+        self.D2 = rg.vec(8, 4)                                                     # 2a for the squaring rows
         self.Tz = [rg.pair() for _ in range(9)]
         self.T = [t[0] for t in self.Tz]
         self.q = [rg.pair() for _ in range(8)]
         self.m = rg.one()
         self.rec, self.off, self.tid4, self.tid64, self.tid96, self.tmp, self.flag = (rg.one() for _ in range(7))
+        if table_kernel:
+            self.QV = rg.vec(8, 4)                                                 # q limbs in VGPRs (carry ops cannot take SGPR operands)
+            self.off2, self.tid32 = rg.one(), rg.one()
         self.first, self.end = first, rg.next
 
 
@@ -483,6 +486,162 @@ def emit_loop():
     return _with_globals(go)
 
 
+def canon(rm, a, out, tmp):
+    """[0, 2q) -> [0, q): out = a - q unless that borrows"""
+    c1, _ = _carries()
+    seq = [i_subco(tmp[0], a[0], rm.QV[0], c1)] + [i_subb(tmp[j], a[j], rm.QV[j], c1) for j in range(1, 8)]
+    seq += [i_cnd(out[j], tmp[j], a[j], c1) for j in range(8)]
+    return seq
+
+
+def emit_table():
+    """The window table of one scalar-mul as a hand-scheduled stream: the 16 multiples of P built with the loop's own double /
+    mixed-add bodies on the curve where P is affine (P = (X, Y, Z) is the affine point (X, Y) of y^2 = x^3 + 3 Z^6), rescaled to ONE
+    common Z (prefix / suffix products), plus the blinding point and its final correction mapped to that curve.
+    Operands: %[tid] %[poff] (VGPR: lane index, byte offset of the lane's point), %[n] (SGPR), %[pts] %[jtab] %[tab] %[zc] (SGPR pairs)."""
+    def go():
+        rm = RegMap(table_kernel=True)
+        L = []
+        A = L.append
+        lbl = lambda s_: "%s_%%=" % s_
+        S_E, S_N96, S_IDX = S_STEP, "s56", "s57"
+        inv = (-pow(Q, -1, 1 << 32)) & M32
+        one = R % Q
+
+        def sched(seq):
+            E = Emitter()
+            E.schedule(seq)
+            L.extend(E.lines)
+            return E
+
+        def ld(regs, off, base, byte=0):
+            A("global_load_dwordx4 %s, %s, %%[%s] offset:%d" % (quad(regs[:4]), off, base, byte))
+            A("global_load_dwordx4 %s, %s, %%[%s] offset:%d" % (quad(regs[4:]), off, base, byte + 16))
+
+        def st(regs, off, base, byte=0):
+            A("global_store_dwordx4 %s, %s, %%[%s] offset:%d" % (off, quad(regs[:4]), base, byte))
+            A("global_store_dwordx4 %s, %s, %%[%s] offset:%d" % (off, quad(regs[4:]), base, byte + 16))
+
+        def entry_off(dst, sidx, stride_s, tid_v):          # dst = sidx * n * stride + tid * stride
+            A("s_mul_i32 %s, %s, %s" % (S_TMP, sidx, stride_s))
+            A("v_add_u32_e32 %s, %s, %s" % (dst, S_TMP, tid_v))
+
+        def const_to(sregs, value):
+            for j in range(8):
+                A("s_mov_b32 %s, 0x%08x" % (sregs[j], (value >> (32 * j)) & M32))
+
+        def mov_const(regs, value):
+            for j in range(8):
+                A("v_mov_b32_e32 %s, 0x%08x" % (regs[j], (value >> (32 * j)) & M32))
+
+        A("s_nop 1")
+        A("s_mov_b32 %s, 0x%08x" % (S_INV, inv))
+        const_to(S_P, Q)
+        mov_const(rm.TWOQ, TWOQ)
+        mov_const(rm.QV, Q)
+        for t in rm.Tz:
+            A("v_mov_b32_e32 %s, 0" % t[1])
+        A("v_lshlrev_b32_e32 %s, 5, %%[tid]" % rm.tid32)
+        A("v_lshlrev_b32_e32 %s, 6, %%[tid]" % rm.tid64)
+        A("v_mul_u32_u24_e32 %s, 96, %%[tid]" % rm.tid96)
+        A("s_lshl_b32 %s, %%[n], 6" % S_N64)
+        A("s_mul_i32 %s, %%[n], 96" % S_N96)
+        # ---- T1 = P as the affine point (X, Y) of the curve scaled by its own Z; T2 = 2 T1
+        ld(rm.X1, "%[poff]", "pts", 0); ld(rm.Y1, "%[poff]", "pts", 32)
+        mov_const(rm.Z1, one)
+        A("s_waitcnt vmcnt(0)")
+        st(rm.X1, rm.tid96, "jtab", 0); st(rm.Y1, rm.tid96, "jtab", 32); st(rm.Z1, rm.tid96, "jtab", 64)
+        Ed = sched(seq_double(rm))
+        A("s_mov_b32 %s, 1" % S_E)
+        entry_off(rm.off, S_E, S_N96, rm.tid96)
+        st(rm.X1, rm.off, "jtab", 0); st(rm.Y1, rm.off, "jtab", 32); st(rm.Z1, rm.off, "jtab", 64)
+        ld(rm.SY, "%[poff]", "pts", 0); ld(rm.SZ, "%[poff]", "pts", 32); ld(rm.SX, "%[poff]", "pts", 64)      # P again: (x, y) for the additions, Z for the end
+        A("s_waitcnt vmcnt(0)")
+        # ---- T[e+1] = T[e] + P, e = 2 .. 15 (entry index = multiple - 1)
+        A("s_mov_b32 %s, 2" % S_E)
+        A(lbl("T_build") + ":")
+        for d, s_ in zip(rm.X2 + rm.Y2, rm.SY + rm.SZ):
+            A("v_mov_b32_e32 %s, %s" % (d, s_))
+        Ea = sched(seq_madd(rm))
+        entry_off(rm.off, S_E, S_N96, rm.tid96)
+        st(rm.X1, rm.off, "jtab", 0); st(rm.Y1, rm.off, "jtab", 32); st(rm.Z1, rm.off, "jtab", 64)
+        A("s_add_u32 %s, %s, 1" % (S_E, S_E))
+        A("s_cmp_lt_u32 %s, 16" % S_E)
+        A("s_cbranch_scc1 " + lbl("T_build"))
+        A("s_waitcnt vmcnt(0)")
+        # ---- prefix products of the z's: p_e = z_0 ... z_e (z_0 = 1), p_e parked in the x slot of tab[e]; "p_-1" = 1 in the x slot of tab[17]
+        mov_const(rm.X1, one)
+        A("s_mov_b32 %s, 17" % S_IDX)
+        entry_off(rm.off, S_IDX, S_N64, rm.tid64)
+        st(rm.X1, rm.off, "tab", 0)
+        st(rm.X1, rm.tid64, "tab", 0)                                  # p_0 = 1
+        A("s_mov_b32 %s, 1" % S_E)
+        A(lbl("T_prefix") + ":")
+        entry_off(rm.off, S_E, S_N96, rm.tid96)
+        ld(rm.T0, rm.off, "jtab", 64)
+        A("s_waitcnt vmcnt(0)")
+        sched(montmul(rm, rm.X1, rm.T0, rm.X1))
+        entry_off(rm.off, S_E, S_N64, rm.tid64)
+        st(rm.X1, rm.off, "tab", 0)
+        A("s_add_u32 %s, %s, 1" % (S_E, S_E))
+        A("s_cmp_lt_u32 %s, 16" % S_E)
+        A("s_cbranch_scc1 " + lbl("T_prefix"))
+        for d, s_ in zip(rm.Z1, rm.X1):                                # Zc = p_15
+            A("v_mov_b32_e32 %s, %s" % (d, s_))
+        A("s_waitcnt vmcnt(0)")
+        # ---- backward: c_e = p_{e-1} * (z_{e+1} ... z_15) = Zc / z_e ; x' = X c^2, y' = Y c^3 ; canonical stores
+        mov_const(rm.Y1, one)                                          # suffix product
+        A("s_mov_b32 %s, 15" % S_E)
+        A(lbl("T_back") + ":")
+        A("s_sub_u32 %s, %s, 1" % (S_IDX, S_E))
+        A("s_cmp_eq_u32 %s, 0" % S_E)
+        A("s_cselect_b32 %s, 17, %s" % (S_IDX, S_IDX))
+        entry_off(rm.off, S_IDX, S_N64, rm.tid64)
+        ld(rm.T0, rm.off, "tab", 0)
+        entry_off(rm.off2, S_E, S_N96, rm.tid96)
+        ld(rm.X2, rm.off2, "jtab", 0); ld(rm.Y2, rm.off2, "jtab", 32); ld(rm.SZ, rm.off2, "jtab", 64)
+        A("s_waitcnt vmcnt(0)")
+        seq = montmul(rm, rm.T0, rm.Y1, rm.T0)                         # c
+        seq += montsqr(rm, rm.T0, rm.T1)                               # c^2
+        seq += montmul(rm, rm.X2, rm.T1, rm.X2)                        # x'
+        seq += montmul(rm, rm.T1, rm.T0, rm.T1)                        # c^3
+        seq += montmul(rm, rm.Y2, rm.T1, rm.Y2)                        # y'
+        seq += montmul(rm, rm.Y1, rm.SZ, rm.Y1)                        # suffix *= z_e
+        seq += canon(rm, rm.X2, rm.X2, rm.T2) + canon(rm, rm.Y2, rm.Y2, rm.T0)
+        sched(seq)
+        entry_off(rm.off, S_E, S_N64, rm.tid64)
+        st(rm.X2, rm.off, "tab", 0); st(rm.Y2, rm.off, "tab", 32)
+        A("s_waitcnt vmcnt(0)")                                        # the next iteration reads the x slot of tab[e-1] (written in the prefix pass: safe) and reuses X2 / Y2
+        A("s_cmp_eq_u32 %s, 0" % S_E)
+        A("s_cbranch_scc1 " + lbl("T_back_done"))
+        A("s_sub_u32 %s, %s, 1" % (S_E, S_E))
+        A("s_branch " + lbl("T_back"))
+        A(lbl("T_back_done") + ":")
+        # ---- total Z of the table on the ORIGINAL curve: Zt = Zc * Z_P; blinding point and correction on the table's curve
+        seq = montmul(rm, rm.Z1, rm.SX, rm.Z1)                         # Zt
+        seq += montsqr(rm, rm.Z1, rm.T0)                               # Zt^2
+        seq += montmul(rm, rm.T0, rm.Z1, rm.T1)                        # Zt^3
+        sched(seq)
+        import hashlib
+        t_ = int.from_bytes(hashlib.sha3_256(b"arkmpc g1 window-loop blinding point R0").digest(), "big") % RORD
+        R0 = g1_mul(GEN, t_)
+        C = g1_mul(R0, (1 << (5 * (N_STEPS // 2 - 1))) % RORD)
+        for idx, (cx, cy) in ((16, R0), (17, (C[0], Q - C[1]))):
+            const_to(S_BETA, mont(cx))
+            sched(montmul(rm, rm.T0, S_BETA, rm.X2))
+            const_to(S_BETA, mont(cy))
+            sched(montmul(rm, rm.T1, S_BETA, rm.Y2) + canon(rm, rm.X2, rm.X2, rm.T2) + canon(rm, rm.Y2, rm.Y2, rm.X1))
+            A("s_mov_b32 %s, %d" % (S_IDX, idx))
+            entry_off(rm.off, S_IDX, S_N64, rm.tid64)
+            st(rm.X2, rm.off, "tab", 0); st(rm.Y2, rm.off, "tab", 32)
+            A("s_waitcnt vmcnt(0)")
+        sched(canon(rm, rm.Z1, rm.Z1, rm.T2))
+        st(rm.Z1, rm.tid32, "zc", 0)
+        A("s_waitcnt vmcnt(0)")
+        return L, rm, dict(double=len(Ed.order), madd=len(Ea.order), vgpr_end=rm.end)
+    return _with_globals(go)
+
+
 def emit_header(path):
     selftest(trials=24)
     lines, rm, st = emit_loop()
@@ -511,9 +670,20 @@ def emit_header(path):
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(rm.first, rm.end)]
     out.append("        : " + ", ".join(clob) + ");")
     out.append("}")
+    tlines, trm, tst = emit_table()
+    out.append("// the window table of one scalar-mul (16 multiples on the curve where P is affine, rescaled to a common Z; blinding point")
+    out.append("// and correction): %d asm lines, VGPRs v%d..v%d" % (len(tlines), trm.first, trm.end - 1))
+    out.append("__device__ __forceinline__ void g1_smul_table_asm(u32 tid, u32 poff, u32 n, const u64* pts, u64* jtab, u64* tab, u64* zc) {")
+    out.append("    asm volatile(")
+    out.append(G.c_string(tlines))
+    out.append("        :")
+    out.append('        : [tid] "v"(tid), [poff] "v"(poff), [n] "s"(n), [pts] "s"(pts), [jtab] "s"(jtab), [tab] "s"(tab), [zc] "s"(zc)')
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS + ["s56", "s57"]] + ['"v%d"' % i for i in range(trm.first, trm.end)]
+    out.append("        : " + ", ".join(clob) + ");")
+    out.append("}")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
-    return st, len(lines)
+    return st, len(lines) + len(tlines)
 
 
 def load_beta():
