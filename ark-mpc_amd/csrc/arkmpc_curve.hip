@@ -712,6 +712,28 @@ __global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public(size_t n, int 
     g1_store(out + 24 * i, sh);
     g1_store(out + 24 * i + 12, mac);
 }
+__global__ void __launch_bounds__(64) k_store_scalar(Fe v, u64* out) {          // a host scalar (kernel argument) -> device memory
+    if (blockIdx.x | threadIdx.x) return;
+    fe_store(out, v);
+}
+// the same two operations with mac_key * point already computed by the scalar-mul pipeline (kp): additions only
+template <bool NEG>
+__global__ void __launch_bounds__(TPB_EC) k_pointshare_add_public_kp(size_t n, int party, const u64* shares, const u64* pub, const u64* kp, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    G1 rhs = g1_load(pub + 12 * i), krhs = g1_load(kp + 12 * i);
+    if (NEG) { rhs = g1_neg(rhs); krhs = g1_neg(krhs); }              // key * (-rhs) = -(key * rhs)
+    G1 sh = g1_load(shares + 24 * i), mac = g1_load(shares + 24 * i + 12);
+    if (party == 0) sh = g1_add(sh, rhs);
+    mac = g1_add(mac, krhs);
+    g1_store(out + 24 * i, sh);
+    g1_store(out + 24 * i + 12, mac);
+}
+__global__ void __launch_bounds__(TPB_EC) k_point_mac_check_kp(size_t n, const u64* kv, const u64* shares, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    g1_store(out + 12 * i, g1_add(g1_load(kv + 12 * i), g1_neg(g1_load(shares + 24 * i + 12))));
+}
 // value * mac_key - share.mac()  (authenticated_curve.rs:215-220)
 __global__ void __launch_bounds__(TPB_EC) k_point_mac_check(size_t n, Fe key, const u64* opened, const u64* shares, u64* out, u64* table_ws) {
     size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
@@ -917,6 +939,36 @@ static void launch_zinv(arkmpc_ctx* ctx, size_t n, const u64* pts, u64* pre, u64
     hipLaunchKernelGGL(k_g1_zinv, dim3(blocks_for(threads, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, K, threads, pts, pre, zinv);
 }
 
+// The hand-scheduled scalar-mul pipeline over m outputs (out_j = points[j / p_div] * scalars[j / s_div]; strides in u64 units,
+// s_stride = 0 broadcasts one scalar), in chunks of G1_ASM_CHUNK; `ws` holds G1_ASM_WS_BYTES per scalar-mul of one chunk.
+static const size_t G1_ASM_CHUNK = (size_t)1 << 19;            // 1.6 GB of tables / records per launch
+static void g1_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride, u32 s_div, u64* out,
+                           char* wsbase) {
+    const size_t achunk = m < G1_ASM_CHUNK ? m : G1_ASM_CHUNK;
+    static const bool asm_prep = !(getenv("ARKMPC_EC_ASM_PREP") && getenv("ARKMPC_EC_ASM_PREP")[0] == '0');
+    for (size_t lo = 0; lo < m; lo += achunk) {                // chunk boundaries are even: the point / scalar divisors (1 or 2) stay aligned
+        const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
+        const u64* pp = points ? points + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
+        const u64* sp = scalars + (size_t)s_stride * (lo / s_div);
+        const G1AsmWs ws = g1_asm_carve(wsbase, cnt);
+        if (pp && asm_prep) {
+            hipLaunchKernelGGL(k_g1_smul_digits, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div,
+                               ws.dig, ws.exc0);
+            hipLaunchKernelGGL(k_g1_smul_table, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, ws.jtab, ws.tab, ws.zc);
+        } else {
+            hipLaunchKernelGGL(k_g1_smul_prep, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+        }
+        hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res, ws.exc1);
+        hipLaunchKernelGGL(k_g1_smul_finish, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws,
+                           out + 12 * lo);
+    }
+}
+static inline size_t g1_smul_ws_bytes(size_t m) { return (m < G1_ASM_CHUNK ? m : G1_ASM_CHUNK) * G1_ASM_WS_BYTES + 256; }
+static bool g1_asm_enabled() {
+    static const bool on = !(getenv("ARKMPC_EC_ASM") && getenv("ARKMPC_EC_ASM")[0] == '0');
+    return on;
+}
+
 extern "C" {
 
 static int g1_addsub(arkmpc_ctx* ctx, bool sub, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t mult) {
@@ -960,11 +1012,9 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
     const size_t chunk = m < CH ? m : CH;
     static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
     // variable-base path: the hand-scheduled window loop (prep / loop / finish kernels) unless ARKMPC_EC_ASM=0
-    static const bool asm_loop = !(getenv("ARKMPC_EC_ASM") && getenv("ARKMPC_EC_ASM")[0] == '0');
-    const size_t ACH = (size_t)1 << 19;                       // scalar-muls per launch of the loop: 1.6 GB of tables / records
-    const size_t achunk = m < ACH ? m : ACH;
+    const bool asm_loop = g1_asm_enabled();
     int iw = -1;
-    if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(achunk * G1_ASM_WS_BYTES + 256) : st.declare_scratch(chunk * 16 * 96);
+    if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(g1_smul_ws_bytes(m)) : st.declare_scratch(chunk * 16 * 96);
     if (st.commit()) return st.rc;
     if (m && !points && fixed_base) {          // multiplication by the generator: tabulated multiples, no doublings
         const u64* table = nullptr;
@@ -975,23 +1025,7 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
         return st.finish();
     }
     if (m && asm_loop) {
-        for (size_t lo = 0; lo < m; lo += achunk) {           // chunk boundaries are even: the point / scalar divisors (1 or 2) stay aligned
-            const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
-            const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
-            const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
-            const G1AsmWs ws = g1_asm_carve(st.scratch<char>(iw), cnt);
-            static const bool asm_prep = !(getenv("ARKMPC_EC_ASM_PREP") && getenv("ARKMPC_EC_ASM_PREP")[0] == '0');
-            if (pp && asm_prep) {
-                hipLaunchKernelGGL(k_g1_smul_digits, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div,
-                                   ws.dig, ws.exc0);
-                hipLaunchKernelGGL(k_g1_smul_table, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, ws.jtab, ws.tab, ws.zc);
-            } else {
-                hipLaunchKernelGGL(k_g1_smul_prep, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
-            }
-            hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res, ws.exc1);
-            hipLaunchKernelGGL(k_g1_smul_finish, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws,
-                               st.out<u64>(io) + 12 * lo);
-        }
+        g1_smul_launch(ctx, m, points ? st.in<u64>(ip) : (const u64*)nullptr, p_stride, p_div, st.in<u64>(is), s_stride, s_div, st.out<u64>(io), st.scratch<char>(iw));
         return st.finish();
     }
     if (m) {
@@ -1040,9 +1074,21 @@ static int pointshare_addsub_public(arkmpc_ctx* ctx, bool sub, size_t n, int par
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int is = st.declare_in(shares, n * 192), ip = st.declare_in(pub_points, n * 96), io = st.declare_out(out, n * 192);
+    const bool asm_loop = g1_asm_enabled();
     const size_t chunk = n < EC_CHUNK ? n : EC_CHUNK;
-    int iw = st.declare_scratch(chunk * 16 * 96);
+    int iw = asm_loop ? st.declare_scratch(g1_smul_ws_bytes(n)) : st.declare_scratch(chunk * 16 * 96);
+    int ik = asm_loop ? st.declare_scratch(n * 96 + 64) : -1;          // mac_key (32 B) + n points mac_key * rhs
     if (st.commit()) return st.rc;
+    if (n && asm_loop) {                                               // mac_key * rhs through the scalar-mul pipeline (one broadcast scalar)
+        u64* dkey = st.scratch<u64>(ik);
+        u64* kp = dkey + 8;
+        hipLaunchKernelGGL(k_store_scalar, dim3(1), dim3(64), 0, ctx->stream, fe_from_host(mac_key), dkey);
+        g1_smul_launch(ctx, n, st.in<u64>(ip), 12, 1, dkey, 0, 1, kp, st.scratch<char>(iw));
+        const dim3 g(blocks_for(n, TPB_EC)), t(TPB_EC);
+        if (sub) hipLaunchKernelGGL(k_pointshare_add_public_kp<true>, g, t, 0, ctx->stream, n, party_id, st.in<u64>(is), st.in<u64>(ip), kp, st.out<u64>(io));
+        else hipLaunchKernelGGL(k_pointshare_add_public_kp<false>, g, t, 0, ctx->stream, n, party_id, st.in<u64>(is), st.in<u64>(ip), kp, st.out<u64>(io));
+        return st.finish();
+    }
     for (size_t lo = 0; lo < n; lo += chunk) {
         const size_t cnt = (n - lo < chunk) ? (n - lo) : chunk;
         const dim3 g(blocks_for(cnt, TPB_EC)), t(TPB_EC);
@@ -1075,9 +1121,19 @@ int arkmpc_point_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int iv = st.declare_in(opened_points, n * 96), is = st.declare_in(shares, n * 192), io = st.declare_out(out_chk_points, n * 96);
+    const bool asm_loop = g1_asm_enabled();
     const size_t chunk = n < EC_CHUNK ? n : EC_CHUNK;
-    int iw = st.declare_scratch(chunk * 16 * 96);
+    int iw = asm_loop ? st.declare_scratch(g1_smul_ws_bytes(n)) : st.declare_scratch(chunk * 16 * 96);
+    int ik = asm_loop ? st.declare_scratch(n * 96 + 64) : -1;
     if (st.commit()) return st.rc;
+    if (n && asm_loop) {                                               // value * mac_key through the scalar-mul pipeline, then - mac
+        u64* dkey = st.scratch<u64>(ik);
+        u64* kv = dkey + 8;
+        hipLaunchKernelGGL(k_store_scalar, dim3(1), dim3(64), 0, ctx->stream, fe_from_host(mac_key), dkey);
+        g1_smul_launch(ctx, n, st.in<u64>(iv), 12, 1, dkey, 0, 1, kv, st.scratch<char>(iw));
+        hipLaunchKernelGGL(k_point_mac_check_kp, dim3(blocks_for(n, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, n, kv, st.in<u64>(is), st.out<u64>(io));
+        return st.finish();
+    }
     for (size_t lo = 0; lo < n; lo += chunk) {
         const size_t cnt = (n - lo < chunk) ? (n - lo) : chunk;
         hipLaunchKernelGGL(k_point_mac_check, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, fe_from_host(mac_key),
