@@ -23,11 +23,13 @@ for _ in range(reps):
     e.pointshare_mul_public(n, shares, sc, out)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / reps * 1e-3
-glv = os.environ.get('ARKMPC_NO_GLV', '0') != '1'
-# GLV: 33 windows x (4 dbl + 2 add + 1 beta mul) + table (7 dbl + 7 add); plain 4-bit windows: 256 dbl + 64 add + table
-w4 = os.environ.get('ARKMPC_GLV_W', '5') == '4'
-# Fq multiplications per scalar-mul: windows x (doublings + 2 additions + 1 beta mul) + table build
-FQ_MULS = ((33 * (4 * 7 + 2 * 16 + 1) + 7 * 7 + 7 * 16) if w4 else (27 * (5 * 7 + 2 * 16 + 1) + 8 * 7 + 7 * 16)) if glv else (256 * 7 + 64 * 16 + 7 * 7 + 7 * 16)
-print(json.dumps({"workload": "2^%d PointShare x Scalar = %d scalar-muls" % (int(np.log2(n)), 2 * n), "ms": t * 1e3,
-                  "scalar_muls_per_s": 2 * n / t, "fq_muls_per_s": 2 * n * FQ_MULS / t,
-                  "algorithm": ("glv + unsigned 4-bit windows" if w4 else "glv + signed 5-bit windows") if glv else "4-bit windows", "fq_muls_per_scalar_mul": FQ_MULS, "frac_of_mad_only_peak": 2 * n * FQ_MULS / t / (31.2e12 / 136)}))
+asm = os.environ.get('ARKMPC_EC_ASM', '1') != '0'
+st = json.load(open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec_asm_stats.json")))
+per = st["mult_instrs_loop"] + st["mult_instrs_table"]
+FQ_R01 = 27 * (5 * 7 + 2 * 16 + 1) + 8 * 7 + 7 * 16          # round 1's work definition: general multiplications per scalar-mul
+res = {"workload": "2^%d PointShare x Scalar = %d scalar-muls" % (int(np.log2(n)), 2 * n), "ms": t * 1e3, "scalar_muls_per_s": 2 * n / t,
+       "path": "hand-scheduled pipeline (digits, table, window loop, finish)" if asm else "compiled window loop (round 1)",
+       "r01_accounting_frac_of_mad_only_peak": 2 * n * FQ_R01 * 136 / t / 31.2e12}
+if asm:
+    res.update({"mult_instrs_per_scalar_mul": per, "frac_of_int_alu_peak": 2 * n * per / t / 31.2e12})
+print(json.dumps(res))

@@ -681,8 +681,28 @@ def emit_header(path):
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS + ["s56", "s57"]] + ['"v%d"' % i for i in range(trm.first, trm.end)]
     out.append("        : " + ", ".join(clob) + ");")
     out.append("}")
+    # multiplier instructions (v_mad_u64_u32 + v_mul_lo_u32) one scalar-mul executes in the two asm kernels
+    def mults(seq_fn, *a):
+        def go():
+            rm = RegMap(table_kernel=True)
+            return sum(1 for i in seq_fn(rm, *a) if i.op in ("mad", "mul_lo"))
+        return _with_globals(go)
+    m_dbl, m_madd = mults(seq_double), mults(seq_madd)
+    m_mul = mults(lambda rm: montmul(rm, rm.X1, rm.Y1, rm.Z1))
+    m_sqr = mults(lambda rm: montsqr(rm, rm.X1, rm.Z1))
+    n_dbl = 5 * (N_STEPS // 2 - 1)
+    loop_m = n_dbl * m_dbl + N_STEPS * m_madd + (N_STEPS // 2) * m_mul
+    table_m = m_dbl + 14 * m_madd + 15 * m_mul + 16 * (5 * m_mul + m_sqr) + (2 * m_mul + m_sqr) + 4 * m_mul
+    out.insert(4, "// multiplier instructions per scalar-mul: window loop %d (%d doublings x %d, %d mixed additions x %d, %d beta products x %d), table %d"
+               % (loop_m, n_dbl, m_dbl, N_STEPS, m_madd, N_STEPS // 2, m_mul, table_m))
+    out.insert(5, "#define G1_ASM_MULT_INSTRS_LOOP %d\n#define G1_ASM_MULT_INSTRS_TABLE %d" % (loop_m, table_m))
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
+    with open(os.path.join(os.path.dirname(path), "ec_asm_stats.json"), "w") as f:
+        import json
+        json.dump({"mult_instrs_loop": loop_m, "mult_instrs_table": table_m, "mult_instrs_per_montmul": m_mul, "mult_instrs_per_montsqr": m_sqr,
+                   "doublings": n_dbl, "mixed_additions": N_STEPS, "beta_products": N_STEPS // 2,
+                   "double_body_instrs": st["double"], "madd_body_instrs": st["madd"]}, f, indent=1)
     return st, len(lines) + len(tlines)
 
 
