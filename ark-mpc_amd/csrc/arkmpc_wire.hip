@@ -106,9 +106,17 @@ __global__ void __launch_bounds__(WIRE_TPB) k_wire_render(size_t n, const unsign
 // ---- decode ------------------------------------------------------------------------------------------------------
 // The body is frame[lo, hi).  `frame` is 16-byte aligned, so every thread examines one aligned 16-byte vector and masks
 // the bytes outside the body; positions are frame-relative.
+// 16 bytes at the aligned offset `off`, never touching a byte at or beyond `limit` (the caller's frame length): the frame is a
+// caller-owned buffer of exactly frame_len bytes, so the one vector that straddles its end is assembled byte by byte
+__device__ __forceinline__ uint4 load16_clamped(const unsigned char* frame, size_t off, size_t limit) {
+    if (off + 16 <= limit) return *reinterpret_cast<const uint4*>(frame + off);
+    u32 w[4] = {0, 0, 0, 0};
+    for (size_t k = 0; k < 16 && off + k < limit; ++k) w[k >> 2] |= (u32)frame[off + k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 __device__ __forceinline__ u32 bracket_mask(const unsigned char* frame, size_t v, size_t lo, size_t hi) {
     if (16 * v + 16 <= lo || 16 * v >= hi) return 0;
-    const uint4 q = *reinterpret_cast<const uint4*>(frame + 16 * v);
+    const uint4 q = load16_clamped(frame, 16 * v, hi + 3);          // the frame ends 3 bytes ("]}}") after the body
     const u32 w[4] = {q.x, q.y, q.z, q.w};
     u32 mask = 0;
 #pragma unroll
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(WIRE_TPB) k_wire_parse(size_t n, size_t lo, si
     const bool fits = span_hi - al <= (size_t)WIRE_TPB * WIRE_MAX_REC + 16;
     if (!fits) { if (threadIdx.x == 0) atomicOr(err, WIRE_E_SYNTAX); return; }
     const u32 nvec = (u32)((span_hi - al + 15) / 16);
-    for (u32 v = threadIdx.x; v < nvec; v += WIRE_TPB) smv[v] = *reinterpret_cast<const uint4*>(frame + al + 16 * (size_t)v);   // reads < 16 B past hi: the trailer
+    for (u32 v = threadIdx.x; v < nvec; v += WIRE_TPB) smv[v] = load16_clamped(frame, al + 16 * (size_t)v, hi + 3);   // up to the end of the frame, not beyond
     __syncthreads();
     if (i >= n) return;
     const size_t end = span_hi - al;                  // LDS-relative end of this workgroup's text
@@ -197,7 +205,7 @@ __global__ void __launch_bounds__(WIRE_TPB) k_wire_parse(size_t n, size_t lo, si
     }
     if (i + 1 < n) {
         // ',' then the next element's '[' immediately (its position is known from pos[])
-        if (pos[i + 1] - al != p + 1 || (p < end ? sm[p] != ',' : frame[al + p] != ',')) bad |= WIRE_E_SYNTAX;
+        if (pos[i + 1] - al != p + 1 || (p < end ? sm[p] != ',' : (al + p >= hi || frame[al + p] != ','))) bad |= WIRE_E_SYNTAX;
     } else if (al + p != hi) {
         bad |= WIRE_E_SYNTAX;
     }
@@ -224,6 +232,52 @@ __global__ void __launch_bounds__(WIRE_TPB) k_wire_to_canonical(size_t n, const 
     const size_t i = (size_t)blockIdx.x * WIRE_TPB + threadIdx.x;
     if (i >= n) return;
     fe_store(reinterpret_cast<u64*>(recs + 32 * i), fe_to_canonical<F>(fe_load(in + 4 * i)));
+}
+
+
+// ---- whitespace --------------------------------------------------------------------------------------------------
+// serde_json::from_slice accepts JSON whitespace (space, tab, LF, CR) between tokens; serde_json::to_vec -- what the reference's
+// transport sends (network/quic.rs:303) -- never emits any.  Frames without whitespace (every frame of a reference peer) take
+// the GPU path untouched; a frame that does contain whitespace is normalised ON THE HOST first: whitespace between tokens is
+// dropped, whitespace inside a string is kept (the literal comparison of the key then fails, as an unknown field would), and
+// whitespace between two digits -- two adjacent number tokens -- is a syntax error.
+__global__ void __launch_bounds__(WIRE_TPB) k_wire_has_ws(const unsigned char* frame, size_t frame_len, int* flag) {
+    const size_t v = (size_t)blockIdx.x * WIRE_TPB + threadIdx.x;
+    if (16 * v >= frame_len) return;
+    const uint4 q = load16_clamped(frame, 16 * v, frame_len);
+    const u32 w[4] = {q.x, q.y, q.z, q.w};
+    bool ws = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const u32 c = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+        if (16 * v + k >= 8 && 16 * v + k < frame_len && (c == 0x20u || c == 0x09u || c == 0x0au || c == 0x0du)) ws = true;
+    }
+    if (__any(ws) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+static bool host_has_ws(const unsigned char* p, size_t len) {
+    for (size_t i = 8; i < len; ++i) if (p[i] == 0x20 || p[i] == 0x09 || p[i] == 0x0a || p[i] == 0x0d) return true;
+    return false;
+}
+// in: a whole frame (8-byte prefix + JSON text).  out: the frame with inter-token whitespace removed and the prefix rewritten.
+static bool normalise_ws(const std::vector<unsigned char>& in, std::vector<unsigned char>& out) {
+    out.assign(in.begin(), in.begin() + 8);
+    bool in_string = false;
+    const size_t n = in.size();
+    for (size_t i = 8; i < n; ++i) {
+        const unsigned char c = in[i];
+        const bool ws = c == 0x20 || c == 0x09 || c == 0x0a || c == 0x0d;
+        if (c == '"') in_string = !in_string;
+        if (!ws || in_string) { out.push_back(c); continue; }
+        size_t j = i;
+        while (j < n && (in[j] == 0x20 || in[j] == 0x09 || in[j] == 0x0a || in[j] == 0x0d)) ++j;
+        const bool digit_before = out.size() > 8 && out.back() >= '0' && out.back() <= '9';
+        const bool digit_after = j < n && in[j] >= '0' && in[j] <= '9';
+        if (digit_before && digit_after) return false;          // "1 2": two number tokens without a separator
+        i = j - 1;
+    }
+    const u64 len = out.size() - 8;
+    for (int k = 0; k < 8; ++k) out[k] = (unsigned char)(len >> (8 * k));
+    return true;
 }
 
 const char* kind_name(int kind) { return kind == ARKMPC_WIRE_SCALAR_BATCH ? "ScalarBatch" : (kind == ARKMPC_WIRE_POINT_BATCH ? "PointBatch" : nullptr); }
@@ -306,7 +360,9 @@ int arkmpc_wire_encode_bytes32(arkmpc_ctx* ctx, int kind, uint64_t result_id, si
     return encode_impl(ctx, kind, result_id, n, n ? records : nullptr, nullptr, out_frame, out_cap, out_len);
 }
 
-// Parses the frame header on the host (it is < 100 bytes), the body on the device.
+static int decode_strict(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
+                         size_t* out_n, uint64_t* out_result_id, int* out_kind);
+// Entry: frames that contain JSON whitespace are normalised first (host, rare), everything else goes straight to the strict GPU parser.
 static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
                        size_t* out_n, uint64_t* out_result_id, int* out_kind) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
@@ -314,6 +370,40 @@ static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, 
     if (guard.rc) return guard.rc;
     if (!frame || !out_n) return ark_bad(ctx, "null frame / out_n");
     if (frame_len < 8 + 30) return ark_bad(ctx, "frame too short");
+    bool ws = false;
+    if (ctx->host_buffers) {
+        ws = host_has_ws(frame, frame_len);
+    } else {
+        if ((uintptr_t)frame & 15) return ark_bad(ctx, "device pointer not 16-byte aligned");
+        ARK_HIP(ctx, hipMemsetAsync(ctx->d_flag + 4, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_wire_has_ws, dim3(blocks_for((frame_len + 15) / 16, WIRE_TPB)), dim3(WIRE_TPB), 0, ctx->stream, frame, frame_len, ctx->d_flag + 4);
+        ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag + 12, ctx->d_flag + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ws = ctx->h_flag[12] != 0;
+    }
+    if (!ws) return decode_strict(ctx, frame, frame_len, max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
+    // the declared length covers the text as sent, whitespace included
+    std::vector<unsigned char> raw(frame_len), norm;
+    if (ctx->host_buffers) memcpy(raw.data(), frame, frame_len);
+    else { ARK_HIP(ctx, hipMemcpyAsync(raw.data(), frame, frame_len, hipMemcpyDeviceToHost, ctx->stream)); ARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+    u64 declared = 0;
+    for (int k = 0; k < 8; ++k) declared |= (u64)raw[k] << (8 * k);
+    if (declared != frame_len - 8) return ark_bad(ctx, "length prefix does not match the frame");
+    if (!normalise_ws(raw, norm)) return ark_bad(ctx, "malformed message: whitespace inside a number");
+    if (norm.size() < 8 + 30) return ark_bad(ctx, "frame too short");
+    if (ctx->host_buffers) return decode_strict(ctx, norm.data(), norm.size(), max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
+    void* dcopy = nullptr;
+    ARK_HIP(ctx, hipMalloc(&dcopy, norm.size() + 16));
+    int rc = ARKMPC_OK;
+    if (hipMemcpyAsync(dcopy, norm.data(), norm.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ARKMPC_ERR_HIP;
+    if (!rc) rc = decode_strict(ctx, (const uint8_t*)dcopy, norm.size(), max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dcopy);
+    return rc;
+}
+// Parses the frame header on the host (it is < 100 bytes), the body on the device.  Compact form only (no whitespace).
+static int decode_strict(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
+                         size_t* out_n, uint64_t* out_result_id, int* out_kind) {
     // header bytes to the host
     unsigned char head[112];
     const size_t hl = frame_len < sizeof(head) ? frame_len : sizeof(head);

@@ -320,9 +320,12 @@ int arkmpc_edshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64
  * with every Scalar as its 32 canonical little-endian bytes (scalar.rs:186-192) and every CurvePoint as its 32
  * compressed bytes (curve.rs:50-55, :103-108; variant "PointBatch"), each byte a decimal number.
  * Frame pointers follow the context's buffer mode like every other buffer.  Encoders and decoders block (the frame
- * length / element count is data dependent).  Decoders validate the whole grammar: any deviation from the compact form
- * above, a byte > 255 or a scalar >= the modulus returns ARKMPC_ERR_BAD_ARG (serde_json / deserialize_uncompressed
- * would return an error to the caller, scalar.rs:195-201). */
+ * length / element count is data dependent).  Decoders validate the whole grammar: a byte > 255, a scalar >= the modulus or
+ * any syntax error returns ARKMPC_ERR_BAD_ARG (serde_json / deserialize_uncompressed would return an error to the caller,
+ * scalar.rs:195-201).  JSON whitespace between tokens is accepted, as serde_json::from_slice accepts it (such a frame is
+ * normalised on the host first; serde_json::to_vec, what a reference peer sends, never emits whitespace).  Still stricter than
+ * serde's derive: the two fields must come in declaration order (result_id, payload) and no unknown fields are skipped.
+ * A device-mode frame buffer needs no padding: no byte at or beyond frame_len is read. */
 #define ARKMPC_WIRE_SCALAR_BATCH 0
 #define ARKMPC_WIRE_POINT_BATCH 1
 /* capacity (bytes) an encode call needs for n elements: 8 + 80 + 131 n + 3 */

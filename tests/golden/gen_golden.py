@@ -160,7 +160,7 @@ def wire_vectors():
     fr = lambda b: (struct.pack("<Q", len(b)) + b).hex()
     out["malformed_scalar_batches_field0"] = {
         "length prefix": (struct.pack("<Q", len(good) + 1) + good).hex(),
-        "whitespace": fr(good.replace(b"[[", b"[ [", 1)),
+        "whitespace inside a number": fr(good.replace(b",255,", b",2 55,", 1)),
         "byte > 255": fr(good.replace(b"[[5,", b"[[256,", 1)),
         "leading zero": fr(good.replace(b",255,", b",0255,", 1)),
         "31 numbers": fr(good.replace(b",255,", b",", 1)),
@@ -168,6 +168,9 @@ def wire_vectors():
         "other variant": fr(good.replace(b"ScalarBatch", b"ScalarShare", 1)),
         "scalar >= modulus": pyref.wire_frame("ScalarBatch", 3, [int(pyref.P[0]).to_bytes(32, "little")]).hex(),
     }
+    # serde_json::from_slice skips whitespace between tokens: accepted, same values
+    out["whitespace_scalar_batches_field0"] = {"values": [hx(v) for v in (5, 255 * 256, 77)], "result_id": 3,
+                                               "frames": [fr(good.replace(b"[[", b"[ [", 1)), fr(good.replace(b",", b" ,\n\t").replace(b":", b" : ") + b"\r\n")]}
     return out
 
 

@@ -28,3 +28,22 @@ def test_every_entry_point_is_declared_with_matching_arity():
         assert len(got) == len(params), name
     for const in ("ARKMPC_OK: i32 = 0", "ARKMPC_ERR_NO_DEVICE: i32 = -4", "ARKMPC_BN254_FR: i32 = 0", "ARKMPC_WIRE_POINT_BATCH: i32 = 1"):
         assert const in rs
+
+
+def test_rust_declarations_type_check_against_the_header(tmp_path):
+    """integration/arkmpc_sys_check.c restates every Rust declaration with the ABI-equivalent C types and initialises a typed
+    function pointer from the header's prototype: gcc rejects any mismatch in arity, integer width or pointer mutability."""
+    src = os.path.join(ROOT, "integration", "arkmpc_sys_check.c")
+    cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror", "-Werror=incompatible-pointer-types", "-I", os.path.join(ROOT, "include"), src]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # and it does catch drift: flip one mutability and one width
+    txt = open(src).read()
+    for good, bad in (("(arkmpc_ctx*, uintptr_t, const uint64_t*, const uint64_t*, uint64_t*) = arkmpc_scalar_add;",
+                       "(arkmpc_ctx*, uintptr_t, uint64_t*, const uint64_t*, uint64_t*) = arkmpc_scalar_add;"),
+                      ("static int32_t (*const chk_arkmpc_sync)(arkmpc_ctx*) = arkmpc_sync;", "static int64_t (*const chk_arkmpc_sync)(arkmpc_ctx*) = arkmpc_sync;")):
+        assert good in txt, good
+        mutated = tmp_path / "mutated.c"
+        mutated.write_text(txt.replace(good, bad))
+        r = subprocess.run(cmd[:-1] + [str(mutated)], capture_output=True, text=True)
+        assert r.returncode != 0

@@ -77,7 +77,7 @@ def _mutations(good):
     body = good[8:]
     def fr(b): return struct.pack("<Q", len(b)) + b
     yield "length prefix", struct.pack("<Q", len(body) + 1) + body
-    yield "whitespace", fr(body.replace(b"[[", b"[ [", 1))
+    yield "whitespace inside a number", fr(body.replace(b",255,", b",2 55,", 1))
     yield "byte > 255", fr(body.replace(b"[[", b"[[256,", 1).replace(b",0]", b"]", 1))
     yield "leading zero", fr(body.replace(b",255,", b",0255,", 1))
     yield "31 numbers", fr(body.replace(b",255,", b",", 1))
@@ -149,8 +149,33 @@ _ELEM = r"\[" + _NUM + r"(?:," + _NUM + r"){31}\]"
 _STRICT = re.compile(r'\{"result_id":(0|[1-9][0-9]{0,19}),"payload":\{"ScalarBatch":\[(?:' + _ELEM + r"(?:," + _ELEM + r")*)?\]\}\}\Z")
 
 
+def normalise_ws(body):
+    """JSON whitespace between tokens dropped (serde_json::from_slice skips it); None when a run of whitespace separates two digits
+    (two number tokens without a comma).  Whitespace inside a string stays: the key then no longer matches."""
+    out = bytearray()
+    in_string = False
+    i, n = 0, len(body)
+    while i < n:
+        c = body[i]
+        if c == 0x22:
+            in_string = not in_string
+        if c not in b" \t\n\r" or in_string:
+            out.append(c); i += 1
+            continue
+        j = i
+        while j < n and body[j] in b" \t\n\r":
+            j += 1
+        if out and chr(out[-1]).isdigit() and j < n and chr(body[j]).isdigit():
+            return None
+        i = j
+    return bytes(out)
+
+
 def strict_accepts(fid, body):
-    """The compact serde_json text of a ScalarBatch message and nothing else; scalars canonical; id fits a u64."""
+    """The serde_json text of a ScalarBatch message (whitespace between tokens allowed) and nothing else; scalars canonical; id fits a u64."""
+    body = normalise_ws(body)
+    if body is None:
+        return False
     m = _STRICT.match(body.decode("latin-1"))
     if not m or int(m.group(1)) >= 1 << 64:
         return False
@@ -192,7 +217,72 @@ def test_decoder_agrees_with_strict_grammar_on_mutated_frames(hip, pkg):
         assert got == want, (trial, bytes(body)[:120])
         if got:
             accepted += 1
-            msg = json.loads(bytes(body))
+            msg = json.loads(normalise_ws(bytes(body)))
             assert rid == msg["result_id"] and cnt == len(msg["payload"]["ScalarBatch"])
             assert np.array_equal(out[:4 * cnt], mont_array(fid, [int.from_bytes(bytes(e), "little") for e in msg["payload"]["ScalarBatch"]]))
     assert 40 < accepted < 360          # the mutation mix exercises both outcomes
+
+
+# ---- round 2: JSON whitespace is accepted as serde_json::from_slice accepts it; exact-size device frames are never over-read ----
+def _with_ws(frame: bytes, mode: str) -> bytes:
+    """re-space the JSON text of a frame (token-level whitespace only) and fix the length prefix"""
+    text = frame[8:]
+    if mode == "pretty":
+        import json as _json
+        text = _json.dumps(_json.loads(text), indent=2).encode()
+    elif mode == "mixed":
+        text = text.replace(b",", b" ,\t").replace(b":", b" : ").replace(b"[", b"[\r\n ").replace(b"]", b" ]") + b"\n"
+    return struct.pack("<Q", len(text)) + text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["pretty", "mixed"])
+@pytest.mark.parametrize("device_frame", [False, True])
+def test_decode_accepts_json_whitespace(hip, pkg, mode, device_frame):
+    fid, n = 0, 70
+    vals = [0, 1, pyref.P[fid] - 1, 255, 256] + rand_values(fid, n - 5, 811)
+    frame = _with_ws(pyref.wire_frame("ScalarBatch", 99, pyref.wire_scalar_records(fid, vals)), mode)
+    out = np.zeros(4 * n, dtype=np.uint64)
+    if device_frame:
+        import torch
+        e = pkg.Engine(fid, device=0, stream=torch.cuda.current_stream().cuda_stream)
+        dfr = torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda()
+        dout = torch.zeros(4 * n, dtype=torch.int64, device="cuda")
+        cnt, rid = e.wire_decode_scalar_batch(dfr, len(frame), n, dout)
+        out = dout.cpu().numpy().view(np.uint64)
+        e.close()
+    else:
+        cnt, rid = hip.eng(fid).wire_decode_scalar_batch(np.frombuffer(frame, dtype=np.uint8).copy(), len(frame), n, out)
+    assert (cnt, rid) == (n, 99) and np.array_equal(out, mont_array(fid, vals))
+
+
+@pytest.mark.gpu
+def test_whitespace_inside_tokens_is_rejected(hip, pkg):
+    """`1 2` is two numbers without a separator and `"result_ id"` is another key: both invalid for serde_json as well"""
+    e = hip.eng(0)
+    good = pyref.wire_frame("ScalarBatch", 5, pyref.wire_scalar_records(0, [300, 7]))
+    for old, new in ((b"[44,1,", b"[4 4,1,"), (b'"result_id"', b'"result_ id"'), (b'"ScalarBatch"', b'"Scalar Batch"')):
+        assert old in good
+        text = good[8:].replace(old, new, 1)
+        frame = struct.pack("<Q", len(text)) + text
+        with pytest.raises(pkg.ArkMpcError):
+            e.wire_decode_scalar_batch(np.frombuffer(frame, dtype=np.uint8).copy(), len(frame), 2, np.zeros(8, dtype=np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 256, 257])
+def test_device_frame_of_exact_size_is_not_over_read(pkg, n):
+    """Device mode with a frame allocation of EXACTLY frame_len bytes placed at the end of a larger buffer whose tail is filled with
+    '[' bytes: a decoder that looked past frame_len would count phantom elements (and, on an exact allocation, read out of bounds)."""
+    import torch
+    fid = 0
+    e = pkg.Engine(fid, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    vals = rand_values(fid, n, 900 + n)
+    frame = pyref.wire_frame("ScalarBatch", n, pyref.wire_scalar_records(fid, vals))
+    buf = torch.full((len(frame) + 64,), ord("["), dtype=torch.uint8, device="cuda")
+    buf[:len(frame)] = torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda()
+    out = torch.zeros(4 * (n + 8), dtype=torch.int64, device="cuda")
+    cnt, rid = e.wire_decode_scalar_batch(buf, len(frame), n + 8, out)
+    assert (cnt, rid) == (n, n)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64)[:4 * n], mont_array(fid, vals))
+    e.close()
