@@ -1,8 +1,8 @@
 """ark-mpc_amd -- MI355X-native engine for ark-mpc's batched authenticated-share hot path.
 
 The product is the C-ABI shared library built from csrc/ (include/arkmpc.h).  This package is
-plumbing: a ctypes binding of that ABI (engine.py) and the host-side mirror of the reference's
-fabric API (fabric.py, over the C++ host library).  There is no CPU fallback: importing the
+plumbing: a ctypes binding of that ABI (engine.py) and the multi-GPU sharding helpers (sharding.py).  The host-side
+mirror of the reference's fabric API is C++ (host/fabric.hpp, drivers host/mock_mpc_main.cpp and host/bench_main.cpp).  There is no CPU fallback: importing the
 binding without the built library, or creating a context without a GPU, raises.
 
 The directory name carries a hyphen, so import it with

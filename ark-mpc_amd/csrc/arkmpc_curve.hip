@@ -11,7 +11,7 @@
 // These kernels are integer-ALU bound (a scalar-mul is ~6k Fq multiplications against 128 B of
 // traffic), one thread per point.
 #include "arkmpc_internal.hpp"
-#include "fp_asm.cuh"
+#include "fp_asm.hpp"
 #include <cstdlib>
 
 // Fq multiplication used by the point formulas: the hand-scheduled block fe_mul_fast (298 instructions, 2 wait states;

@@ -9,7 +9,7 @@
 // a square, d is not), so addition needs no exceptional cases at all; doubling is dbl-2008-hwcd.
 // Scalars are Curve25519 Fr elements: the context's field must be ARKMPC_CURVE25519_FR.
 #include "arkmpc_internal.hpp"
-#include "fp_asm.cuh"
+#include "fp_asm.hpp"
 #include <cstdlib>
 
 #define TPB_ED 128

@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include "../../include/arkmpc.h"
-#include "fp.cuh"
+#include "fp.hpp"
 
 struct arkmpc_ctx {
     int field_id = 0;

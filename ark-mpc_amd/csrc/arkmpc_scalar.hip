@@ -23,7 +23,7 @@ struct ColOut {
     u32 stride;
 };
 
-#include "fp_asm.cuh"
+#include "fp_asm.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // elementwise Scalar kernels

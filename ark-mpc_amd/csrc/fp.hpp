@@ -1,4 +1,4 @@
-// fp.cuh -- 256-bit prime-field arithmetic for gfx950 (CDNA4), device side.
+// fp.hpp -- 256-bit prime-field arithmetic for gfx950 (CDNA4), device side.
 //
 // Replaces, for the hot path, what ark-mpc delegates to arkworks `Fp256<MontBackend<_,4>>`
 // (reference call sites: online-phase/src/algebra/scalar/scalar.rs:215,235,255,264).

@@ -1,7 +1,7 @@
 // Probe for the design choice "one thread per element" vs the limb-sliced form BASELINE.json's north_star sketches
 // (SoA limbs, one limb per lane, carries moved between lanes with wavefront shuffles): the same batch of 256-bit
 // Montgomery multiplications over BN254 Fr computed both ways, results compared, both timed.
-//   thread-per-element : fp.cuh's fe_mul (8 x u32 limbs in 8 VGPRs of one lane, carries in VCC)
+//   thread-per-element : fp.hpp's fe_mul (8 x u32 limbs in 8 VGPRs of one lane, carries in VCC)
 //   limb-sliced        : 8 adjacent lanes own one element (lane l holds limb l); CIOS rows with the multiplier limb
 //                        broadcast by ds_bpermute / DPP shuffles, per-lane 64-bit lazy accumulators, the limb shift and
 //                        the carries moved one lane up with shuffles, final carry / borrow resolution across the 8 lanes.
@@ -10,7 +10,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "fp.cuh"
+#include "fp.hpp"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 constexpr int F = 0;   // BN254 Fr

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "fp_asm.cuh"
+#include "fp_asm.hpp"
 constexpr int FQ = F_BN254_FQ;
 template <int CH>
 __global__ void __launch_bounds__(256) k_chain(const u64* in, u64* out, int reps) {
