@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_smul_prep(u32 n, const u64* point
         ws.dig[(size_t)(step + 1) * n + i] = r2;
     }
     ws.dig[(size_t)(G1_ASM_STEPS - 1) * n + i] = 17u | (1u << 6);            // the final step: + (-(2^130 R0))'
-    ws.exc0[i] = FQ_ISZERO(p.z) ? 1u : 0u;
+    ws.exc0[i] = (FQ_ISZERO(p.z) || fe_is_zero(s)) ? 1u : 0u;                 // trivial lanes: identity in or zero scalar -> identity out
     // ---- Jacobian multiples 1..16 (as the compiled path builds them), then one common Z
     g1_build_table(p, ws.jtab, i, n, 16);
     Fe run = fe_one<FQ>();
@@ -658,7 +658,9 @@ __global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_digits(u32 n, const u64* p
         dig[(size_t)(step + 1) * n + i] = (m2 ? m2 - 1 : 0u) | ((((e2 >> 5) & 1u) ^ (u32)h2.neg) << 5) | ((m2 != 0) << 6);
     }
     dig[(size_t)(G1_ASM_STEPS - 1) * n + i] = 17u | (1u << 6);
-    exc0[i] = fe_is_zero(fe_load(points + (size_t)p_stride * (i / p_div) + 8)) ? 1u : 0u;     // the identity: recomputed (trivially) by finish
+    // trivial lanes: the identity as input or a zero scalar give the identity -- finish stores it without recomputing anything
+    // (the loop would end on acc == 2^130 R0 and flag the lane; zero shares / MACs are common: a party's MAC-key share can be 0)
+    exc0[i] = (fe_is_zero(fe_load(points + (size_t)p_stride * (i / p_div) + 8)) || fe_is_zero(s)) ? 1u : 0u;
 }
 __global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_table(u32 n, const u64* points, u32 p_stride, u32 p_div, u64* jtab, u64* tab, u64* zc) {
     const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
@@ -674,7 +676,8 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_smul_finish(u32 n, const u64* poi
                                                             u32 s_div, G1AsmWs ws, u64* out) {
     const u32 i = blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
-    if (ws.exc0[i] | ws.exc1[i]) {                                           // rare: exact recomputation on the compiled path
+    if (ws.exc0[i]) { g1_store(out + 12 * (size_t)i, g1_identity()); return; }        // identity in / zero scalar: nothing to compute
+    if (ws.exc1[i]) {                                                        // rare: exact recomputation on the compiled path
         const G1 p = points ? g1_load(points + (size_t)p_stride * (i / p_div)) : g1_generator();
         const Fe s = fe_load(scalars + (size_t)s_stride * (i / s_div));
         g1_store(out + 12 * (size_t)i, g1_scalar_mul_glv5(p, s, ws.jtab, i, n));
