@@ -310,6 +310,17 @@ __global__ void __launch_bounds__(TPB) k_mac_check(size_t n, Fe key, const u64* 
     Fe mac = fe_load(shares + 8 * i + 4);
     fe_store(out_chk + 4 * i, fe_sub<F>(fe_mul<F>(key, v), mac));
 }
+// K2+K4 on share / MAC columns (engine-native split layout, or any strided view): the `.share()` payload a party sends IS its share
+// column, so there is no extraction pass and the MAC half is read exactly once: 160 B per share here + 0 for the projection, against
+// 96 + 160 on AoS records (which must be fetched whole twice)
+template <int F>
+__global__ void __launch_bounds__(TPB) k_mac_check_v(size_t n, Fe key, Col sh, Col mac, const u64* peer, u64* out_opened, u64* out_chk) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const Fe v = fe_add<F>(fe_load(sh.p + (size_t)sh.stride * i), fe_load_nt(peer + 4 * i));
+    fe_store(out_opened + 4 * i, v);
+    fe_store(out_chk + 4 * i, fe_sub<F>(fe_mul<F>(key, v), fe_load_nt(mac.p + (size_t)mac.stride * i)));
+}
 // K5: all(mine_i + peer_i == 0)  (:218-219).  A wave with a failing element stores 1 into the context's verify flag, a word of
 // host-coherent mapped memory: the success path writes nothing, so a call costs no memset and no read-back copy (round 1's
 // memset + kernel + blocking D2H ran at 1.8 TB/s end to end).  Both inputs are streamed exactly once: non-temporal loads.
@@ -1011,6 +1022,22 @@ int arkmpc_open_and_mac_check(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[
                                                st.in<u64>(ip), st.out<u64>(iv), st.out<u64>(io)));
     }
     return st.finish();
+}
+int arkmpc_open_and_mac_check_v(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* share_col, const uint64_t* mac_col, size_t stride,
+                                const uint64_t* peer, uint64_t* out_opened, uint64_t* out_chk) {
+    ENTER(ctx);
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    if (!stride_ok(stride)) return ark_bad(ctx, "bad stride");
+    if (ctx->host_buffers) return ark_bad(ctx, "share-view entry points take device pointers only");
+    if (n && (!share_col || !mac_col || !peer || !out_opened || !out_chk)) return ark_bad(ctx, "null pointer");
+    if (((uintptr_t)share_col | (uintptr_t)mac_col | (uintptr_t)peer | (uintptr_t)out_opened | (uintptr_t)out_chk) & 15) return ark_bad(ctx, "device pointer not 16-byte aligned");
+    if (n) {
+        const Fe k = fe_from_host(mac_key);
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, launch_k(ctx, k_mac_check_v<F>, g, t, n, k, Col{share_col, (u32)stride}, Col{mac_col, (u32)stride}, peer, out_opened, out_chk));
+        ARK_HIP(ctx, hipGetLastError());
+    }
+    return ARKMPC_OK;
 }
 // enqueue K5 on the context's stream; failures accumulate in the sticky verify flag
 static int mac_verify_enqueue(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, bool keep_staged) {

@@ -203,6 +203,8 @@ class Engine:
     def mac_check_shares(self, n, key, opened, shares, out): self.call("mac_check_shares", ("size", n), ("key", key), opened, shares, out)
     def open_and_mac_check(self, n, key, shares, peer, out_opened, out_chk):
         self.call("open_and_mac_check", ("size", n), ("key", key), shares, peer, out_opened, out_chk)
+    def open_and_mac_check_v(self, n, key, share_col, mac_col, stride, peer, out_opened, out_chk):
+        self.call("open_and_mac_check_v", ("size", n), ("key", key), share_col, mac_col, ("size", stride), peer, out_opened, out_chk)
     def mac_verify(self, n, mine, peer):
         ok = ctypes.c_int(-1)
         self.call("mac_verify", ("size", n), mine, peer, ("ref", ctypes.byref(ok)))

@@ -429,6 +429,24 @@ def leg_config5(pkg, dev):
 
     ms_dev = timed_events(device_part, reps=5, warm=1)
     ok = oks == [True, True] and bool(torch.equal(opened[0], v)) and bool(torch.equal(opened[1], v))
+    # the same step on the engine-native split columns (shares resident as gate outputs are kept): the payload a party sends IS its share
+    # column -- no extraction pass -- and the MAC half is read once: 160 + 64 = 224 B per party-share of traffic instead of 96 + 160 + 64 = 320
+    cols = []
+    for p in (0, 1):
+        sc, mc = torch.empty(4 * n, dtype=torch.int64, device="cuda"), torch.empty(4 * n, dtype=torch.int64, device="cuda")
+        eng.share_split(n, sh[p], sc, mc)
+        cols.append((sc, mc))
+    oks2 = []
+
+    def device_part_split():
+        for p in (0, 1):
+            eng.open_and_mac_check_v(n, keys[p], cols[p][0], cols[p][1], 4, cols[1 - p][0], opened[p], chk[p])
+        oks2[:] = [eng.mac_verify(n, chk[p], chk[1 - p]) for p in (0, 1)]
+
+    opened[0].zero_(); opened[1].zero_()
+    ms_dev_split = timed_events(device_part_split, reps=5, warm=1)
+    ok = ok and oks2 == [True, True] and bool(torch.equal(opened[0], v)) and bool(torch.equal(opened[1], v))
+    del cols
     t0 = time.perf_counter()
     c_one = eng.commit_sha3(n, chk[0], blind[0])
     ms_one = (time.perf_counter() - t0) * 1e3
@@ -459,6 +477,12 @@ def leg_config5(pkg, dev):
             "device_ms_both_parties": ms_dev, "device_what": "share extract + K2+K4 (open + MAC-check shares) + K5 (verify) for both parties",
             "device_shares_per_s": n / (ms_dev * 1e-3), "device_alg_GBps": 2 * n * 256 / (ms_dev * 1e-3) / 1e9,
             "device_frac_of_hbm_peak": 2 * n * 256 / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBPS, "alg_bytes_per_party_share": 256,
+            "layout": "arkworks AoS ScalarShare records (what the boundary receives)",
+            "split_columns": {"device_ms_both_parties": ms_dev_split, "device_shares_per_s": n / (ms_dev_split * 1e-3),
+                              "device_alg_GBps": 2 * n * 256 / (ms_dev_split * 1e-3) / 1e9,
+                              "device_frac_of_hbm_peak": 2 * n * 256 / (ms_dev_split * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "note": "shares resident in the engine-native split columns: no extraction pass (the share column is the payload), K2+K4 column form + K5; "
+                                      "224 B of traffic per party-share against the 256 B algorithmic figure, which counts the payload write"},
             "host_sha3_ms_one_commitment": ms_one, "host_sha3_MBps": 32 * n / (ms_one * 1e-3) / 1e6,
             "host_sha3_note": "one sequential SHA3-256 over 512 MiB (commitment.rs:36-40 hashes one message); 4 such per batch (2 per party)",
             "end_to_end_ms": ms_e2e, "end_to_end_what": "device part + commit phase + verify phase; the two parties hash concurrently (one host thread each), "

@@ -199,6 +199,10 @@ int arkmpc_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4]
 /* K2+K4 fused: opened_i = shares_i.share + peer_i ; chk_i = mac_key*opened_i - shares_i.mac */
 int arkmpc_open_and_mac_check(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* shares,
                               const uint64_t* peer_share_values, uint64_t* out_opened, uint64_t* out_chk);
+/* K2+K4 on share / MAC columns (stride in u64 units: 4 = split columns, 8 = AoS view with mac = share + 4).  With split columns the
+ * `.share()` payload a party sends IS its share column: no arkmpc_share_extract pass, and the MAC half is read once. */
+int arkmpc_open_and_mac_check_v(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4], const uint64_t* share_col, const uint64_t* mac_col,
+                                size_t stride, const uint64_t* peer_share_values, uint64_t* out_opened, uint64_t* out_chk);
 /* K5  all(mine_i + peer_i == 0) (:218-219).  Blocking; *out_ok = 1 or 0. */
 int arkmpc_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, int* out_ok);
 /* Non-blocking form for callers that verify several ranges (sharded batches, the two parties of a mock run): _async enqueues K5

@@ -413,3 +413,31 @@ def test_mac_verify_async_is_sticky_until_collected(pkg, host_mode):
     assert e.mac_verify(n, A, Bb) is False                         # the gate re-opened after the failure was collected
     assert e.mac_verify(n, A, B) is True
     e.close()
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_open_and_mac_check_on_columns_equals_aos(pkg, oracle, fid):
+    """arkmpc_open_and_mac_check_v on split columns and on an AoS view (stride 8) == the AoS entry point == the oracle."""
+    import torch
+    n = 1237
+    e = pkg.Engine(fid, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    p = pyref.P[fid]
+    key = rand_values(fid, 1, 77)[0]
+    vals = mixed_values(fid, n, 78)
+    sh0, sh1 = authenticated_shares(fid, vals, key, 79)
+    kk = mont_array(fid, [rand_values(fid, 1, 80)[0]])
+    peer = np.ascontiguousarray(sh1.reshape(n, 8)[:, :4]).reshape(-1)
+    want_o = oracle.open_combine(fid, np.ascontiguousarray(sh0.reshape(n, 8)[:, :4]).reshape(-1), peer)
+    want_c = oracle.mac_check_shares(fid, kk, want_o, sh0)
+    dev = lambda a: torch.from_numpy(a.view(np.int64).copy()).cuda()
+    d_aos, d_peer = dev(sh0), dev(peer)
+    sc, mc = torch.empty(4 * n, dtype=torch.int64, device="cuda"), torch.empty(4 * n, dtype=torch.int64, device="cuda")
+    e.share_split(n, d_aos, sc, mc)
+    for share_col, mac_col, stride in ((sc, mc, 4), (d_aos, d_aos[4:], 8)):
+        o = torch.zeros(4 * n, dtype=torch.int64, device="cuda"); c = torch.zeros_like(o)
+        e.open_and_mac_check_v(n, kk, share_col, mac_col, stride, d_peer, o, c)
+        torch.cuda.synchronize()
+        assert np.array_equal(o.cpu().numpy().view(np.uint64), want_o) and np.array_equal(c.cpu().numpy().view(np.uint64), want_c)
+    with pytest.raises(pkg.ArkMpcError):
+        e.open_and_mac_check_v(n, kk, sc, mc, 3, d_peer, o, c)
+    e.close()
