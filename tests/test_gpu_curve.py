@@ -217,3 +217,90 @@ def test_empty_batches_on_point_entry_points(hip, oracle):
     cap = eng.wire_frame_bound(0); buf = np.zeros(cap, dtype=np.uint8)
     ln = eng.wire_encode_bytes32(1, 5, 0, zb, buf, cap)
     assert buf[8:ln].tobytes() == b'{"result_id":5,"payload":{"PointBatch":[]}}'
+
+
+# ---- round 2: the hand-scheduled scalar-mul pipeline's exceptional lanes ----------------------------------------------------
+def _asm_blinding_points():
+    """R0 and C = 2^130 R0 of the window loop, read back from the GENERATED header (Montgomery limbs) -- the test does not trust the generator's Python"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "ark-mpc_amd", "csrc", "ec_asm_kernels.inc")).read()
+    def const(name):
+        m = re.search(r"G1_ASM_%s\[8\] = \{([^}]*)\}" % name, txt)
+        limbs = [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+        return pyref.from_mont(3, sum(l << (32 * i) for i, l in enumerate(limbs)))
+    R0 = (const("R0X"), const("R0Y"))
+    negC = (const("NCX"), const("NCY"))
+    return R0, (negC[0], pyref.P[3] - negC[1])
+
+
+def _exceptional_cases():
+    R0, C = _asm_blinding_points()
+    r = pyref.RORD
+    neg = lambda P: (P[0], pyref.P[3] - P[1])
+    R32 = pyref.g1_mul(R0, 32)
+    k25 = (1 << 125) + 12345                                           # below the GLV lattice's reach: decomposes as (k, 0); window 25 digit = +1
+    flagged = [(R32, k25), (neg(R32), k25), (R32, (1 << 125)), (neg(pyref.g1_add(C, C)), 1), (neg(C), 1), (C, r - 1)]
+    plain = [(R0, 1), (R0, 0), (None, 7), (R32, r - k25)]            # the last one decomposes differently (k1 is not -k25): an ordinary lane
+    return flagged, plain
+
+
+def test_crafted_inputs_really_hit_the_exceptional_path(tmp_path):
+    """With the recomputation switched off (ARKMPC_EC_ASM_NOFIX=1, a test hook) every crafted lane must come out WRONG and every
+    ordinary lane right: the inputs do reach H = 0 inside the loop, and nothing else does."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import importlib, sys, os
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, pyref, oracle_api
+        from helpers import mont_array, limbs_to_ints, EngineAdapter
+        import test_gpu_curve as T
+        hip = EngineAdapter(importlib.import_module("ark-mpc_amd")); ora = oracle_api.load()
+        flagged, plain = T._exceptional_cases()
+        cases = flagged + plain
+        P = T.jac([c[0] for c in cases], [5 + i for i in range(len(cases))]); S = mont_array(0, [c[1] for c in cases])
+        got = hip.g1_batch_scalar_mul(P, S); want = ora.g1_batch_scalar_mul(P, S)
+        gx, gi = hip.g1_batch_to_affine(got); wx, wi = ora.g1_batch_to_affine(want)
+        print([int(np.array_equal(gx[8 * i:8 * i + 8], wx[8 * i:8 * i + 8]) and gi[i] == wi[i]) for i in range(len(cases))])
+    """ % (root, root))
+    env = dict(os.environ, ARKMPC_EC_ASM_NOFIX="1")
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    flagged, plain = _exceptional_cases()
+    assert eval(r.stdout.strip().splitlines()[-1]) == [0] * len(flagged) + [1] * len(plain)
+
+
+def test_asm_loop_exceptional_lanes_are_recomputed_exactly(hip, oracle):
+    """Inputs crafted against the loop's PUBLIC blinding point so that a mixed addition inside it meets H = 0 (the accumulator equals, or is
+    the negative of, the table entry it adds): P = +-32 R0 with a scalar whose window-25 digit is 1 hits step 2 (accumulator = 2^5 R0);
+    P = -2 C with scalar 1 makes the final correction a doubling; P = -C with scalar 1 makes it P - P.  The loop only flags such lanes and the
+    finish kernel recomputes them on the compiled path, so the results must still be the exact group-law answers -- mixed into a batch of
+    ordinary lanes.  Also: the identity as input, scalars 0, 1, r - 1."""
+    R0, C = _asm_blinding_points()
+    r = pyref.RORD
+    assert pyref.g1_mul(R0, pow(2, 130, r)) == C                       # the header's constants are consistent with each other
+    flagged, plain = _exceptional_cases()
+    cases = flagged + plain
+    rnd_pts, _ = random_points(54, 4242, with_identity=False)
+    rnd_k = rand_values(0, 54, 4243)
+    pts = [c[0] for c in cases] + rnd_pts
+    ks = [c[1] for c in cases] + rnd_k
+    order = np.random.RandomState(7).permutation(len(pts))             # exceptional lanes scattered inside the wave
+    pts, ks = [pts[i] for i in order], [ks[i] for i in order]
+    P = jac(pts, [3 + 7 * i for i in range(len(pts))])
+    S = mont_array(0, ks)
+    got = hip.g1_batch_scalar_mul(P, S)
+    assert affine_equal(hip, oracle, got, oracle.g1_batch_scalar_mul(P, S))
+    xy, inf = hip.g1_batch_to_affine(got)
+    for i, (pt, k) in enumerate(zip(pts, ks)):
+        want = None if pt is None else pyref.g1_mul(pt, k % r)
+        if want is None:
+            assert inf[i] == 1
+        else:
+            x, y = limbs_to_ints(xy[8 * i:8 * i + 8])
+            assert (pyref.from_mont(3, x), pyref.from_mont(3, y)) == want, (i, k)
