@@ -330,3 +330,41 @@ def test_config4_all_2p18_pointshare_scalar_muls_vs_oracle(pkg, oracle):
     bad = np.nonzero((gxy != wxy.reshape(-1, 8)).any(axis=1))[0]
     assert bad.size == 0, "%d of %d scalar-muls differ from the oracle, first at %d" % (bad.size, gxy.shape[0], bad[0])
     e.close()
+
+
+def test_config3_all_2p24_gates_in_8_ranges_bitexact_vs_oracle(pkg, oracle):
+    """BASELINE config 3's shape on one GPU: 2^24 Beaver muls over BN254 Fr evaluated as the 8 contiguous ranges of 2^21 gates that 8 GPUs
+    would each own (ark-mpc_amd/sharding.py: shard_range), every range through its own K1 / K2+K3 launches; the concatenation of the ranges'
+    d||e and result records == the oracle's UNSHARDED 9-pass batch_mul on all 2^24 gates, both parties, every word."""
+    import importlib
+    sharding = importlib.import_module("ark-mpc_amd.sharding")
+    fid, n, world = 0, 1 << 24, 8
+    e = _eng(pkg, fid)
+    vals, sh, key, keys = _setup(e, n, 0xA11CE003)
+    del vals
+    d = [torch.empty(4 * n, dtype=torch.int64, device="cuda") for _ in (0, 1)]       # gathered in rank order: all d, then all e
+    ee = [torch.empty(4 * n, dtype=torch.int64, device="cuda") for _ in (0, 1)]
+    res = [torch.empty(8 * n, dtype=torch.int64, device="cuda") for _ in (0, 1)]
+    for rank in range(world):
+        lo, hi = sharding.shard_range(n, world, rank)
+        m = hi - lo
+        sl = lambda t: t[8 * lo: 8 * hi]
+        de = [torch.empty(8 * m, dtype=torch.int64, device="cuda") for _ in (0, 1)]
+        for p in (0, 1):
+            e.beaver_mask(m, sl(sh["x"][p]), sl(sh["y"][p]), sl(sh["a"][p]), sl(sh["b"][p]), de[p])
+        for p in (0, 1):
+            e.beaver_finish_fused(m, p, keys[p], de[p], de[1 - p], sl(sh["a"][p]), sl(sh["b"][p]), sl(sh["c"][p]), res[p][8 * lo: 8 * hi])
+            d[p][4 * lo: 4 * hi] = de[p][:4 * m]
+            ee[p][4 * lo: 4 * hi] = de[p][4 * m:]
+    torch.cuda.synchronize()
+    H = [{k: _host(sh[k][p]) for k in "xyabc"} for p in (0, 1)]
+    del sh
+    ode = [oracle.beaver_mask_mt(fid, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"]) for p in (0, 1)]
+    for p in (0, 1):
+        assert np.array_equal(_host(d[p]), ode[p][:4 * n]) and np.array_equal(_host(ee[p]), ode[p][4 * n:]), "party %d d||e" % p
+        _, want = oracle.batch_mul_9pass_mt(fid, p, keys[p], H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], ode[1 - p])
+        got = _host(res[p])
+        bad = np.nonzero((got.reshape(n, 8) != want.reshape(n, 8)).any(axis=1))[0]
+        assert bad.size == 0, "party %d: %d of %d gates differ from the oracle, first at %d" % (p, bad.size, n, bad[0])
+        del want, got
+    e.close()
