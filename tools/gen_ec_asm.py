@@ -376,6 +376,21 @@ def quad(regs4):
     return G.quad(regs4)
 
 
+def align_head(A):
+    """Placement of a loop head: EC_ALIGN = "<log2 alignment>:<extra 4-byte nops>" (measured per setting on MI355X; hand-scheduled streams are
+    sensitive to their fetch phase -- MI355X_MICROARCH.md, code-placement note)."""
+    spec = os.environ.get("EC_ALIGN", LOOP_ALIGN)
+    if not spec:
+        return
+    p2, nops = (int(x) for x in spec.split(":"))
+    A(".p2align %d" % p2)
+    for _ in range(nops):
+        A("s_nop 0")
+
+
+LOOP_ALIGN = "6:2"        # measured on MI355X (config 4): "6:0" 8.15 ms, none 7.73, "6:1" 7.65, "6:2" 7.61, "6:3" 7.65 (+-1 % run to run)
+
+
 def emit_loop():
     """Returns (lines, regmap, stats): the whole step loop as assembler text.
     Operands: %[tid] (VGPR, lane's index in the launch), %[n] (SGPR, lanes in the launch), %[tab] %[dig] %[res] %[exc] (SGPR pairs)."""
@@ -409,6 +424,7 @@ def emit_loop():
         for j in range(8):
             A("v_mov_b32_e32 %s, 0x%08x" % (rm.Z1[j], (one >> (32 * j)) & M32))
         A("s_mov_b32 %s, 0" % S_STEP)
+        align_head(A)
         A(lbl("L_step") + ":")
         # digit record of this step: bits 0-4 table index, bit 5 negate, bit 6 digit non-zero
         A("s_mul_i32 %s, %s, %s" % (S_TMP, S_STEP, S_N4))
@@ -423,6 +439,7 @@ def emit_loop():
         A("s_cmp_eq_u32 %s, %d" % (S_STEP, N_STEPS - 1))
         A("s_cbranch_scc1 " + lbl("L_nodbl"))
         A("s_mov_b32 %s, 5" % S_DBL)
+        align_head(A)
         A(lbl("L_dbl") + ":")
         Ed = Emitter()
         Ed.schedule(seq_double(rm))
