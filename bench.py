@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=20, help="CPU baseline sample size (gates)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed: run the pipeline for this long BEFORE the W warm-up steps, on every rank, so that the "
+                    "timed region does not sit inside the power controller's transient after idle (tools/ramp_probe.py: a cold MI355X runs the first steps fast, "
+                    "then creeps from 0.195 to 0.21-0.25 ms per step for several ms before settling at 0.198).  0 disables.  Reported in config.settle_ms.")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs reported next to the headline at N=1 (AoS layout, config 4, config 5)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the timed ordered all-gather of opened-value buffers (config 5 shape, 64 MiB per rank)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for launch-path tests)")
@@ -249,6 +252,13 @@ def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier):
     chunks = args.chunks if args.chunks > 0 else max(1, n >> 20)
     call_sets = [prepare_step(eng, n, ps, layout, chunks, args.k3_order) for ps, _ in sets]
     per_step = 4 * chunks                           # launches per step: per gate range K1(P0), K1(P1), K3(P0), K3(P1)
+    if getattr(args, "settle_ms", 0) > 0:           # disclosed in config.settle_ms: steady-state clocks before the warm-up steps
+        t_s = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            for _ in range(8):
+                step(call_sets[k % len(call_sets)]); k += 1
+            torch.cuda.synchronize()
     for w in range(warmup):
         step(call_sets[w % len(call_sets)])
     barrier()
@@ -579,6 +589,8 @@ def main():
             "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": wl, "gates_per_gpu": n, "gates_per_step_all_gpus": n * world, "field": "bn254_fr", "layout": args.layout,
                        "launches_per_step": 4 * chunks, "gates_per_launch": m_launch, "workload_sets_rotated": len(sets),
+                       "settle_ms": args.settle_ms, "settle_note": "untimed run of the same pipeline before the warm-up steps, every rank: keeps the timed region out of the "
+                                   "power controller's transient after idle (profiles/r02/ramp_probe.txt); --settle-ms 0 disables",
                        "parallelism": "gate-range sharding, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": ("k_beaver_finish_asm<0,NT>" if args.layout == "split" else "k_beaver_finish_asm_aos<0>") + " (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
