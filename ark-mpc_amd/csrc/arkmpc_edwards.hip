@@ -118,6 +118,69 @@ __device__ __forceinline__ Ed ed_scalar_mul_plain(const Ed& p, const Fe& s_mont)
     return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variable-base scalar-mul, hand-scheduled form (round 2): prep -> window loop (ed_asm_kernels.inc, tools/gen_ed_asm.py) -> finish.
+//   prep    signed 5-bit digits of the canonical scalar (51 windows: |d| <= 16, sign bit) and the table of cached points
+//           (Y+X, Y-X, 2dT, 2Z) of 0*P .. 16*P (entry 0 = the identity, so a zero digit needs no special case)
+//   loop    one asm stream: accumulator = identity; per window 5 doublings (dbl-2008-hwcd, T only in the last) and one
+//           addition of +-T[|d|] (add-2008-hwcd-3: complete on this curve -- no exceptional lanes, no flags, no fallback)
+//   finish  values below 2^255 -> canonical, stored as ark-ec's (x, y, t, z)
+// ---------------------------------------------------------------------------------------------
+#include "ed_asm_kernels.inc"
+#define TPB_EDLOOP 256
+#define ED_ASM_WS_BYTES (ED_ASM_TABLE * 128 + ED_ASM_WINDOWS * 4 + 128)
+struct EdAsmWs { u64* tab; u64* res; u32* dig; };
+static inline EdAsmWs ed_asm_carve(char* base, size_t n) {
+    EdAsmWs w;
+    w.tab = (u64*)base; base += n * ED_ASM_TABLE * 128;
+    w.res = (u64*)base; base += n * 128;
+    w.dig = (u32*)base;
+    return w;
+}
+__device__ __forceinline__ void ed_store_cached(u64* p, const Ed& a) {
+    fe_store(p, fe_add<EQ>(a.y, a.x));
+    fe_store(p + 4, fe_sub<EQ>(a.y, a.x));
+    fe_store(p + 8, EQ_MUL(a.t, ed_const(ED_D2_MONT)));
+    fe_store(p + 12, fe_dbl<EQ>(a.z));
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_smul_prep(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride, u32 s_div,
+                                                          EdAsmWs ws) {
+    const u32 i = blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    const Ed p = points ? ed_load(points + (size_t)p_stride * (i / p_div)) : ed_generator();
+    const Fe s = fe_to_canonical<ER>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
+    u32 carry = 0;
+    for (int j = 0; j < ED_ASM_WINDOWS; ++j) {                 // LSB first; step index = windows - 1 - j (the loop runs MSB first)
+        const int bit = 5 * j, limb = bit >> 5, sh = bit & 31;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lo = (limb == k) ? s.v[k] : lo; hi = (limb + 1 == k) ? s.v[k] : hi; }
+        u32 v = lo >> sh;
+        if (sh > 27) v |= hi << (32 - sh);
+        u32 d = (v & 31u) + carry, neg = 0;
+        if (d > 16u) { d = 32u - d; neg = 1; carry = 1; } else carry = 0;
+        ws.dig[(size_t)(ED_ASM_WINDOWS - 1 - j) * n + i] = d | ((d ? neg : 0u) << 5);
+    }
+    ed_store_cached(ws.tab + ((size_t)0 * n + i) * 16, ed_identity());
+    Ed acc = p;
+    ed_store_cached(ws.tab + ((size_t)1 * n + i) * 16, acc);
+    for (int k = 2; k <= 16; ++k) {                            // the unified addition covers k = 2 (P + P) as well
+        acc = ed_add(acc, p);
+        ed_store_cached(ws.tab + ((size_t)k * n + i) * 16, acc);
+    }
+}
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_loop(u32 n, const u64* tab, const u32* dig, u64* res) {
+    const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
+    if (i >= n) return;
+    ed_smul_loop_asm(i, n, tab, dig, res);
+}
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_finish(u32 n, const u64* res, u64* out) {
+    const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fe_store(out + 16 * (size_t)i + 4 * c, fe_reduce_once_loop<EQ>(fe_load(res + 16 * (size_t)i + 4 * c)));
+}
+
 template <bool NEGB>
 __global__ void __launch_bounds__(TPB_ED) k_ed_add(size_t n, const u64* a, const u64* b, u64* out) {
     size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
@@ -484,7 +547,11 @@ static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_
     const size_t CH = (size_t)1 << 20;
     const size_t chunk = m < CH ? m : CH;
     static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
-    int iw = (points || !fixed_base) ? st.declare_scratch(chunk * 15 * 128) : -1;
+    static const bool asm_loop = !(getenv("ARKMPC_ED_ASM") && getenv("ARKMPC_ED_ASM")[0] == '0');
+    const size_t ACH = (size_t)1 << 19;
+    const size_t achunk = m < ACH ? m : ACH;
+    int iw = -1;
+    if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(achunk * ED_ASM_WS_BYTES + 256) : st.declare_scratch(chunk * 15 * 128);
     if (st.commit()) return st.rc;
     if (m && !points && fixed_base) {
         const u64* table = nullptr;
@@ -492,6 +559,18 @@ static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_
         if (rc) return rc;
         hipLaunchKernelGGL(k_ed_generator_mul_fixed, dim3(blocks_for(m, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, m, st.in<u64>(is), s_stride, s_div, table,
                            st.out<u64>(io));
+        return st.finish();
+    }
+    if (m && asm_loop) {                                   // hand-scheduled window loop (prep / loop / finish kernels)
+        for (size_t lo = 0; lo < m; lo += achunk) {
+            const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
+            const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
+            const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
+            const EdAsmWs ws = ed_asm_carve(st.scratch<char>(iw), cnt);
+            hipLaunchKernelGGL(k_ed_smul_prep, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+            hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res);
+            hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.res, st.out<u64>(io) + 16 * lo);
+        }
         return st.finish();
     }
     for (size_t lo = 0; lo < m; lo += chunk) {

@@ -117,3 +117,51 @@ def test_committed_ec_header_is_current(tmp_path):
     import json
     st = json.load(open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec_asm_stats.json")))
     assert st["mult_instrs_per_montmul"] == 136 and st["mult_instrs_per_montsqr"] == 108 and st["doublings"] == 130 and st["mixed_additions"] == 55
+
+
+# ---- round 2: the Curve25519 window loop (tools/gen_ed_asm.py -> csrc/ed_asm_kernels.inc) ------------------------------------
+import gen_ed_asm as ed  # noqa: E402
+
+
+def test_ed_double_and_add_bodies_match_the_affine_edwards_law():
+    """dbl-2008-hwcd (rearranged without negations) and add-2008-hwcd-3 with a cached operand, with and without the T output, on the
+    emulator against the affine twisted-Edwards law in Python integers -- incl. the identity entry, P + P and P + (-P): the law is complete."""
+    r = ed.selftest(trials=36, seed=20260930)
+    assert len(r[False][0].order) < 2300 and len(r[False][1].order) < 2300
+
+
+def test_ed_value_range_at_its_edges():
+    """Every value the loop holds is below 2^255 + 19; multiplier outputs are below 2^255.  The folds are exercised at the edges of those
+    ranges (where the 257th bit and the top bit fire), not just on random operands."""
+    import random
+    rng = random.Random(9)
+    Q, R, LIM, B = ed.Q, ed.R, ed.LIM, ed.B255
+    Rinv = pow(R, -1, Q)
+
+    def run(seq_fn, vals, out):
+        def go():
+            rm = ed.RegMap()
+            E = ed.Emitter(); E.schedule(seq_fn(rm))
+            em = ed._emu(rm)
+            for regs, v in vals(rm):
+                em.setv(regs, v)
+            em.run(E.order)
+            return em.getv(out(rm))
+        return ed._with_globals(go)
+
+    edge = [0, 1, 18, 19, Q - 1, Q, Q + 1, B - 1, B, B + 18, LIM - 1]
+    for t in range(80):
+        a = rng.choice(edge) if t < 40 else rng.randrange(LIM)
+        b = rng.choice(edge) if t % 2 == 0 else rng.randrange(LIM)
+        m = run(lambda rm: ed.montmul(rm, rm.X1, rm.Y1, rm.Z1), lambda rm: ((rm.X1, a), (rm.Y1, b)), lambda rm: rm.Z1)
+        assert m < B and m % Q == a * b * Rinv % Q
+        s_ = run(lambda rm: ed.add_lz(rm, rm.X1, rm.Y1, rm.Z1, rm.A), lambda rm: ((rm.X1, a), (rm.Y1, b)), lambda rm: rm.Z1)
+        assert s_ < LIM and (s_ - (a + b)) % Q == 0
+        d = run(lambda rm: ed.sub_lz(rm, rm.X1, rm.Y1, rm.Z1, rm.A), lambda rm: ((rm.X1, a), (rm.Y1, b)), lambda rm: rm.Z1)
+        assert d < LIM and (d - (a - b)) % Q == 0
+
+
+def test_committed_ed_header_is_current(tmp_path):
+    out = tmp_path / "ed_asm_kernels.inc"
+    ed.emit_header(str(out))
+    assert out.read_text() == open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ed_asm_kernels.inc")).read(), "regenerate with: python tools/gen_ed_asm.py"

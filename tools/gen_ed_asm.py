@@ -1,0 +1,400 @@
+#!/usr/bin/env python3
+"""Generator for the hand-scheduled Curve25519 (twisted Edwards, a = -1) window loop (ark-mpc_amd/csrc/ed_asm_kernels.inc) -- the
+Edwards counterpart of tools/gen_ec_asm.py, built from the same multiplier rows, scheduler and emulator.
+
+What differs from the BN254 loop:
+  * the field is 2^255 - 19, so 4q > 2^256 and the [0, 2q) lazy range of BN254 does not exist.  Values live in [0, 2^255 + 19):
+    the multiplier rows accept that (input + q < 2^256 keeps the 9-limb accumulator below 2^288) and return < 1.5 * 2^255, a top-bit
+    fix (clear bit 255, add 19) brings that below 2^255; an addition is a 257-bit sum folded with 19 * (bits 255..256), a subtraction
+    is a + (2q - b) folded the same way -- both stay below 2^255 + 19.  No dedicated squaring rows (2a + q overflows the accumulator);
+  * the group law is COMPLETE (add-2008-hwcd-3 with a = -1 on a curve where -1 is a square and d is not): no exceptional lanes, no
+    blinding point, no flags -- the accumulator starts at the identity and a zero digit adds the identity's table entry;
+  * table entries are cached extended points (Y+X, Y-X, 2dT, 2Z): 7 multiplications per addition plus one for T when the next
+    operation needs it; doubling is dbl-2008-hwcd rearranged to avoid negations (3S + 4M, + 1 for T).
+
+One step = 5 doublings (the last one with T) + one addition of +-T[|d|]; 51 signed 5-bit windows cover the 253-bit scalars.
+The two bodies are executed by the single-lane emulator against the affine Edwards law in Python integers (--selftest).
+
+Reference semantics: CurvePoint * Scalar on ark_curve25519::EdwardsProjective (online-phase/src/algebra/curve/curve.rs:403-409,
+README.md:24), PointShare * Scalar (curve/share.rs:108-114).
+"""
+import argparse
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_asm_kernels as G
+import gen_ec_asm as EC
+from gen_asm_kernels import Ins, Emitter, M32, R, i_mov, i_mad, i_addco, i_addc, i_subco, i_subb, i_cnd, regs_of
+
+Q = dict(G.FIELDS)["CURVE25519_FQ"]
+L_ORD = dict(G.FIELDS)["CURVE25519_FR"]
+B255 = 1 << 255
+LIM = B255 + 19                      # every value the loop holds is below this
+D_ED = (-121665 * pow(121666, -1, Q)) % Q
+
+S_JUNK, S_CY2, S_INV = EC.S_JUNK, EC.S_CY2, EC.S_INV
+S_P = EC.S_P
+S_STEP, S_N4, S_N128, S_TMP, S_DBL = "s37", "s38", "s39", "s40", "s41"
+S_NEG, S_CY3, S_CY4 = "s[44:45]", EC.S_CY3, EC.S_CY4
+CLOBBER_SGPRS = ["s%d" % i for i in range(16, 56)]
+N_WINDOWS = 51
+N_TABLE = 17                         # identity + 16 multiples
+
+_POOL = [("vcc", S_CY2), (S_CY3, S_CY4)]
+_turn = [0]
+
+
+def _carries():
+    _turn[0] ^= 1
+    return _POOL[_turn[0]]
+
+
+class RegMap:
+    def __init__(self, first=8):
+        rg = G.Regs(first)
+        self.TWOQ = rg.vec(8)
+        self.X1, self.Y1, self.Z1, self.T1 = (rg.vec(8, 4) for _ in range(4))      # accumulator, extended coordinates
+        self.QP, self.QM, self.QT, self.QZ = (rg.vec(8, 4) for _ in range(4))      # table entry: Y+X, Y-X, 2dT, 2Z
+        self.A, self.Bv, self.Cv = (rg.vec(8, 4) for _ in range(3))                # temporaries
+        self.Tz = [rg.pair() for _ in range(9)]
+        self.T = [t[0] for t in self.Tz]
+        self.q = [rg.pair() for _ in range(8)]
+        self.m = rg.one()
+        self.c9, self.top = rg.one(), rg.one()
+        self.rec, self.off, self.tid4, self.tid128, self.tmp = (rg.one() for _ in range(5))
+        self.first, self.end = first, rg.next
+
+
+def i_and(d, a, b): return G.i_and(d, a, b)
+def i_lshr(d, a, sh): return EC.i_lshr(d, a, sh)
+def i_shl(d, a, sh): return EC.i_shl(d, a, sh)
+def i_or(d, a, b): return EC.i_or(d, a, b)
+def i_mul24(d, k, a): return Ins("v_mul_u32_u24_e32 %s, %d, %s" % (d, k, a), "mul24", (d, k, a), rd=regs_of(a), wr=[d])
+
+
+def fold(rm, s, c9, out, cy):
+    """out = (s mod 2^255) + 19 * (bits 255.. of the 257-bit value c9 * 2^256 + s).  For a value < 4 * 2^255 the result is < 2^255 + 57;
+    for the sums this generator forms it is < 2^255 + 19 (see the module docstring).  c9 = None: the value has no 257th bit."""
+    seq = [i_lshr(rm.top, s[7], 31)]
+    if c9 is not None:
+        seq += [i_shl(rm.c9, c9, 1), i_or(rm.top, rm.top, rm.c9)]
+    seq += [i_mul24(rm.top, 19, rm.top), i_and(rm.c9, 0x7fffffff, s[7])]
+    seq += [i_addco(out[0], s[0], rm.top, cy)] + [i_addc(out[j], 0, s[j], cy) for j in range(1, 7)] + [i_addc(out[7], 0, rm.c9, cy)]
+    return seq
+
+
+def montmul(rm, a, b, out):
+    """out = a b / R mod q, out < 2^255, for a, b < 2^255 + 19 (b may be SGPR names).  Multiplier rows + the top-bit fix."""
+    before = t = 0
+    for _ in range(64):                                   # exact worst case of the 9-limb accumulator for these input bounds
+        before = t + (LIM - 1) * M32 + M32 * Q
+        after = before >> 32
+        if after == t:
+            break
+        t = after
+    assert before < (1 << 288), "accumulator overflow for this input bound"
+    seq, _ = G.montmul_sum_seq(Q, [(a, b)], rm.T, rm.Tz, rm.q, rm.m, S_P, 0, final_out=out)
+    return seq + fold(rm, out, None, out, _carries()[0])
+
+
+def add_lz(rm, a, b, out, tmp):
+    c1, c2 = _carries()
+    seq = [i_addco(tmp[0], a[0], b[0], c1)] + [i_addc(tmp[j], a[j], b[j], c1) for j in range(1, 8)]
+    seq += [i_addc(rm.c9, 0, rm.Tz[8][1], c1)]            # the 257th bit (Tz[8][1] holds 0; src1 must be a VGPR)
+    return seq + fold(rm, tmp, rm.c9, out, c2)
+
+
+def sub_lz(rm, a, b, out, tmp):
+    """a - b = a + (2q - b) folded; b < 2^255 + 19 < 2q so the inner difference never borrows"""
+    c1, c2 = _carries()
+    seq = [i_subco(tmp[0], rm.TWOQ[0], b[0], c1)] + [i_subb(tmp[j], rm.TWOQ[j], b[j], c1) for j in range(1, 8)]
+    seq += [i_addco(tmp[0], a[0], tmp[0], c2)] + [i_addc(tmp[j], a[j], tmp[j], c2) for j in range(1, 8)]
+    seq += [i_addc(rm.c9, 0, rm.Tz[8][1], c2)]
+    return seq + fold(rm, tmp, rm.c9, out, c1)
+
+
+def seq_double(rm, with_t):
+    """dbl-2008-hwcd with a = -1, arranged without negations: A = X^2, B = Y^2, Cc = 2 Z^2, E = 2 X Y, G = B - A, F' = Cc - G (= -F),
+    Hn = A + B (= -H); (X3, Y3, Z3, T3) = (E F', G Hn, F' G, E Hn) is the standard result scaled by -1 throughout, i.e. the same point.
+    In place on the accumulator; scratch: the table-entry registers and A / Bv / Cv."""
+    X, Y, Z, T = rm.X1, rm.Y1, rm.Z1, rm.T1
+    A, B, Cc, E, Gv, Fp, Hn, t = rm.A, rm.Bv, rm.QP, rm.QM, rm.QT, rm.QZ, rm.Cv, rm.T1
+    s = []
+    s += montmul(rm, X, X, A)
+    s += montmul(rm, Y, Y, B)
+    s += montmul(rm, X, Y, E)
+    s += montmul(rm, Z, Z, Cc)
+    s += add_lz(rm, E, E, E, t)                  # E = 2 X Y           (T1 is dead inside a doubling: scratch)
+    s += add_lz(rm, Cc, Cc, Cc, t)               # Cc = 2 Z^2
+    s += sub_lz(rm, B, A, Gv, t)                 # G = B - A
+    s += add_lz(rm, A, B, Hn, t)                 # Hn = A + B
+    s += sub_lz(rm, Cc, Gv, Fp, t)               # F' = Cc - G
+    s += montmul(rm, E, Fp, X)
+    s += montmul(rm, Gv, Hn, Y)
+    s += montmul(rm, Fp, Gv, Z)
+    if with_t:
+        s += montmul(rm, E, Hn, T)
+    return s
+
+
+def seq_add(rm, with_t):
+    """add-2008-hwcd-3 (a = -1) with a cached second operand (Y2+X2, Y2-X2, 2d T2, 2 Z2): complete on this curve.  In place."""
+    X, Y, Z, T = rm.X1, rm.Y1, rm.Z1, rm.T1
+    A, B, t = rm.A, rm.Bv, rm.Cv
+    s = []
+    s += sub_lz(rm, Y, X, A, t)                  # Y1 - X1
+    s += add_lz(rm, Y, X, B, t)                  # Y1 + X1
+    s += montmul(rm, A, rm.QM, A)                # A
+    s += montmul(rm, B, rm.QP, B)                # B
+    s += montmul(rm, T, rm.QT, rm.QT)            # C
+    s += montmul(rm, Z, rm.QZ, rm.QZ)            # D
+    E, H, F, Gv = rm.QP, rm.QM, X, Y             # X1, Y1 are dead now
+    s += sub_lz(rm, B, A, E, t)                  # E = B - A
+    s += add_lz(rm, B, A, H, t)                  # H = B + A
+    s += sub_lz(rm, rm.QZ, rm.QT, F, t)          # F = D - C
+    s += add_lz(rm, rm.QZ, rm.QT, Gv, t)         # G = D + C
+    s += montmul(rm, F, Gv, Z)                   # Z3 = F G
+    if with_t:
+        s += montmul(rm, E, H, T)                # T3 = E H
+    s += montmul(rm, E, F, X)                    # X3 = E F     (F lives in X1: read before the write by the row structure)
+    s += montmul(rm, Gv, H, Y)                   # Y3 = G H
+    return s
+
+
+# ---- emulator -------------------------------------------------------------------------------------------------------------
+class EdEmu(EC.EcEmu):
+    def run(self, order):
+        for ins in order:
+            if ins.op == "mul24":
+                a = ins.args
+                self.v[a[0]] = (a[1] * (self.rd(a[2]) & 0xffffff)) & M32
+            else:
+                EC.EcEmu.run(self, [ins])
+
+
+def _with_globals(fn):
+    saved = (G.JUNK, G.S_INV, G.CY2)
+    G.JUNK, G.S_INV, G.CY2 = S_JUNK, S_INV, S_CY2
+    try:
+        return fn()
+    finally:
+        G.JUNK, G.S_INV, G.CY2 = saved
+
+
+def ed_add_aff(p, q_):
+    (x1, y1), (x2, y2) = p, q_
+    k = D_ED * x1 * x2 * y1 * y2 % Q
+    return ((x1 * y2 + y1 * x2) * pow(1 + k, -1, Q) % Q, (y1 * y2 + x1 * x2) * pow(1 - k, -1, Q) % Q)
+
+
+def ed_mul_aff(p, k):
+    r = (0, 1)
+    while k:
+        if k & 1: r = ed_add_aff(r, p)
+        p = ed_add_aff(p, p); k >>= 1
+    return r
+
+
+ED_BY = 4 * pow(5, -1, Q) % Q
+def _bx():
+    u = (ED_BY * ED_BY - 1) * pow(D_ED * ED_BY * ED_BY + 1, -1, Q) % Q
+    x = pow(u, (Q + 3) // 8, Q)
+    if (x * x - u) % Q: x = x * pow(2, (Q - 1) // 4, Q) % Q
+    assert (x * x - u) % Q == 0
+    return x if x % 2 == 0 else Q - x
+ED_B = (_bx(), ED_BY)
+mont = lambda v: v * R % Q
+unmont = lambda v: v * pow(R, -1, Q) % Q
+
+
+def _emu(rm):
+    em = EdEmu()
+    em.setv(rm.TWOQ, 2 * Q)
+    for t in rm.Tz:
+        em.v[t[1]] = 0
+    for j in range(8):
+        em.s[S_P[j]] = (Q >> (32 * j)) & M32
+    em.s[S_INV] = (-pow(Q, -1, 1 << 32)) & M32
+    return em
+
+
+def _lazy(rng, v):
+    """a representative of v mod q below 2^255 + 19"""
+    return v + Q if (rng.random() < 0.5 and v + Q < LIM) else v
+
+
+def selftest(trials=30, seed=11):
+    rng = random.Random(seed)
+    def body(fn, with_t):
+        def go():
+            rm = RegMap()
+            E = Emitter(); E.schedule(fn(rm, with_t))
+            return E, rm
+        return _with_globals(go)
+    out = {}
+    for with_t in (False, True):
+        Ed, rm = body(seq_double, with_t)
+        Ea, rm2 = body(seq_add, with_t)
+        out[with_t] = (Ed, Ea)
+        for t in range(trials):
+            P = ed_mul_aff(ED_B, rng.randrange(1, L_ORD)) if t % 7 else (0, 1)
+            z = rng.randrange(1, Q)
+            ext = lambda p_, z_: (p_[0] * z_ % Q, p_[1] * z_ % Q, z_, p_[0] * p_[1] * z_ % Q)
+            X, Y, Z, T = ext(P, z)
+            em = _emu(rm)
+            for regs, v in ((rm.X1, X), (rm.Y1, Y), (rm.Z1, Z), (rm.T1, T)):
+                em.setv(regs, mont(v))                    # the accumulator always holds multiplier outputs (< 2^255)
+            em.run(Ed.order)
+            gx, gy, gz, gt = (unmont(em.getv(r_) % Q) for r_ in (rm.X1, rm.Y1, rm.Z1, rm.T1))
+            assert max(em.getv(r_) for r_ in (rm.X1, rm.Y1, rm.Z1)) < B255
+            zi = pow(gz, -1, Q)
+            want = ed_add_aff(P, P)
+            assert (gx * zi % Q, gy * zi % Q) == want, ("double", with_t, t)
+            if with_t:
+                assert gt * zi % Q == want[0] * want[1] % Q
+            # addition with a cached operand, incl. the identity entry, the same point and the opposite point (complete law)
+            kind = t % 6
+            Qp = (0, 1) if kind == 0 else (P if kind == 1 else ((Q - P[0]) % Q, P[1]) if kind == 2 else ed_mul_aff(ED_B, rng.randrange(1, L_ORD)))
+            z2 = rng.randrange(1, Q)
+            X2, Y2, Z2, T2 = ext(Qp, z2)
+            em = _emu(rm2)
+            for regs, v in ((rm2.X1, X), (rm2.Y1, Y), (rm2.Z1, Z), (rm2.T1, T)):
+                em.setv(regs, mont(v))
+            for regs, v in ((rm2.QP, (Y2 + X2) % Q), (rm2.QM, (Y2 - X2) % Q), (rm2.QT, 2 * D_ED * T2 % Q), (rm2.QZ, 2 * Z2 % Q)):
+                em.setv(regs, _lazy(rng, mont(v)))
+            em.run(Ea.order)
+            gx, gy, gz, gt = (unmont(em.getv(r_) % Q) for r_ in (rm2.X1, rm2.Y1, rm2.Z1, rm2.T1))
+            zi = pow(gz, -1, Q)
+            want = ed_add_aff(P, Qp)
+            assert (gx * zi % Q, gy * zi % Q) == want, ("add", with_t, t, kind)
+            if with_t:
+                assert gt * zi % Q == want[0] * want[1] % Q
+    return out
+
+
+# ---- the loop ---------------------------------------------------------------------------------------------------------------
+def emit_loop():
+    """Operands: %[tid] (VGPR), %[n] (SGPR), %[tab] %[dig] %[res] (SGPR pairs).  tab: [17][n] cached entries of 128 B; dig: [51][n] records
+    (bits 0-4 table index = |digit|, bit 5 negate); res: [n] (X, Y, Z, T) of 128 B, values below 2^255."""
+    def go():
+        rm = RegMap()
+        L = []
+        A = L.append
+        lbl = lambda s: "%s_%%=" % s
+        quad = G.quad
+        inv = (-pow(Q, -1, 1 << 32)) & M32
+        one = R % Q
+        A("s_nop 1")
+        A("s_mov_b32 %s, 0x%08x" % (S_INV, inv))
+        for j in range(8):
+            A("s_mov_b32 %s, 0x%08x" % (S_P[j], (Q >> (32 * j)) & M32))
+            A("v_mov_b32_e32 %s, 0x%08x" % (rm.TWOQ[j], ((2 * Q) >> (32 * j)) & M32))
+        for t in rm.Tz:
+            A("v_mov_b32_e32 %s, 0" % t[1])
+        A("v_lshlrev_b32_e32 %s, 2, %%[tid]" % rm.tid4)
+        A("v_lshlrev_b32_e32 %s, 7, %%[tid]" % rm.tid128)
+        A("s_lshl_b32 %s, %%[n], 2" % S_N4)
+        A("s_lshl_b32 %s, %%[n], 7" % S_N128)
+        for j in range(8):                                            # accumulator = identity (0, 1, 1, 0)
+            A("v_mov_b32_e32 %s, 0" % rm.X1[j])
+            A("v_mov_b32_e32 %s, 0x%08x" % (rm.Y1[j], (one >> (32 * j)) & M32))
+            A("v_mov_b32_e32 %s, 0x%08x" % (rm.Z1[j], (one >> (32 * j)) & M32))
+            A("v_mov_b32_e32 %s, 0" % rm.T1[j])
+        A("s_mov_b32 %s, 0" % S_STEP)
+        EC.align_head(A)
+        A(lbl("E_step") + ":")
+        A("s_mul_i32 %s, %s, %s" % (S_TMP, S_STEP, S_N4))
+        A("v_add_u32_e32 %s, %s, %s" % (rm.off, S_TMP, rm.tid4))
+        A("global_load_dword %s, %s, %%[dig]" % (rm.rec, rm.off))
+        A("s_cmp_eq_u32 %s, 0" % S_STEP)
+        A("s_cbranch_scc1 " + lbl("E_nodbl"))
+        A("s_mov_b32 %s, 5" % S_DBL)
+        EC.align_head(A)
+        A(lbl("E_dbl") + ":")
+        Ed = Emitter(); Ed.schedule(seq_double(rm, False)); L.extend(Ed.lines)
+        # T = E Hn only before the addition: the last of the five doublings
+        A("s_cmp_lg_u32 %s, 1" % S_DBL)
+        A("s_cbranch_scc1 " + lbl("E_dbl_not"))
+        Et = Emitter(); Et.schedule(montmul(rm, rm.QM, rm.Cv, rm.T1)); L.extend(Et.lines)
+        A(lbl("E_dbl_not") + ":")
+        A("s_sub_u32 %s, %s, 1" % (S_DBL, S_DBL))
+        A("s_cmp_lg_u32 %s, 0" % S_DBL)
+        A("s_cbranch_scc1 " + lbl("E_dbl"))
+        A(lbl("E_nodbl") + ":")
+        A("s_waitcnt vmcnt(0)")
+        A("v_and_b32_e32 %s, 31, %s" % (rm.tmp, rm.rec))
+        A("v_mul_lo_u32 %s, %s, %s" % (rm.tmp, rm.tmp, S_N128))
+        A("v_add_u32_e32 %s, %s, %s" % (rm.off, rm.tmp, rm.tid128))
+        for k, regs in enumerate((rm.QP, rm.QM, rm.QT, rm.QZ)):
+            A("global_load_dwordx4 %s, %s, %%[tab] offset:%d" % (quad(regs[:4]), rm.off, 32 * k))
+            A("global_load_dwordx4 %s, %s, %%[tab] offset:%d" % (quad(regs[4:]), rm.off, 32 * k + 16))
+        A("v_and_b32_e32 %s, 32, %s" % (rm.tmp, rm.rec))
+        A("v_cmp_ne_u32_e64 %s, 0, %s" % (S_NEG, rm.tmp))
+        A("s_waitcnt vmcnt(0)")
+        # negative digit: -(x, y) has the cached form (Y-X, Y+X, -2dT, 2Z): swap the first two, 2dT -> 2q - 2dT (entries are canonical: < q)
+        En = Emitter()
+        seq = [i_subco(rm.A[0], rm.TWOQ[0], rm.QT[0], "vcc")] + [i_subb(rm.A[j], rm.TWOQ[j], rm.QT[j], "vcc") for j in range(1, 8)]
+        seq += fold(rm, rm.A, None, rm.A, S_CY2)                      # 2q - 0 = 2q would leave the value range (points with T = 0): fold it back
+        seq += EC.movs(rm.Bv, rm.QP)
+        En.lastw[S_NEG] = -1
+        seq += [i_cnd(rm.QP[j], rm.QP[j], rm.QM[j], S_NEG) for j in range(8)]
+        seq += [i_cnd(rm.QM[j], rm.QM[j], rm.Bv[j], S_NEG) for j in range(8)]
+        seq += [i_cnd(rm.QT[j], rm.QT[j], rm.A[j], S_NEG) for j in range(8)]
+        En.schedule(seq); L.extend(En.lines)
+        # 2q - 0 = 2q is not below 2^255 + 19: the identity entry (2dT = 0) is never negated (its record carries no sign)
+        Ea = Emitter(); Ea.schedule(seq_add(rm, False)); L.extend(Ea.lines)
+        # the very last addition also produces T (the result is stored in extended coordinates)
+        A("s_cmp_lg_u32 %s, %d" % (S_STEP, N_WINDOWS - 1))
+        A("s_cbranch_scc1 " + lbl("E_add_not"))
+        # T3 = E H with E = QP, H = QM as seq_add leaves them
+        Eat = Emitter(); Eat.schedule(montmul(rm, rm.QP, rm.QM, rm.T1)); L.extend(Eat.lines)
+        A(lbl("E_add_not") + ":")
+        A("s_add_u32 %s, %s, 1" % (S_STEP, S_STEP))
+        A("s_cmp_lt_u32 %s, %d" % (S_STEP, N_WINDOWS))
+        A("s_cbranch_scc1 " + lbl("E_step"))
+        for k, regs in enumerate((rm.X1, rm.Y1, rm.T1, rm.Z1)):        # ark-ec order: x, y, t, z
+            A("global_store_dwordx4 %s, %s, %%[res] offset:%d" % (rm.tid128, quad(regs[:4]), 32 * k))
+            A("global_store_dwordx4 %s, %s, %%[res] offset:%d" % (rm.tid128, quad(regs[4:]), 32 * k + 16))
+        A("s_waitcnt vmcnt(0)")
+        st = dict(double=len(Ed.order), double_nops=Ed.nops, add=len(Ea.order), add_nops=Ea.nops, vgpr_end=rm.end)
+        return L, rm, st
+    return _with_globals(go)
+
+
+def emit_header(path):
+    selftest(trials=14)
+    lines, rm, st = emit_loop()
+    def mults(fn):
+        def go():
+            rm_ = RegMap()
+            return sum(1 for i in fn(rm_) if i.op in ("mad", "mul_lo"))
+        return _with_globals(go)
+    m_mul = mults(lambda r_: montmul(r_, r_.X1, r_.Y1, r_.Z1))
+    loop_m = (N_WINDOWS - 1) * 5 * mults(lambda r_: seq_double(r_, False)) + (N_WINDOWS - 1) * m_mul + N_WINDOWS * mults(lambda r_: seq_add(r_, False)) + m_mul
+    out = ["// GENERATED by tools/gen_ed_asm.py -- do not edit.  The Curve25519 (twisted Edwards) window loop as one hand-scheduled gfx950 stream;",
+           "// see the generator for the value range (< 2^255 + 19), the complete addition law (no exceptional lanes) and the emulator check.",
+           "// double: %d instructions (%d wait states), add: %d (%d), VGPRs v%d..v%d; %d multiplier instructions per scalar-mul in the loop." %
+           (st["double"], st["double_nops"], st["add"], st["add_nops"], rm.first, rm.end - 1, loop_m),
+           "#pragma once", "#define ED_ASM_WINDOWS %d" % N_WINDOWS, "#define ED_ASM_TABLE %d" % N_TABLE, "#define ED_ASM_MULT_INSTRS_LOOP %d" % loop_m,
+           "__device__ __forceinline__ void ed_smul_loop_asm(u32 tid, u32 n, const u64* tab, const u32* dig, u64* res) {", "    asm volatile(",
+           G.c_string(lines), "        :", '        : [tid] "v"(tid), [n] "s"(n), [tab] "s"(tab), [dig] "s"(dig), [res] "s"(res)']
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(rm.first, rm.end)]
+    out += ["        : " + ", ".join(clob) + ");", "}"]
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    return st, len(lines), loop_m
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--selftest", action="store_true")
+    ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ark-mpc_amd", "csrc", "ed_asm_kernels.inc"))
+    a = ap.parse_args()
+    if a.selftest:
+        r = selftest(trials=120)
+        print("ok:", {k: (len(v[0].order), v[0].nops, len(v[1].order), v[1].nops) for k, v in r.items()})
+        sys.exit(0)
+    st, n, loop_m = emit_header(a.o)
+    print("ed loop: %d asm lines; %s; %d multiplier instructions per scalar-mul" % (n, st, loop_m))
