@@ -502,6 +502,48 @@ static void ed_launch_zinv(arkmpc_ctx* ctx, size_t n, const u64* pts, u64* pre, 
     hipLaunchKernelGGL(k_ed_zinv, dim3(blocks_for(threads, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, K, threads, pts, pre, zinv);
 }
 
+// the hand-scheduled pipeline over m outputs (out_j = points[j / p_div] * scalars[j / s_div]; s_stride = 0 broadcasts one scalar)
+static const size_t ED_ASM_CHUNK = (size_t)1 << 19;
+static bool ed_asm_enabled() {
+    static const bool on = !(getenv("ARKMPC_ED_ASM") && getenv("ARKMPC_ED_ASM")[0] == '0');
+    return on;
+}
+static inline size_t ed_smul_ws_bytes(size_t m) { return (m < ED_ASM_CHUNK ? m : ED_ASM_CHUNK) * ED_ASM_WS_BYTES + 256; }
+static void ed_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride, u32 s_div, u64* out,
+                           char* wsbase) {
+    const size_t achunk = m < ED_ASM_CHUNK ? m : ED_ASM_CHUNK;
+    for (size_t lo = 0; lo < m; lo += achunk) {
+        const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
+        const u64* pp = points ? points + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
+        const u64* sp = scalars + (size_t)s_stride * (lo / s_div);
+        const EdAsmWs ws = ed_asm_carve(wsbase, cnt);
+        hipLaunchKernelGGL(k_ed_smul_prep, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+        hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res);
+        hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.res, out + 16 * lo);
+    }
+}
+__global__ void __launch_bounds__(64) k_ed_store_scalar(Fe v, u64* out) {
+    if (blockIdx.x | threadIdx.x) return;
+    fe_store(out, v);
+}
+// add_public / sub_public and the point MAC check with mac_key * point already computed by the pipeline (kp): additions only
+template <bool NEG>
+__global__ void __launch_bounds__(TPB_ED) k_edshare_add_public_kp(size_t n, int party, const u64* shares, const u64* pub, const u64* kp, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    Ed rhs = ed_load(pub + 16 * i), krhs = ed_load(kp + 16 * i), sh = ed_load(shares + 32 * i), mac = ed_load(shares + 32 * i + 16);
+    if (NEG) { rhs = ed_neg(rhs); krhs = ed_neg(krhs); }
+    if (party == 0) sh = ed_add(sh, rhs);
+    mac = ed_add(mac, krhs);
+    ed_store(out + 32 * i, sh);
+    ed_store(out + 32 * i + 16, mac);
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_mac_check_kp(size_t n, const u64* kv, const u64* shares, u64* out) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    ed_store(out + 16 * i, ed_add(ed_load(kv + 16 * i), ed_neg(ed_load(shares + 32 * i + 16))));
+}
+
 #define ENTER_ED(ctx)                                                                           \
     if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
     CtxGuard guard__(ctx);                                                                      \
@@ -547,11 +589,9 @@ static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_
     const size_t CH = (size_t)1 << 20;
     const size_t chunk = m < CH ? m : CH;
     static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
-    static const bool asm_loop = !(getenv("ARKMPC_ED_ASM") && getenv("ARKMPC_ED_ASM")[0] == '0');
-    const size_t ACH = (size_t)1 << 19;
-    const size_t achunk = m < ACH ? m : ACH;
+    const bool asm_loop = ed_asm_enabled();
     int iw = -1;
-    if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(achunk * ED_ASM_WS_BYTES + 256) : st.declare_scratch(chunk * 15 * 128);
+    if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(ed_smul_ws_bytes(m)) : st.declare_scratch(chunk * 15 * 128);
     if (st.commit()) return st.rc;
     if (m && !points && fixed_base) {
         const u64* table = nullptr;
@@ -562,15 +602,7 @@ static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_
         return st.finish();
     }
     if (m && asm_loop) {                                   // hand-scheduled window loop (prep / loop / finish kernels)
-        for (size_t lo = 0; lo < m; lo += achunk) {
-            const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
-            const u64* pp = points ? st.in<u64>(ip) + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
-            const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
-            const EdAsmWs ws = ed_asm_carve(st.scratch<char>(iw), cnt);
-            hipLaunchKernelGGL(k_ed_smul_prep, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
-            hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res);
-            hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.res, st.out<u64>(io) + 16 * lo);
-        }
+        ed_smul_launch(ctx, m, points ? st.in<u64>(ip) : (const u64*)nullptr, p_stride, p_div, st.in<u64>(is), s_stride, s_div, st.out<u64>(io), st.scratch<char>(iw));
         return st.finish();
     }
     for (size_t lo = 0; lo < m; lo += chunk) {
@@ -603,8 +635,19 @@ static int edshare_addsub_public(arkmpc_ctx* ctx, bool sub, size_t n, int party_
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int is = st.declare_in(shares, n * 256), ip = st.declare_in(pub_points, n * 128), io = st.declare_out(out, n * 256);
+    const bool asm_loop = ed_asm_enabled();
+    int iw = asm_loop ? st.declare_scratch(ed_smul_ws_bytes(n)) : -1, ik = asm_loop ? st.declare_scratch(n * 128 + 64) : -1;
     if (st.commit()) return st.rc;
     const dim3 g(blocks_for(n, TPB_ED)), t(TPB_ED);
+    if (n && asm_loop) {                                   // mac_key * rhs through the scalar-mul pipeline (one broadcast scalar)
+        u64* dkey = st.scratch<u64>(ik);
+        u64* kp = dkey + 8;
+        hipLaunchKernelGGL(k_ed_store_scalar, dim3(1), dim3(64), 0, ctx->stream, fe_from_host(mac_key), dkey);
+        ed_smul_launch(ctx, n, st.in<u64>(ip), 16, 1, dkey, 0, 1, kp, st.scratch<char>(iw));
+        if (sub) hipLaunchKernelGGL(k_edshare_add_public_kp<true>, g, t, 0, ctx->stream, n, party_id, st.in<u64>(is), st.in<u64>(ip), kp, st.out<u64>(io));
+        else hipLaunchKernelGGL(k_edshare_add_public_kp<false>, g, t, 0, ctx->stream, n, party_id, st.in<u64>(is), st.in<u64>(ip), kp, st.out<u64>(io));
+        return st.finish();
+    }
     if (n && sub) hipLaunchKernelGGL(k_edshare_add_public<true>, g, t, 0, ctx->stream, n, party_id, fe_from_host(mac_key), st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
     else if (n) hipLaunchKernelGGL(k_edshare_add_public<false>, g, t, 0, ctx->stream, n, party_id, fe_from_host(mac_key), st.in<u64>(is), st.in<u64>(ip), st.out<u64>(io));
     return st.finish();
@@ -636,7 +679,17 @@ int arkmpc_ed_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int iv = st.declare_in(opened_points, n * 128), is = st.declare_in(shares, n * 256), io = st.declare_out(out_chk_points, n * 128);
+    const bool asm_loop = ed_asm_enabled();
+    int iw = asm_loop ? st.declare_scratch(ed_smul_ws_bytes(n)) : -1, ik = asm_loop ? st.declare_scratch(n * 128 + 64) : -1;
     if (st.commit()) return st.rc;
+    if (n && asm_loop) {
+        u64* dkey = st.scratch<u64>(ik);
+        u64* kv = dkey + 8;
+        hipLaunchKernelGGL(k_ed_store_scalar, dim3(1), dim3(64), 0, ctx->stream, fe_from_host(mac_key), dkey);
+        ed_smul_launch(ctx, n, st.in<u64>(iv), 16, 1, dkey, 0, 1, kv, st.scratch<char>(iw));
+        hipLaunchKernelGGL(k_ed_mac_check_kp, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, kv, st.in<u64>(is), st.out<u64>(io));
+        return st.finish();
+    }
     if (n) hipLaunchKernelGGL(k_ed_mac_check, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, fe_from_host(mac_key), st.in<u64>(iv),
                               st.in<u64>(is), st.out<u64>(io));
     return st.finish();
