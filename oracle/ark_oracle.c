@@ -921,3 +921,22 @@ void ora_beaver_mask_mt(int fid, size_t n, const u64* x, const u64* y, const u64
     bmk_ctx c = {fid, n, x, y, a, b, out_de};
     par_for(n, nthreads, bmk_range, &c);
 }
+
+typedef struct { const u64 *pts, *scalars; size_t p_div, s_div; u64* out; } edm_ctx;
+static void edm_range(void* p, size_t lo, size_t hi) {
+    edm_ctx* c = (edm_ctx*)p;
+    for (size_t i = lo; i < hi; ++i) ora_ed_scalar_mul(c->pts + 16 * (i / c->p_div), c->scalars + 4 * (i / c->s_div), c->out + 16 * i);
+}
+void ora_ed_batch_scalar_mul_mt(size_t n, const u64* pts, size_t p_div, const u64* scalars, size_t s_div, u64* out, int nthreads) {
+    edm_ctx c = {pts, scalars, p_div, s_div, out};
+    par_for(n, nthreads, edm_range, &c);
+}
+typedef struct { const u64* pts; u64* xy; } eda_ctx;
+static void eda_range(void* p, size_t lo, size_t hi) {
+    eda_ctx* c = (eda_ctx*)p;
+    ora_ed_batch_to_affine(hi - lo, c->pts + 16 * lo, c->xy + 8 * lo);
+}
+void ora_ed_batch_to_affine_mt(size_t n, const u64* pts, u64* out_xy, int nthreads) {
+    eda_ctx c = {pts, out_xy};
+    par_for(n, nthreads, eda_range, &c);
+}

@@ -172,6 +172,8 @@ void ora_open_and_mac_check_mt(int field_id, size_t n, const u64 mac_key[4], con
                                u64* out_opened, u64* out_chk, int nthreads);
 void ora_pointshare_batch_mul_public_mt(size_t n, const u64* shares, const u64* scalars, u64* out, int nthreads);
 void ora_g1_batch_to_affine_mt(size_t n, const u64* pts, u64* out_xy, unsigned char* is_inf, int nthreads);
+void ora_ed_batch_scalar_mul_mt(size_t n, const u64* pts, size_t p_div, const u64* scalars, size_t s_div, u64* out, int nthreads);
+void ora_ed_batch_to_affine_mt(size_t n, const u64* pts, u64* out_xy, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -260,6 +260,18 @@ class Oracle:
                                                     ctypes.c_int(nthreads or self.host_threads()))
         return out
 
+    def ed_batch_scalar_mul_mt(self, pts, scalars, n, p_div=1, s_div=1, nthreads=None):
+        out = np.zeros(16 * n, dtype=np.uint64)
+        self.lib.ora_ed_batch_scalar_mul_mt(ctypes.c_size_t(n), self._p(pts), ctypes.c_size_t(p_div), self._p(scalars), ctypes.c_size_t(s_div), self._p(out),
+                                            ctypes.c_int(nthreads or self.host_threads()))
+        return out
+
+    def ed_batch_to_affine_mt(self, pts, nthreads=None):
+        n = len(pts) // 16
+        out = np.zeros(8 * n, dtype=np.uint64)
+        self.lib.ora_ed_batch_to_affine_mt(ctypes.c_size_t(n), self._p(pts), self._p(out), ctypes.c_int(nthreads or self.host_threads()))
+        return out
+
     def g1_batch_to_affine_mt(self, pts, nthreads=None):
         n = len(pts) // 12
         xy = np.zeros(8 * n, dtype=np.uint64); inf = np.zeros(n, dtype=np.uint8)

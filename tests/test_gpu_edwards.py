@@ -180,3 +180,43 @@ def test_ed_sums(eng, oracle):
         assert aff_equal(eng, oracle, o, want)
         o1 = np.zeros(16, dtype=np.uint64); eng.ed_sum(2 * n, A, o1)
         assert aff_equal(eng, oracle, o1, oracle.ed_sum(A) if n else oracle.ed_identity())
+
+
+def test_edshare_mul_public_at_scale_vs_oracle(pkg, oracle):
+    """The hand-scheduled Curve25519 window loop on 2^15 PointShares (2^16 scalar-muls) against the oracle's double-and-add on affine
+    coordinates: random scalars plus scalars built so that every window sees every digit of the signed recoding (0, +-1 ... +-15, +16,
+    carries into the top window), points with random Z.  Hosts with fewer than 16 cores check a 2^11 sample."""
+    import torch
+    n = 1 << 15
+    e = pkg.Engine("curve25519_fr", device=0, stream=torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda"); g.manual_seed(0xED25519)
+    def rnd(cnt):
+        raw = torch.randint(-(2**63), 2**63 - 1, (4 * cnt,), dtype=torch.int64, device="cuda", generator=g)
+        out = torch.empty_like(raw); e.scalar_from_canonical(cnt, raw, out); return out
+    k = rnd(2 * n)
+    shares = torch.empty(32 * n, dtype=torch.int64, device="cuda")
+    e.scalarshare_mul_ed_generator(n, k, shares)                 # P_i = k_i B: extended points with Z = 1 from the fixed-base path ...
+    # ... and doubled points (Z != 1) for the other half of the batch
+    dbl = torch.empty_like(shares); e.edshare_add(n, shares, shares, dbl)
+    pts = torch.cat([shares[:16 * n], dbl[16 * n:]])
+    L = pyref.EL
+    special = []
+    for d in list(range(0, 32)):
+        special.append(sum(d << (5 * j) for j in range(51)) % L)                       # the same 5-bit pattern in every window
+    special += [0, 1, 2, 15, 16, 17, 31, 32, L - 1, L - 2, (1 << 252), (1 << 252) - 1, (L - 1) // 2]
+    sc_host = mont_array(2, special + rand_values(2, n - len(special), 777))
+    sc = torch.from_numpy(sc_host.view(np.int64)).cuda()
+    out = torch.empty_like(pts)
+    e.edshare_mul_public(n, pts, sc, out)
+    xy = torch.empty(8 * 2 * n, dtype=torch.int64, device="cuda"); e.ed_to_affine(2 * n, out, xy)
+    torch.cuda.synchronize()
+    threads = oracle.host_threads()
+    idx = np.arange(n) if threads >= 16 else np.concatenate([np.arange(64), np.arange(64, n, n >> 11)])
+    hp = np.ascontiguousarray(pts.cpu().numpy().view(np.uint64).reshape(n, 32)[idx]).reshape(-1)
+    hs = np.ascontiguousarray(sc_host.reshape(n, 4)[idx]).reshape(-1)
+    want = oracle.ed_batch_scalar_mul_mt(hp, hs, 2 * len(idx), p_div=1, s_div=2)
+    wxy = oracle.ed_batch_to_affine_mt(want)
+    gxy = xy.cpu().numpy().view(np.uint64).reshape(n, 16)[idx].reshape(-1)
+    bad = np.nonzero((gxy.reshape(-1, 8) != wxy.reshape(-1, 8)).any(axis=1))[0]
+    assert bad.size == 0, "%d of %d scalar-muls differ from the oracle, first at %d" % (bad.size, 2 * len(idx), bad[0])
+    e.close()
