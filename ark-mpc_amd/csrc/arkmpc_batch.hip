@@ -203,4 +203,36 @@ int arkmpc_batch_beaver_finish(arkmpc_ctx* ctx, int party_id, const uint64_t mac
     return rc;
 }
 
+// ---- events: device-side ordering between the streams of two contexts ---------------------------------------------------------
+}  // extern "C"
+struct arkmpc_event { hipEvent_t ev; int device; };
+extern "C" {
+int arkmpc_event_record(arkmpc_ctx* ctx, arkmpc_event** out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    CtxGuard guard(ctx);
+    if (guard.rc) return guard.rc;
+    if (!out) return ark_bad(ctx, "null out");
+    *out = nullptr;
+    hipEvent_t ev;
+    ARK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);
+    if (e != hipSuccess) { (void)hipEventDestroy(ev); ctx->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    *out = new arkmpc_event{ev, ctx->device};
+    return ARKMPC_OK;
+}
+int arkmpc_event_wait(arkmpc_ctx* ctx, arkmpc_event* event) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    CtxGuard guard(ctx);
+    if (guard.rc) return guard.rc;
+    if (!event) return ark_bad(ctx, "null event");
+    ARK_HIP(ctx, hipStreamWaitEvent(ctx->stream, event->ev, 0));
+    return ARKMPC_OK;
+}
+int arkmpc_event_destroy(arkmpc_event* event) {
+    if (!event) return ARKMPC_ERR_BAD_ARG;
+    (void)hipEventDestroy(event->ev);          // HIP defers the release until the event has completed
+    delete event;
+    return ARKMPC_OK;
+}
+
 }  // extern "C"

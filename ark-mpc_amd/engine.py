@@ -122,6 +122,18 @@ class Engine:
     def sync(self):
         self._ck(self.lib.arkmpc_sync(self.h))
 
+    # ---- device-side ordering between two contexts' streams (arkmpc_event_*)
+    def event_record(self):
+        ev = ctypes.c_void_p()
+        self._ck(self.lib.arkmpc_event_record(self.h, ctypes.byref(ev)))
+        return ev
+
+    def event_wait(self, ev):
+        self._ck(self.lib.arkmpc_event_wait(self.h, ev))
+
+    def event_destroy(self, ev):
+        self.lib.arkmpc_event_destroy(ev)
+
     # ---- raw call helper: name, n, then pointers / scalars in ABI order
     def call(self, name, *args):
         fn = getattr(self.lib, "arkmpc_" + name)

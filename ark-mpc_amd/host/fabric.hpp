@@ -142,6 +142,8 @@ struct NetworkOutbound {
     // device mode (LinkMode::Device): the batch stays in HBM and the message carries its buffer -- the in-memory move of
     // network/mock.rs:63-88 for a GPU-resident value (both parties of the mock run in one process on one GPU)
     std::shared_ptr<DeviceBuf> dev;
+    // ... ordered after the sender's stream by an event the receiver's stream waits on (device side; neither host thread blocks)
+    std::shared_ptr<arkmpc_event> ready;
 };
 class MpcNetwork {
   public:
@@ -391,14 +393,20 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         frames_sent()++;
         net_->send(std::move(m));
     }
-    // device handoff: a private copy of the words (the sender keeps using its buffer), ordered before the receiver's
-    // stream by a sync of the sender's stream
+    // device handoff: a private copy of the words (the sender keeps using its buffer); the receiver's stream waits for the copy
+    // through an event (arkmpc_event_record / _wait) -- the sending thread does not block on its stream, which is what bounds the
+    // round time of latency-bound circuits (one network round per sequential gate)
     void send_device(const DeviceBuf& src, size_t words) {
         auto copy = std::make_shared<DeviceBuf>(eng_, words ? words : 1);
         copy->set_words(words);
         if (words) check(ctx(), arkmpc_memcpy_d2d(ctx(), copy->ptr(), src.ptr(), words * 8), "d2d");
-        check(ctx(), arkmpc_sync(ctx()), "sync");
-        net_->send(NetworkOutbound{next_id_++, {}, {}, std::move(copy)});
+        arkmpc_event* ev = nullptr;
+        check(ctx(), arkmpc_event_record(ctx(), &ev), "event_record");
+        NetworkOutbound m{next_id_++, {}, {}, std::move(copy), std::shared_ptr<arkmpc_event>(ev, [](arkmpc_event* e) { arkmpc_event_destroy(e); })};
+        net_->send(std::move(m));
+    }
+    void await_device(const NetworkOutbound& m) {
+        if (m.ready) check(ctx(), arkmpc_event_wait(ctx(), m.ready.get()), "event_wait");
     }
     // `expect` = the element count the protocol step requires.  What arrives is the PEER's choice (a short, empty or oversized
     // payload would otherwise be read out of bounds by the kernels launched with the local n), so a mismatch is a network
@@ -416,6 +424,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         const uint64_t id = next_id_++;
         if (link_ == LinkMode::Device) {
             if (!m.dev) throw std::runtime_error("MpcNetworkError: device link message without a buffer");
+            await_device(m);
             ScalarBatch b; b.n = m.dev->words() / 4; b.buf = std::move(*m.dev); b.buf.rebind(eng_); return b;
         }
         if (!wire_) return allocate_scalars(m.payload);
@@ -475,6 +484,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         const uint64_t id = next_id_++;
         if (link_ == LinkMode::Device) {
             if (!m.dev || m.dev->words() != Cv::PW * n) throw std::runtime_error("MpcNetworkError: unexpected point payload size");
+            await_device(m);
             PB r; r.n = n; r.buf = std::move(*m.dev); r.buf.rebind(eng_); return r;
         }
         PB r; r.n = n; r.buf = DeviceBuf(eng_, ARKMPC_KIND_POINT, n);

@@ -73,6 +73,14 @@ const char* arkmpc_last_error(arkmpc_ctx* ctx);
  * (it blocks until the kernel has finished).  Unlike marker events recorded between launches this excludes the dispatch gap. */
 int arkmpc_kernel_timer_arm(arkmpc_ctx* ctx, int slot);
 int arkmpc_kernel_timer_ms(arkmpc_ctx* ctx, int slot, float* out_ms);
+/* Cross-context ordering without blocking the host: arkmpc_event_record marks the work submitted so far on ctx's stream,
+ * arkmpc_event_wait makes ANOTHER context's stream wait for that mark on the device (the host call returns at once).  This is
+ * how a batch handed from one party / gate to another stays ordered when both keep their own stream (the mock link of the
+ * host mirror; rayon workers sharing device batches).  The event may be waited on by any number of contexts, then destroyed. */
+typedef struct arkmpc_event arkmpc_event;
+int arkmpc_event_record(arkmpc_ctx* ctx, arkmpc_event** out_event);
+int arkmpc_event_wait(arkmpc_ctx* ctx, arkmpc_event* event);
+int arkmpc_event_destroy(arkmpc_event* event);
 const char* arkmpc_version(void);
 int arkmpc_device_count(void);
 /* device memory helpers for callers without their own allocator (Rust shim, tests).  Blocks come from a per-device pool;

@@ -441,3 +441,29 @@ def test_open_and_mac_check_on_columns_equals_aos(pkg, oracle, fid):
     with pytest.raises(pkg.ArkMpcError):
         e.open_and_mac_check_v(n, kk, sc, mc, 3, d_peer, o, c)
     e.close()
+
+
+def test_event_orders_one_contexts_stream_after_anothers(pkg):
+    """arkmpc_event_record / _wait: context B (own stream) consumes what context A (own stream) is still computing, with no host
+    synchronisation in between -- the shape of the mirror's device link (one party's masked values feeding the peer's K3)."""
+    import torch
+    fid, n = 0, 1 << 18
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    A = pkg.Engine(fid, device=0, stream=sa.cuda_stream)
+    B = pkg.Engine(fid, device=0, stream=sb.cuda_stream)
+    x = torch.from_numpy(mont_array(fid, rand_values(fid, n, 77)).view(np.int64)).cuda()
+    inv = torch.zeros_like(x); prod = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    for _ in range(8):                                             # a few ms of work queued on A's stream
+        A.scalar_batch_inverse(n, x, inv)
+    ev = A.event_record()
+    B.event_wait(ev)                                               # returns at once; B's stream waits on the device
+    B.scalar_mul(n, x, inv, prod)
+    B.sync()
+    A.event_destroy(ev)
+    one = mont_array(fid, [1])
+    got = prod.cpu().numpy().view(np.uint64).reshape(n, 4)
+    assert (got == one.reshape(1, 4)).all()
+    with pytest.raises(pkg.ArkMpcError):
+        B.event_wait(None)
+    A.close(); B.close()
