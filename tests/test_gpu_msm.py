@@ -62,6 +62,40 @@ def test_msm_exceptional_bucket_members(hip, oracle):
     assert np.array_equal(msm(hip, Q, SQ), oracle.g1_identity())
 
 
+def test_msm_asm_accumulation_flags_exceptional_members():
+    """The hand-scheduled bucket accumulation (k_msm_accumulate_asm) only FLAGS a task whose chain of mixed additions meets H = 0; the compiled
+    kernel then redoes it.  With that recomputation switched off (ARKMPC_MSM_ASM_NOFIX=1, a test hook) the repeated-base input must come out
+    wrong and an ordinary input right -- i.e. the exceptional test above does travel through the flag, and nothing else does."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import importlib, sys, os
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, oracle_api
+        from helpers import mont_array, rand_values, EngineAdapter
+        import test_gpu_msm as T
+        hip = EngineAdapter(importlib.import_module("ark-mpc_amd")); ora = oracle_api.load()
+        n = 16
+        pts, P = T.random_points(n, 950, with_identity=False)
+        ks = rand_values(0, n, 951)
+        S = mont_array(0, ks)
+        plain = T.affine_equal(hip, ora, T.msm(hip, P, S), ora.g1_msm(P, S))
+        P[12 * 3:12 * 4] = P[12 * 2:12 * 3]; ks[3] = ks[2]
+        S = mont_array(0, ks)
+        repeated = T.affine_equal(hip, ora, T.msm(hip, P, S), ora.g1_msm(P, S))
+        print([int(plain), int(repeated)])
+    """ % (root, root))
+    out = {}
+    for nofix in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, ARKMPC_MSM_ASM_NOFIX=nofix), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[nofix] = eval(r.stdout.strip().splitlines()[-1])
+    assert out["1"] == [1, 0] and out["0"] == [1, 1]
+
+
 @pytest.mark.parametrize("c", [2, 4, 7, 11, 13, 16])
 def test_msm_every_window_width(hip, oracle, c):
     """Force the window width: W = 254 // c + 1 signed digits, top-window carry included."""

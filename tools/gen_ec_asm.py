@@ -503,6 +503,99 @@ def emit_loop():
     return _with_globals(go)
 
 
+def emit_msm_acc():
+    """Bucket accumulation of the variable-base MSM (arkmpc_msm.inc, step M3) on the mixed-addition body of the window loop: a lane folds
+    the `len` members of its task -- vals[first .. first + len): point index | sign << 31 -- into one Jacobian sum.  The accumulator starts
+    as the first member (Z = 1), so it is never the identity; H = 0 (a repeated point, or P + (-P)) only raises the lane's flag and the
+    compiled kernel redoes that task.  The next member's index is fetched while the current one is added, and its coordinates are
+    requested as soon as the addition has consumed the registers.
+    Operands: %[lo4] (VGPR: byte offset of the first member in vals), %[len] (VGPR, >= 1), %[maxlen] (SGPR: longest task of the wave),
+    %[vals] %[aff] %[exc] (SGPR pairs), %[dst] (VGPR pair: where this lane's sum goes), %[t4] (VGPR: 4 * task index)."""
+    def go():
+        rm = RegMap()
+        rec2, last = rm.tid96, rm.tid64
+        L = []
+        A = L.append
+        lbl = lambda s: "%s_%%=" % s
+        inv = (-pow(Q, -1, 1 << 32)) & M32
+        A("s_nop 1")
+        A("s_mov_b32 %s, 0x%08x" % (S_INV, inv))
+        for j in range(8):
+            A("s_mov_b32 %s, 0x%08x" % (S_P[j], (Q >> (32 * j)) & M32))
+        for j in range(8):
+            A("v_mov_b32_e32 %s, 0x%08x" % (rm.TWOQ[j], (TWOQ >> (32 * j)) & M32))
+        for t in rm.Tz:
+            A("v_mov_b32_e32 %s, 0" % t[1])
+        A("s_mov_b64 %s, 0" % S_EXC)
+        A("v_add_u32_e32 %s, -1, %%[len]" % last)                      # index of the last member: prefetches beyond it are clamped to it
+
+        def load_xy(dst_x, dst_y):
+            A("v_lshlrev_b32_e32 %s, 6, %s" % (rm.off, rm.rec))         # 64 bytes per affine point; the shift drops the sign bit (index < 2^25)
+            for k, regs in enumerate((dst_x[:4], dst_x[4:], dst_y[:4], dst_y[4:])):
+                A("global_load_dwordx4 %s, %s, %%[aff] offset:%d" % (quad(regs), rm.off, 16 * k))
+
+        def neg_y(Y):
+            En = Emitter()
+            seq = [i_subco(rm.T2[0], rm.TWOQ[0], Y[0], "vcc")] + [i_subb(rm.T2[j], rm.TWOQ[j], Y[j], "vcc") for j in range(1, 8)]
+            En.lastw[S_NEG] = -1
+            seq += [i_cnd(Y[j], Y[j], rm.T2[j], S_NEG) for j in range(8)]
+            En.schedule(seq)
+            L.extend(En.lines)
+
+        A("global_load_dword %s, %%[lo4], %%[vals]" % rm.rec)
+        A("v_min_u32_e32 %s, 1, %s" % (rm.tmp, last))
+        A("v_lshl_add_u32 %s, %s, 2, %%[lo4]" % (rm.tmp, rm.tmp))
+        A("global_load_dword %s, %s, %%[vals]" % (rec2, rm.tmp))
+        A("s_waitcnt vmcnt(1)")
+        load_xy(rm.X1, rm.Y1)
+        A("v_cmp_gt_i32_e64 %s, 0, %s" % (S_NEG, rm.rec))
+        one = R % Q
+        for j in range(8):
+            A("v_mov_b32_e32 %s, 0x%08x" % (rm.Z1[j], (one >> (32 * j)) & M32))
+        A("s_waitcnt vmcnt(0)")
+        neg_y(rm.Y1)
+        A("v_mov_b32_e32 %s, %s" % (rm.rec, rec2))
+        load_xy(rm.X2, rm.Y2)
+        A("s_mov_b32 %s, 1" % S_STEP)
+        A("s_cmp_ge_u32 %s, %%[maxlen]" % S_STEP)
+        A("s_cbranch_scc1 " + lbl("L_done"))
+        align_head(A)
+        A(lbl("L_step") + ":")
+        A("s_add_u32 %s, %s, 1" % (S_TMP, S_STEP))
+        A("v_min_u32_e32 %s, %s, %s" % (rm.tmp, S_TMP, last))
+        A("v_lshl_add_u32 %s, %s, 2, %%[lo4]" % (rm.tmp, rm.tmp))
+        A("global_load_dword %s, %s, %%[vals]" % (rec2, rm.tmp))
+        A("v_cmp_gt_u32_e64 %s, %%[len], %s" % (S_NZ, S_STEP))          # this lane still has a member at this step
+        A("v_cmp_gt_i32_e64 %s, 0, %s" % (S_NEG, rm.rec))
+        for d, s_ in zip(rm.SX + rm.SY + rm.SZ, rm.X1 + rm.Y1 + rm.Z1):
+            A("v_mov_b32_e32 %s, %s" % (d, s_))
+        A("s_waitcnt vmcnt(1)")
+        neg_y(rm.Y2)
+        Ea = Emitter()
+        Ea.schedule(seq_madd(rm))
+        L.extend(Ea.lines)
+        A("s_nop 1")
+        A("s_or_b64 %s, %s, %s" % (S_M1, S_M1, S_M2))
+        A("s_and_b64 %s, %s, %s" % (S_M1, S_M1, S_NZ))
+        A("s_or_b64 %s, %s, %s" % (S_EXC, S_EXC, S_M1))
+        for d, s_ in zip(rm.X1 + rm.Y1 + rm.Z1, rm.SX + rm.SY + rm.SZ):
+            A("v_cndmask_b32_e64 %s, %s, %s, %s" % (d, s_, d, S_NZ))
+        A("s_waitcnt vmcnt(0)")
+        A("v_mov_b32_e32 %s, %s" % (rm.rec, rec2))
+        load_xy(rm.X2, rm.Y2)
+        A("s_add_u32 %s, %s, 1" % (S_STEP, S_STEP))
+        A("s_cmp_lt_u32 %s, %%[maxlen]" % S_STEP)
+        A("s_cbranch_scc1 " + lbl("L_step"))
+        A(lbl("L_done") + ":")
+        for k, regs in enumerate((rm.X1[:4], rm.X1[4:], rm.Y1[:4], rm.Y1[4:], rm.Z1[:4], rm.Z1[4:])):
+            A("global_store_dwordx4 %%[dst], %s, off offset:%d" % (quad(regs), 16 * k))
+        A("v_cndmask_b32_e64 %s, 0, 1, %s" % (rm.flag, S_EXC))
+        A("global_store_dword %%[t4], %s, %%[exc]" % rm.flag)
+        A("s_waitcnt vmcnt(0)")
+        return L, rm, dict(madd=len(Ea.order), madd_nops=Ea.nops, vgpr_end=rm.end)
+    return _with_globals(go)
+
+
 def canon(rm, a, out, tmp):
     """[0, 2q) -> [0, q): out = a - q unless that borrows"""
     c1, _ = _carries()
@@ -698,6 +791,16 @@ def emit_header(path):
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS + ["s56", "s57"]] + ['"v%d"' % i for i in range(trm.first, trm.end)]
     out.append("        : " + ", ".join(clob) + ");")
     out.append("}")
+    mlines, mrm, mst = emit_msm_acc()
+    out.append("// bucket accumulation of the variable-base MSM on the same mixed-addition body: %d asm lines, VGPRs v%d..v%d" % (len(mlines), mrm.first, mrm.end - 1))
+    out.append("__device__ __forceinline__ void g1_msm_acc_asm(u32 lo4, u32 len, u32 maxlen, const u32* vals, const u64* aff, u64* dst, u32 t4, u32* exc) {")
+    out.append("    asm volatile(")
+    out.append(G.c_string(mlines))
+    out.append("        :")
+    out.append('        : [lo4] "v"(lo4), [len] "v"(len), [maxlen] "s"(maxlen), [vals] "s"(vals), [aff] "s"(aff), [dst] "v"(dst), [t4] "v"(t4), [exc] "s"(exc)')
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mrm.first, mrm.end)]
+    out.append("        : " + ", ".join(clob) + ");")
+    out.append("}")
     # multiplier instructions (v_mad_u64_u32 + v_mul_lo_u32) one scalar-mul executes in the two asm kernels
     def mults(seq_fn, *a):
         def go():
@@ -720,7 +823,7 @@ def emit_header(path):
         json.dump({"mult_instrs_loop": loop_m, "mult_instrs_table": table_m, "mult_instrs_per_montmul": m_mul, "mult_instrs_per_montsqr": m_sqr,
                    "doublings": n_dbl, "mixed_additions": N_STEPS, "beta_products": N_STEPS // 2,
                    "double_body_instrs": st["double"], "madd_body_instrs": st["madd"]}, f, indent=1)
-    return st, len(lines) + len(tlines)
+    return st, len(lines) + len(tlines) + len(mlines)
 
 
 def load_beta():
