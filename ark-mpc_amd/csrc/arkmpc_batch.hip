@@ -55,6 +55,7 @@ int arkmpc_batch_create(arkmpc_ctx* ctx, int kind, int layout, size_t n, arkmpc_
     if (layout != ARKMPC_LAYOUT_AOS && !(layout == ARKMPC_LAYOUT_SPLIT && kind == ARKMPC_KIND_SCALAR_SHARE))
         return ark_bad(ctx, "split layout is defined for ScalarShare batches only");
     const u32 w = elem_words(kind, ctx->field_id);
+    if (n > (((size_t)1 << 48) / w)) return ark_bad(ctx, "batch too large");     // far above any HBM size; keeps n * w * 8 from wrapping
     void* p = nullptr;
     int rc = arkmpc_malloc(ctx, (n ? n : 1) * (size_t)w * 8 + 16, &p);
     if (rc) return rc;
@@ -216,7 +217,7 @@ int arkmpc_event_record(arkmpc_ctx* ctx, arkmpc_event** out) {
     hipEvent_t ev;
     ARK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipError_t e = hipEventRecord(ev, ctx->stream);
-    if (e != hipSuccess) { (void)hipEventDestroy(ev); ctx->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    if (e != hipSuccess) { (void)hipEventDestroy(ev); ark_set_err(ctx, std::string("hipEventRecord: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
     *out = new arkmpc_event{ev, ctx->device};
     return ARKMPC_OK;
 }

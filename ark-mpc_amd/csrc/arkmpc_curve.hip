@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(TPB_EC) k_commit_points(size_t n, const u64* p
     if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
     CtxGuard guard__(ctx);                                                                      \
     if (guard__.rc) return guard__.rc;                                                          \
-    if ((ctx)->field_id != ARKMPC_BN254_FR) { (ctx)->err = "point ops need a BN254_FR context"; return ARKMPC_ERR_UNSUPPORTED; }
+    if ((ctx)->field_id != ARKMPC_BN254_FR) { ark_set_err((ctx), "point ops need a BN254_FR context"); return ARKMPC_ERR_UNSUPPORTED; }
 
 static inline bool party_ok(int p) { return p == 0 || p == 1; }
 static const size_t EC_CHUNK = (size_t)1 << 20;     // scalar-muls per launch: bounds the window-table workspace at 1.4 GiB

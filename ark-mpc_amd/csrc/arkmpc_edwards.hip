@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_mac_check_kp(size_t n, const u64*
     if (!(ctx)) return ARKMPC_ERR_BAD_ARG;                                                      \
     CtxGuard guard__(ctx);                                                                      \
     if (guard__.rc) return guard__.rc;                                                          \
-    if ((ctx)->field_id != ARKMPC_CURVE25519_FR) { (ctx)->err = "Curve25519 point ops need a CURVE25519_FR context"; return ARKMPC_ERR_UNSUPPORTED; }
+    if ((ctx)->field_id != ARKMPC_CURVE25519_FR) { ark_set_err((ctx), "Curve25519 point ops need a CURVE25519_FR context"); return ARKMPC_ERR_UNSUPPORTED; }
 
 extern "C" {
 

@@ -17,6 +17,9 @@ struct arkmpc_ctx {
     bool own_stream = false;
     bool host_buffers = false;
     std::mutex mu;
+    // last error text: written through ark_set_err only (its own lock: some entry points -- the batch carrier, the argument checks
+    // before a CtxGuard -- report errors without holding `mu`, and arkmpc_last_error may run on another thread)
+    std::mutex err_mu;
     std::string err;
     // device scratch arena for host-buffer staging and internal temporaries
     char* arena = nullptr;
@@ -41,17 +44,24 @@ struct arkmpc_ctx {
     int timer_slot = -1;
 };
 
+struct arkmpc_ctx;
+static inline void ark_set_err(arkmpc_ctx* ctx, const std::string& what);
 #define ARK_HIP(ctx, call)                                                                      \
     do {                                                                                        \
         hipError_t e__ = (call);                                                                \
         if (e__ != hipSuccess) {                                                                \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            ark_set_err((ctx), std::string(#call) + ": " + hipGetErrorString(e__));             \
             return ARKMPC_ERR_HIP;                                                              \
         }                                                                                       \
     } while (0)
 
+static inline void ark_set_err(arkmpc_ctx* ctx, const std::string& what) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    ctx->err = what;
+}
 static inline int ark_bad(arkmpc_ctx* ctx, const char* what) {
-    if (ctx) ctx->err = what;
+    ark_set_err(ctx, what);
     return ARKMPC_ERR_BAD_ARG;
 }
 
@@ -62,7 +72,7 @@ struct CtxGuard {
     int rc = ARKMPC_OK;
     explicit CtxGuard(arkmpc_ctx* ctx) : c(ctx), lk(ctx->mu) {
         hipError_t e = hipSetDevice(ctx->device);
-        if (e != hipSuccess) { ctx->err = std::string("hipSetDevice: ") + hipGetErrorString(e); rc = ARKMPC_ERR_HIP; }
+        if (e != hipSuccess) { ark_set_err(ctx, std::string("hipSetDevice: ") + hipGetErrorString(e)); rc = ARKMPC_ERR_HIP; }
     }
 };
 
@@ -130,7 +140,7 @@ struct Stage {
         for (auto& i : ins) {
             if (!i.bytes) continue;
             hipError_t e = hipMemcpyAsync(ctx->arena + i.off, i.host, i.bytes, hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) { ctx->err = std::string("H2D: ") + hipGetErrorString(e); return rc = ARKMPC_ERR_HIP; }
+            if (e != hipSuccess) { ark_set_err(ctx, std::string("H2D: ") + hipGetErrorString(e)); return rc = ARKMPC_ERR_HIP; }
         }
         return ARKMPC_OK;
     }
@@ -144,15 +154,15 @@ struct Stage {
     int finish() {
         if (rc) return rc;
         hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { ctx->err = std::string("kernel launch: ") + hipGetErrorString(le); return ARKMPC_ERR_HIP; }
+        if (le != hipSuccess) { ark_set_err(ctx, std::string("kernel launch: ") + hipGetErrorString(le)); return ARKMPC_ERR_HIP; }
         if (!ctx->host_buffers) return ARKMPC_OK;
         for (auto& o : oplan) {
             if (!o.bytes) continue;
             hipError_t e = hipMemcpyAsync(o.host, ctx->arena + o.off, o.bytes, hipMemcpyDeviceToHost, ctx->stream);
-            if (e != hipSuccess) { ctx->err = std::string("D2H: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+            if (e != hipSuccess) { ark_set_err(ctx, std::string("D2H: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { ctx->err = std::string("sync: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+        if (e != hipSuccess) { ark_set_err(ctx, std::string("sync: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
         return ARKMPC_OK;
     }
 };

@@ -614,12 +614,13 @@ int arkmpc_kernel_timer_ms(arkmpc_ctx* ctx, int slot, float* out_ms) {
     return ARKMPC_OK;
 }
 
-// The message is copied under the context lock into a per-thread buffer: a concurrent call on the same context may be
-// rewriting ctx->err (std::string reallocation) while this thread reads it.
+// The message is copied under the error-text lock into a per-thread buffer: a concurrent call on the same context may be
+// rewriting ctx->err (std::string reallocation) while this thread reads it.  (Not the context lock: asking for the last
+// error must not wait behind a long-running call of another thread.)
 const char* arkmpc_last_error(arkmpc_ctx* ctx) {
     if (!ctx) return "null context";
     static thread_local std::string snapshot;
-    { std::lock_guard<std::mutex> lk(ctx->mu); snapshot = ctx->err; }
+    { std::lock_guard<std::mutex> lk(ctx->err_mu); snapshot = ctx->err; }
     return snapshot.c_str();
 }
 
@@ -646,7 +647,7 @@ int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
             pool_release_all(p);
             e = hipMalloc(out_dptr, cls);
         }
-        if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+        if (e != hipSuccess) { ark_set_err(ctx, std::string("hipMalloc: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
     }
     p.live_[*out_dptr] = cls;
     return ARKMPC_OK;
@@ -902,7 +903,7 @@ int arkmpc_beaver_mask_v(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, siz
         (void)g; (void)t;
         DISPATCH_FIELD(ctx, launch_mask<F>(ctx, n, x, y, a, b, out_de));
         hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { ctx->err = hipGetErrorString(le); return ARKMPC_ERR_HIP; }
+        if (le != hipSuccess) { ark_set_err(ctx, hipGetErrorString(le)); return ARKMPC_ERR_HIP; }
     }
     return ARKMPC_OK;
 }
@@ -985,7 +986,7 @@ int arkmpc_beaver_finish_fused_v(arkmpc_ctx* ctx, size_t n, int party_id, const 
                                                    Col{b_share, (u32)b_stride}, Col{b_mac, (u32)b_stride}, Col{c_share, (u32)c_stride},
                                                    Col{c_mac, (u32)c_stride}, ColOut{out_share, (u32)out_stride}, ColOut{out_mac, (u32)out_stride}));
         hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { ctx->err = hipGetErrorString(le); return ARKMPC_ERR_HIP; }
+        if (le != hipSuccess) { ark_set_err(ctx, hipGetErrorString(le)); return ARKMPC_ERR_HIP; }
     }
     return ARKMPC_OK;
 }

@@ -315,7 +315,7 @@ int encode_impl(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const u
     int io = st.declare_out(out_frame, bound);
     size_t scan_bytes = 0;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const u64*)nullptr, (u64*)nullptr, n + 1, ctx->stream);
-    if (e != hipSuccess) { ctx->err = std::string("scan sizing: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    if (e != hipSuccess) { ark_set_err(ctx, std::string("scan sizing: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
     int il = st.declare_scratch((n + 1) * 8), iof = st.declare_scratch((n + 1) * 8), it = st.declare_scratch(scan_bytes + 64),
         ic = st.declare_scratch(n * 32 + 32);
     if (st.commit()) return st.rc;
@@ -325,7 +325,7 @@ int encode_impl(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const u
                                                          st.scratch<unsigned char>(ic)));
     hipLaunchKernelGGL(k_wire_lengths, dim3(blocks_for(n + 1, WIRE_TPB)), dim3(WIRE_TPB), 0, s, n, recs, st.scratch<u64>(il));
     e = hipcub::DeviceScan::ExclusiveSum(st.scratch<void>(it), scan_bytes, st.scratch<u64>(il), st.scratch<u64>(iof), n + 1, s);
-    if (e != hipSuccess) { ctx->err = std::string("scan: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    if (e != hipSuccess) { ark_set_err(ctx, std::string("scan: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
     hipLaunchKernelGGL(k_wire_render, dim3(n ? blocks_for(n, WIRE_TPB) : 1), dim3(WIRE_TPB), 0, s, n, recs, st.scratch<u64>(iof), hdr, st.out<unsigned char>(io));
     // the frame length is data dependent: read the scan total back
     u64* h_total = (u64*)ctx->h_flag;
@@ -462,7 +462,7 @@ static int decode_strict(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len
     const u32 nblocks = (u32)((v1 - v0 + WIRE_TPB - 1) / WIRE_TPB);
     size_t scan_bytes = 0;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const u32*)nullptr, (u32*)nullptr, nblocks + 1, ctx->stream);
-    if (e != hipSuccess) { ctx->err = std::string("scan sizing: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+    if (e != hipSuccess) { ark_set_err(ctx, std::string("scan sizing: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
     int ic = st.declare_scratch(((size_t)nblocks + 1) * 4), io = st.declare_scratch(((size_t)nblocks + 1) * 4), it = st.declare_scratch(scan_bytes + 64),
         ip = st.declare_scratch((max_n + 1) * 8), irc = st.declare_scratch(max_n * 32 + 32);
     if (st.commit()) return st.rc;
@@ -473,7 +473,7 @@ static int decode_strict(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len
     if (body_len) {
         hipLaunchKernelGGL(k_wire_count, dim3(nblocks), dim3(WIRE_TPB), 0, s, fr, v0, lo, hi, st.scratch<u32>(ic), nblocks);
         e = hipcub::DeviceScan::ExclusiveSum(st.scratch<void>(it), scan_bytes, st.scratch<u32>(ic), st.scratch<u32>(io), nblocks + 1, s);
-        if (e != hipSuccess) { ctx->err = std::string("scan: ") + hipGetErrorString(e); return ARKMPC_ERR_HIP; }
+        if (e != hipSuccess) { ark_set_err(ctx, std::string("scan: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
         ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag, st.scratch<u32>(io) + nblocks, 4, hipMemcpyDeviceToHost, s));
         ARK_HIP(ctx, hipStreamSynchronize(s));
         n = (size_t)*(u32*)ctx->h_flag;

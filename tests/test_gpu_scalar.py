@@ -467,3 +467,36 @@ def test_event_orders_one_contexts_stream_after_anothers(pkg):
     with pytest.raises(pkg.ArkMpcError):
         B.event_wait(None)
     A.close(); B.close()
+
+
+def test_error_text_is_safe_under_concurrent_failures(pkg):
+    """arkmpc_last_error returns a per-thread copy taken under the error-text lock: threads that keep failing (argument errors from the
+    batch carrier, which reports without the context lock, and from a guarded entry point) while others read the text must never crash
+    or see a torn string."""
+    import ctypes
+    import threading
+    eng = pkg.Engine(0, device=0)
+    lib, h = eng.lib, eng.h
+    seen, errs = set(), []
+    stop = threading.Event()
+
+    def fail_carrier():
+        out = ctypes.c_void_p()
+        while not stop.is_set():
+            if lib.arkmpc_batch_create(h, 99, 0, ctypes.c_size_t(4), ctypes.byref(out)) == 0: errs.append("carrier accepted kind 99")
+
+    def fail_guarded():
+        while not stop.is_set():
+            if lib.arkmpc_kernel_timer_arm(h, ctypes.c_int(-5)) == 0: errs.append("timer accepted slot -5")
+
+    def read():
+        for _ in range(20000):
+            msg = lib.arkmpc_last_error(h)
+            seen.add(msg.decode() if msg else "")
+
+    ts = [threading.Thread(target=f) for f in (fail_carrier, fail_guarded, read, read)]
+    for t in ts: t.start()
+    ts[2].join(); ts[3].join(); stop.set(); ts[0].join(); ts[1].join()
+    assert not errs
+    assert seen <= {"", "element kind not defined for this context", "timer slot out of range"}, seen
+    eng.close()
