@@ -143,11 +143,8 @@ __device__ __forceinline__ void ed_store_cached(u64* p, const Ed& a) {
     fe_store(p + 8, EQ_MUL(a.t, ed_const(ED_D2_MONT)));
     fe_store(p + 12, fe_dbl<EQ>(a.z));
 }
-__global__ void __launch_bounds__(TPB_ED) k_ed_smul_prep(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride, u32 s_div,
-                                                          EdAsmWs ws) {
-    const u32 i = blockIdx.x * TPB_ED + threadIdx.x;
-    if (i >= n) return;
-    const Ed p = points ? ed_load(points + (size_t)p_stride * (i / p_div)) : ed_generator();
+// signed 5-bit digit records of the canonical scalar, MSB window first (what both prep forms share)
+__device__ __forceinline__ void ed_smul_digits(u32 i, u32 n, const u64* scalars, u32 s_stride, u32 s_div, u32* dig) {
     const Fe s = fe_to_canonical<ER>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
     u32 carry = 0;
     for (int j = 0; j < ED_ASM_WINDOWS; ++j) {                 // LSB first; step index = windows - 1 - j (the loop runs MSB first)
@@ -159,8 +156,28 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_smul_prep(u32 n, const u64* point
         if (sh > 27) v |= hi << (32 - sh);
         u32 d = (v & 31u) + carry, neg = 0;
         if (d > 16u) { d = 32u - d; neg = 1; carry = 1; } else carry = 0;
-        ws.dig[(size_t)(ED_ASM_WINDOWS - 1 - j) * n + i] = d | ((d ? neg : 0u) << 5);
+        dig[(size_t)(ED_ASM_WINDOWS - 1 - j) * n + i] = d | ((d ? neg : 0u) << 5);
     }
+}
+__global__ void __launch_bounds__(256) k_ed_smul_digits(u32 n, const u64* scalars, u32 s_stride, u32 s_div, u32* dig) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ed_smul_digits(i, n, scalars, s_stride, s_div, dig);
+}
+// the table in the loop's own arithmetic (ed_asm_kernels.inc, ed_smul_table_asm): the arkworks limbs are read as plain field elements --
+// the same projective point, see tools/gen_ed_asm.py
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_table(u32 n, const u64* points, u32 p_stride, u32 p_div, u64* tab) {
+    const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
+    if (i >= n) return;
+    ed_smul_table_asm(i, p_stride * 8u * (i / p_div), n, points, tab);
+}
+// compiled form of both (generator base, ARKMPC_ED_ASM_PREP=0)
+__global__ void __launch_bounds__(TPB_ED) k_ed_smul_prep(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride, u32 s_div,
+                                                          EdAsmWs ws) {
+    const u32 i = blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    const Ed p = points ? ed_load(points + (size_t)p_stride * (i / p_div)) : ed_generator();
+    ed_smul_digits(i, n, scalars, s_stride, s_div, ws.dig);
     ed_store_cached(ws.tab + ((size_t)0 * n + i) * 16, ed_identity());
     Ed acc = p;
     ed_store_cached(ws.tab + ((size_t)1 * n + i) * 16, acc);
@@ -517,7 +534,13 @@ static void ed_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_s
         const u64* pp = points ? points + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
         const u64* sp = scalars + (size_t)s_stride * (lo / s_div);
         const EdAsmWs ws = ed_asm_carve(wsbase, cnt);
-        hipLaunchKernelGGL(k_ed_smul_prep, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+        static const bool asm_prep = !(getenv("ARKMPC_ED_ASM_PREP") && getenv("ARKMPC_ED_ASM_PREP")[0] == '0');
+        if (asm_prep && pp && (size_t)p_stride * 8 * (cnt / p_div + 1) < ((size_t)1 << 32)) {
+            hipLaunchKernelGGL(k_ed_smul_digits, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, (u32)cnt, sp, s_stride, s_div, ws.dig);
+            hipLaunchKernelGGL(k_ed_smul_table, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, ws.tab);
+        } else {
+            hipLaunchKernelGGL(k_ed_smul_prep, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
+        }
         hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res);
         hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.res, out + 16 * lo);
     }

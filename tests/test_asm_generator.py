@@ -127,16 +127,18 @@ def test_ed_double_and_add_bodies_match_the_affine_edwards_law():
     """dbl-2008-hwcd (rearranged without negations) and add-2008-hwcd-3 with a cached operand, with and without the T output, on the
     emulator against the affine twisted-Edwards law in Python integers -- incl. the identity entry, P + P and P + (-P): the law is complete."""
     r = ed.selftest(trials=36, seed=20260930)
-    assert len(r[False][0].order) < 2300 and len(r[False][1].order) < 2300
+    assert len(r[False][0].order) < 1300 and len(r[False][1].order) < 1400          # plain products: about half of the Montgomery bodies
 
 
 def test_ed_value_range_at_its_edges():
-    """Every value the loop holds is below 2^255 + 19; multiplier outputs are below 2^255.  The folds are exercised at the edges of those
-    ranges (where the 257th bit and the top bit fire), not just on random operands."""
+    """Every value the loop holds is below 2^255 + 19 * 77 (a folded 512-bit product: 2^256 = 38, 2^255 = 19 mod q); sums and differences
+    come out below 2^255 + 57.  Plain products, squarings (doubled-operand rows, operand folded in place), additions and subtractions are
+    exercised at the edges of that range -- where the ninth limb, the 257th bit and the top bit fire -- not just on random operands."""
     import random
     rng = random.Random(9)
-    Q, R, LIM, B = ed.Q, ed.R, ed.LIM, ed.B255
-    Rinv = pow(R, -1, Q)
+    Q, LIM, B = ed.Q, ed.LIM, ed.B255
+    assert LIM == B + 19 * 77 and 2 * Q > LIM
+    assert ed.selftest_field(trials=120, seed=77)
 
     def run(seq_fn, vals, out):
         def go():
@@ -150,15 +152,49 @@ def test_ed_value_range_at_its_edges():
         return ed._with_globals(go)
 
     edge = [0, 1, 18, 19, Q - 1, Q, Q + 1, B - 1, B, B + 18, LIM - 1]
-    for t in range(80):
-        a = rng.choice(edge) if t < 40 else rng.randrange(LIM)
+    for t in range(60):
+        a = rng.choice(edge) if t < 30 else rng.randrange(LIM)
         b = rng.choice(edge) if t % 2 == 0 else rng.randrange(LIM)
-        m = run(lambda rm: ed.montmul(rm, rm.X1, rm.Y1, rm.Z1), lambda rm: ((rm.X1, a), (rm.Y1, b)), lambda rm: rm.Z1)
-        assert m < B and m % Q == a * b * Rinv % Q
+        m = run(lambda rm: ed.pmul(rm, rm.X1, rm.Y1, rm.Z1), lambda rm: ((rm.X1, a), (rm.Y1, b)), lambda rm: rm.Z1)
+        assert m < LIM and m % Q == a * b % Q                       # no Montgomery factor: the plain product
+        q2 = run(lambda rm: ed.psqr(rm, rm.X1, rm.Z1), lambda rm: ((rm.X1, a),), lambda rm: rm.Z1)
+        assert q2 < LIM and q2 % Q == a * a % Q
         s_ = run(lambda rm: ed.add_lz(rm, rm.X1, rm.Y1, rm.Z1, rm.A), lambda rm: ((rm.X1, a), (rm.Y1, b)), lambda rm: rm.Z1)
-        assert s_ < LIM and (s_ - (a + b)) % Q == 0
+        assert s_ < B + 58 and (s_ - (a + b)) % Q == 0
         d = run(lambda rm: ed.sub_lz(rm, rm.X1, rm.Y1, rm.Z1, rm.A), lambda rm: ((rm.X1, a), (rm.Y1, b)), lambda rm: rm.Z1)
-        assert d < LIM and (d - (a - b)) % Q == 0
+        assert d < B + 58 and (d - (a - b)) % Q == 0
+
+
+def test_ed_projective_scaling_makes_montgomery_inputs_plain():
+    """Why the loop needs no domain conversion: extended coordinates scaled by any non-zero factor are the same point, so the Montgomery-form
+    limbs (X R, Y R, Z R, T R) read as plain elements -- and cached entries built from them -- give the right point through the plain-product
+    bodies, and the plain result is again a valid representative.  One doubling + one addition on the emulator, inputs scaled by R."""
+    import random
+    rng = random.Random(31)
+    Q, R = ed.Q, ed.R
+
+    def go():
+        rm = ed.RegMap()
+        Ed_ = ed.Emitter(); Ed_.schedule(ed.seq_double(rm, True))
+        Ea_ = ed.Emitter(); Ea_.schedule(ed.seq_add(rm, True))
+        for _ in range(6):
+            P = ed.ed_mul_aff(ed.ED_B, rng.randrange(1, ed.L_ORD)); P2 = ed.ed_mul_aff(ed.ED_B, rng.randrange(1, ed.L_ORD))
+            z, z2 = rng.randrange(1, Q), rng.randrange(1, Q)
+            X, Y, Z, T = (P[0] * z % Q, P[1] * z % Q, z, P[0] * P[1] * z % Q)
+            X2, Y2, Z2, T2 = (P2[0] * z2 % Q, P2[1] * z2 % Q, z2, P2[0] * P2[1] * z2 % Q)
+            em = ed._emu(rm)
+            for regs, v in ((rm.X1, X), (rm.Y1, Y), (rm.Z1, Z), (rm.T1, T)):
+                em.setv(regs, v * R % Q)                                                   # arkworks limbs, read as plain elements
+            em.run(Ed_.order)
+            cached = ((Y2 + X2) * R % Q, (Y2 - X2) * R % Q, 2 * ed.D_ED * T2 * R % Q, 2 * Z2 * R % Q)   # what k_ed_smul_prep stores (Montgomery form)
+            for regs, v in zip((rm.QP, rm.QM, rm.QT, rm.QZ), cached):
+                em.setv(regs, v)
+            em.run(Ea_.order)
+            gx, gy, gz, gt = (em.getv(r_) % Q for r_ in (rm.X1, rm.Y1, rm.Z1, rm.T1))
+            zi = pow(gz, -1, Q)
+            want = ed.ed_add_aff(ed.ed_add_aff(P, P), P2)
+            assert (gx * zi % Q, gy * zi % Q) == want and gt * gz % Q == gx * gy % Q
+    ed._with_globals(go)
 
 
 def test_committed_ed_header_is_current(tmp_path):
