@@ -67,7 +67,8 @@ int main(int argc, char** argv) {
                     continue;
                 } else if (bench == "point_batch_mul") {
                     // BASELINE config 4, secondary op: AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714),
-                    // [x * yG] by a Beaver triple: 10 scalar-muls + 8 additions per element and party; timed without the sharing
+                    // [x * yG] by a Beaver triple: the reference's 10 scalar-muls per element and party regrouped to 6 (fabric.hpp batch_mul;
+                    // ARKMPC_POINT_MUL_LITERAL=1 runs the literal sequence); timed without the sharing
                     auto x = fabric->batch_share_scalar(a_m, n, PARTY0);
                     auto y = fabric->batch_share_scalar(b_m, n, PARTY1);
                     auto Y = AuthenticatedPointBatch::batch_mul_generator(y);

@@ -266,6 +266,75 @@ class PartyIDBeaverSource : public PreprocessingPhase {
     Scalar s_[7];
 };
 
+// A trusted-dealer source for tests and benches with NON-degenerate material (the dummy source above has MAC key shares 0 / 1 and
+// constant triples, so party 0's MACs are all zero): both parties construct it with the same seed, derive the same random values
+// in the same order -- MAC key shares, triples c = a * b, masks, bits, inverse pairs -- with random additive splits of every value
+// and of mac_key * value, and each keeps its own halves.  What PreprocessingPhase promises (offline_prep.rs:12-82) and nothing more;
+// the arithmetic runs on the engine's host-pointer context.
+class DealerBeaverSource : public PreprocessingPhase {
+  public:
+    DealerBeaverSource(PartyId party, const Engine& e, uint64_t seed) : party_(party), e_(e), state_(seed ^ 0xD1B54A32D192ED03ull) {
+        std::vector<Scalar> k = random(2);
+        key_share_[0] = k[0]; key_share_[1] = k[1];
+        key_ = add(std::vector<Scalar>{k[0]}, std::vector<Scalar>{k[1]})[0];
+    }
+    Scalar get_mac_key_share() override { return key_share_[party_]; }
+    std::pair<std::vector<Scalar>, std::vector<ScalarShare>> next_local_input_mask_batch(size_t n) override {
+        std::vector<Scalar> v = random(n);
+        return {v, split(v)};
+    }
+    std::vector<ScalarShare> next_counterparty_input_mask_batch(size_t n) override { return split(random(n)); }
+    void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) override {
+        std::vector<Scalar> va = random(n), vb = random(n);
+        a = split(va); b = split(vb); c = split(mul(va, vb));
+    }
+    std::vector<ScalarShare> next_shared_bit_batch(size_t n) override {
+        std::vector<Scalar> bits(n);
+        for (size_t i = 0; i < n; ++i) bits[i] = Scalar{{next() & 1u, 0, 0, 0}};
+        return split(e_.from_canonical(bits));
+    }
+    std::vector<ScalarShare> next_shared_value_batch(size_t n) override { return split(random(n)); }
+    void next_shared_inverse_pair_batch(size_t n, std::vector<ScalarShare>& l, std::vector<ScalarShare>& r) override {
+        std::vector<Scalar> v = random(n), inv(n);                    // a random element is zero with probability ~2^-252
+        if (n) check(e_.host(), arkmpc_scalar_batch_inverse(e_.host(), n, &v[0].l[0], &inv[0].l[0]), "batch_inverse");
+        l = split(v); r = split(inv);
+    }
+
+  private:
+    uint64_t next() {                                                 // splitmix64
+        uint64_t z = (state_ += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    std::vector<Scalar> random(size_t n) {                            // uniform below 2^252 (< every modulus of the engine), Montgomery form
+        std::vector<Scalar> c(n);
+        for (size_t i = 0; i < n; ++i) c[i] = Scalar{{next(), next(), next(), next() >> 12}};
+        return e_.from_canonical(c);
+    }
+    typedef int (*BinOp)(arkmpc_ctx*, size_t, const uint64_t*, const uint64_t*, uint64_t*);
+    std::vector<Scalar> bin(BinOp f, const std::vector<Scalar>& a, const std::vector<Scalar>& b) const {
+        std::vector<Scalar> o(a.size());
+        if (!a.empty()) check(e_.host(), f(e_.host(), a.size(), &a[0].l[0], &b[0].l[0], &o[0].l[0]), "dealer arithmetic");
+        return o;
+    }
+    std::vector<Scalar> add(const std::vector<Scalar>& a, const std::vector<Scalar>& b) const { return bin(arkmpc_scalar_add, a, b); }
+    std::vector<Scalar> mul(const std::vector<Scalar>& a, const std::vector<Scalar>& b) const { return bin(arkmpc_scalar_mul, a, b); }
+    // this party's (share, mac) halves of additive splits of v and of mac_key * v
+    std::vector<ScalarShare> split(const std::vector<Scalar>& v) {
+        const size_t n = v.size();
+        std::vector<Scalar> r = random(n), t = random(n), macs = mul(std::vector<Scalar>(n, key_), v);
+        std::vector<ScalarShare> out(n);
+        if (party_ == 0) { for (size_t i = 0; i < n; ++i) out[i] = ScalarShare{r[i], t[i]}; return out; }
+        std::vector<Scalar> s1 = bin(arkmpc_scalar_sub, v, r), m1 = bin(arkmpc_scalar_sub, macs, t);
+        for (size_t i = 0; i < n; ++i) out[i] = ScalarShare{s1[i], m1[i]};
+        return out;
+    }
+    PartyId party_;
+    const Engine& e_;
+    uint64_t state_;
+    Scalar key_share_[2], key_;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Curve traits: the reference is generic over `C: CurveGroup` (authenticated_curve.rs, curve.rs); the C ABI has one set of
 // entry points per curve.  A traits struct binds the point-side API of the mirror to one of them.
@@ -780,18 +849,37 @@ template <class Cv> class AuthenticatedPointBatchT {
         return res;
     }
     // ---- Beaver point x shared-scalar multiplication (:682-714): [x * yG] = deG + d[bG] + [a]eG + [c]G ----
-    static Self batch_mul(const AuthenticatedScalarBatch& a, const Self& b) {
+    // The reference evaluates the four terms as written: 6 variable-base and 4 generator scalar-muls per element and party
+    // (deG: 1, d[bG]: 2, [a]eG: 2, mac_key * deG inside add_public: 1; [b]G and [c]G: 2 + 2).  Every term is a multiple of either the
+    // opened point eG or of G, and [bG] = [b]G, so by distributivity -- exact in the group, share by share and MAC by MAC --
+    //     deG + d[bG] + [a]eG + [c]G  =  ([a] + d) * eG  +  ([c] + d[b]) * G
+    // where "[a] + d" is ScalarShare::add_public (share += d iff PARTY0, mac += mac_key * d: what add_public(dbG, deG) does to the points,
+    // share.rs:74-77 / curve/share.rs:57-60).  That is 2 variable-base + 4 generator scalar-muls (the generator ones on the fixed-base
+    // table): the form this engine runs.  `literal` = the reference's op sequence, kept for the parity test (both must open to the same
+    // points and pass the same MAC check; mock_mpc scenario point_mul_forms).
+    static Self batch_mul(const AuthenticatedScalarBatch& a, const Self& b, bool literal = point_mul_literal()) {
+        same(a.n, b.n);
+        if (a.n == 0) return alloc(a.fabric, 0);
+        AuthenticatedScalarBatch ta, tb, tc;
+        a.fabric->next_triple_batch(a.n, ta, tb, tc);
+        return batch_mul_with_triple(a, b, ta, tb, tc, literal);
+    }
+    // the gate itself, on a triple the caller has drawn (the parity test evaluates both forms on ONE triple)
+    static Self batch_mul_with_triple(const AuthenticatedScalarBatch& a, const Self& b, const AuthenticatedScalarBatch& ta,
+                                      const AuthenticatedScalarBatch& tb, const AuthenticatedScalarBatch& tc, bool literal) {
         same(a.n, b.n);
         const size_t n = a.n;
         auto f = a.fabric;
-        if (n == 0) return alloc(f, 0);
-        AuthenticatedScalarBatch ta, tb, tc;
-        f->next_triple_batch(n, ta, tb, tc);
         Self beaver_b_gen = batch_mul_generator(tb);                                               // :696
         AuthenticatedScalarBatch masked_rhs = AuthenticatedScalarBatch::batch_sub(a, ta);          // :698
         Self masked_lhs = batch_sub(b, beaver_b_gen);                                              // :699
         PointBatch eG_open = masked_lhs.open_batch();                                              // :701
         ScalarBatch d_open = masked_rhs.open_batch();                                              // :702
+        if (!literal) {
+            AuthenticatedScalarBatch on_eG = AuthenticatedScalarBatch::batch_add_public(ta, d_open);                       // [a] + d
+            AuthenticatedScalarBatch on_G = AuthenticatedScalarBatch::batch_add(tc, AuthenticatedScalarBatch::batch_mul_public(tb, d_open));   // [c] + d[b]
+            return batch_add(batch_mul_authenticated(on_eG, eG_open), batch_mul_generator(on_G));
+        }
         PointBatch deG = point_batch_mul(f, d_open, eG_open);                                      // :705
         Self dbG = batch_mul_public(d_open, beaver_b_gen);                                         // :706
         Self aeG = batch_mul_authenticated(ta, eG_open);                                           // :707
@@ -799,6 +887,10 @@ template <class Cv> class AuthenticatedPointBatchT {
         Self de_db_G = batch_add_public(dbG, deG);                                                 // :710
         Self ae_c_G = batch_add(aeG, cG);                                                          // :711
         return batch_add(de_db_G, ae_c_G);                                                         // :713
+    }
+    static bool point_mul_literal() {
+        static const bool v = std::getenv("ARKMPC_POINT_MUL_LITERAL") && std::getenv("ARKMPC_POINT_MUL_LITERAL")[0] == '1';
+        return v;
     }
 
     // ---- multiscalar multiplication (:787-806): batch_mul, then one gate summing the PointShares ----

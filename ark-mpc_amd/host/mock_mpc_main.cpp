@@ -36,6 +36,7 @@ static PartyOut point_scenario(std::shared_ptr<MpcFabric> fabric, const std::str
         return pg;
     };
     APB Z;
+    uint64_t forms_mismatch = 0;
     if (scenario == "share_point") {
         // batch_share_point (fabric.rs:622-649): party 0 shares P_i = [a_i]G; open_authenticated must return P_i
         std::vector<uint64_t> pts = gen_mul(a_m).to_host();       // both parties can compute it here; only the sender's copy is used
@@ -53,6 +54,20 @@ static PartyOut point_scenario(std::shared_ptr<MpcFabric> fabric, const std::str
         auto y = fabric->batch_share_scalar(b_m, n, PARTY1);
         auto Y = APB::batch_mul_generator(y);
         if (scenario == "msm_public_points") Z = APB::msm_authenticated(x, gen_mul(b_m));     // curve.rs:618-642: bases [b_i]G public
+        else if (scenario == "point_mul_forms") {
+            // the regrouped form the engine runs, ([a] + d) eG + ([c] + d[b]) G, against the reference's literal op sequence
+            // (authenticated_curve.rs:696-713): EVERY local share and MAC point must be the same group element
+            AuthenticatedScalarBatch ta, tb, tc;
+            fabric->next_triple_batch(n, ta, tb, tc);                 // ONE triple for both forms: with it, the local shares must coincide
+            Z = APB::batch_mul_with_triple(x, Y, ta, tb, tc, false);
+            APB Zl = APB::batch_mul_with_triple(x, Y, ta, tb, tc, true);
+            std::vector<uint8_t> b1(64 * n + 8), b2(64 * n + 8);
+            DeviceBuf d1(fabric->engine(), 8 * n + 1), d2(fabric->engine(), 8 * n + 1);
+            check(fabric->ctx(), Cv::to_bytes(fabric->ctx(), 2 * n, Z.buf.ptr(), reinterpret_cast<uint8_t*>(d1.ptr())), "to_bytes");
+            check(fabric->ctx(), Cv::to_bytes(fabric->ctx(), 2 * n, Zl.buf.ptr(), reinterpret_cast<uint8_t*>(d2.ptr())), "to_bytes");
+            d1.download(b1.data(), 64 * n); d2.download(b2.data(), 64 * n);
+            for (size_t i = 0; i < 2 * n; ++i) if (std::memcmp(&b1[32 * i], &b2[32 * i], 32) != 0) forms_mismatch += 1;
+        }
         else Z = (scenario == "msm") ? APB::msm(x, Y) : APB::batch_mul(x, Y);
     }
     const size_t zn = Z.n;    // msm collapses the batch to one point
@@ -66,6 +81,7 @@ static PartyOut point_scenario(std::shared_ptr<MpcFabric> fabric, const std::str
     auto o = Z.open_authenticated_batch(bl);
     PartyOut out;
     for (size_t i = 0; i < zn; ++i) if (!o.ok[i]) out.err += 1;          // number of failed MAC checks
+    out.err += 1000000 * forms_mismatch;                                 // point_mul_forms: local shares that differ between the two forms
     out.opened.resize(zn);
     if (zn) {
         DeviceBuf bytes(fabric->engine(), 4 * zn);
@@ -90,7 +106,13 @@ int main(int argc, char** argv) {
         if (!in) { std::fprintf(stderr, "short input file\n"); return 2; }
     }
     try {
-        auto make_prep = [](PartyId p, const Engine& e) { return std::unique_ptr<PreprocessingPhase>(new PartyIDBeaverSource(p, e)); };
+        // ARKMPC_MOCK_DEALER=<seed>: a trusted-dealer source with random MAC key shares and triples instead of the reference's constant dummy source
+        const char* dealer = std::getenv("ARKMPC_MOCK_DEALER");
+        const uint64_t dealer_seed = dealer ? std::strtoull(dealer, nullptr, 0) : 0;
+        auto make_prep = [&](PartyId p, const Engine& e) {
+            return dealer ? std::unique_ptr<PreprocessingPhase>(new DealerBeaverSource(p, e, dealer_seed))
+                          : std::unique_ptr<PreprocessingPhase>(new PartyIDBeaverSource(p, e));
+        };
         auto program = [&](std::shared_ptr<MpcFabric> fabric) -> PartyOut {
             const Engine& eng = *fabric->engine();
             std::vector<Scalar> a_m = eng.from_canonical(a_c), b_m = eng.from_canonical(b_c);
@@ -141,7 +163,7 @@ int main(int argc, char** argv) {
                 // fabric.rs:961-984 random_shared_bits over PreprocessingPhase::next_shared_bit_batch (offline_prep.rs:39-44): the
                 // dummy source's "bit" is the party id, so the authenticated open gives 0 + 1 = 1 for every element
                 res = fabric->random_shared_bits(n);
-            } else if (scenario == "share_point" || scenario == "point_mul" || scenario == "msm" || scenario == "msm_public_points" ||
+            } else if (scenario == "share_point" || scenario == "point_mul" || scenario == "point_mul_forms" || scenario == "msm" || scenario == "msm_public_points" ||
                        scenario == "point_sub_public") {
                 return field_id == ARKMPC_CURVE25519_FR ? point_scenario<AuthenticatedEdPointBatch>(fabric, scenario, n, a_m, b_m, bad_mac)
                                                         : point_scenario<AuthenticatedPointBatch>(fabric, scenario, n, a_m, b_m, bad_mac);

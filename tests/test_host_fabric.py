@@ -303,3 +303,75 @@ def test_short_peer_batch_is_a_network_error(tmp_path):
     inp.write_bytes(ints_to_limbs(a).tobytes() + ints_to_limbs(a).tobytes())
     rr = subprocess.run([EXE, "short_peer", "0", str(n), str(inp), str(outp)], capture_output=True, text=True, timeout=300)
     assert rr.returncode == 1 and "MpcNetworkError" in rr.stderr, rr.stderr
+
+
+@pytest.fixture
+def dealer_source():
+    """ARKMPC_MOCK_DEALER: the mirror's trusted-dealer source (random MAC key shares -- party 0's is 0 with the reference's dummy source --
+    random triples, masks, bits and inverse pairs, random additive splits)."""
+    os.environ["ARKMPC_MOCK_DEALER"] = "0x5EED0001"
+    yield
+    os.environ.pop("ARKMPC_MOCK_DEALER", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fid", [0, 1, 2])
+def test_scalar_protocols_with_random_preprocessing(tmp_path, dealer_source, fid):
+    """batch_mul, a small circuit, batch_inverse and the corrupted-MAC / corrupted-share detections again, with non-degenerate
+    preprocessing material: both parties' MAC key shares, every triple and every mask are random."""
+    n = 130
+    p = pyref.P[fid]
+    a, b = mixed_values(fid, n, 801 + fid), rand_values(fid, n, 811 + fid)
+    want = [(x * y) % p for x, y in zip(a, b)]
+    res = run(tmp_path, "batch_mul", fid, a, b)
+    assert res[0] == (0, want) and res[1] == (0, want)
+    res = run(tmp_path, "batch_mul", fid, a, b, "--bad-mac")
+    assert res[0][0] == 2 and res[1][0] == 2                    # AuthenticationError (out code 2) on BOTH parties
+    res = run(tmp_path, "batch_mul", fid, a, b, "--bad-share")
+    assert res[0][0] == 2 and res[1][0] == 2
+    nz = [v for v in a if v != 0]
+    res = run(tmp_path, "inverse", fid, nz, nz)
+    want = [pow(v, -1, p) for v in nz]
+    assert res[0] == (0, want) and res[1] == (0, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fid", [0, 2])
+@pytest.mark.parametrize("source", ["dummy", "dealer"])
+def test_point_beaver_mul_regrouped_equals_literal_sequence(tmp_path, fid, source):
+    """AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714): the mirror evaluates deG + d[bG] + [a]eG + [c]G regrouped as
+    ([a] + d) eG + ([c] + d[b]) G -- 2 variable-base + 4 generator scalar-muls instead of 6 + 4.  Scenario point_mul_forms runs both that
+    form and the reference's literal op sequence on the same shares and counts the LOCAL share / MAC points that differ (as group elements,
+    compared in the compressed encoding): none may, on either party, with the dummy source and with random preprocessing material; and
+    the result opens to (x*y) G with every MAC check passing."""
+    if source == "dealer":
+        os.environ["ARKMPC_MOCK_DEALER"] = "0x5EED0002"
+    try:
+        n = 24
+        l, comp = _curve(fid)
+        x, y = [0, 1, l - 1, 5] + rand_values(fid, n - 4, 171), [5, 7, 2, 0] + rand_values(fid, n - 4, 172)
+        want = b"".join(comp((u * v) % l) for u, v in zip(x, y))
+        for nfail, got in _run_points(tmp_path, "point_mul_forms", fid, x, y):
+            assert nfail == 0 and got == want                    # nfail carries 10^6 per differing local point + failed MAC checks
+    finally:
+        os.environ.pop("ARKMPC_MOCK_DEALER", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fid", [0, 2])
+def test_point_protocols_with_random_preprocessing(tmp_path, dealer_source, fid):
+    """point batch_mul + authenticated open, sub_public, share_point and msm with random preprocessing; one corrupted MAC point is
+    caught for exactly one element."""
+    n = 9
+    l, comp = _curve(fid)
+    x, y = [0, 1, l - 1] + rand_values(fid, n - 3, 181), [5, 7, 2] + rand_values(fid, n - 3, 182)
+    want = b"".join(comp((u * v) % l) for u, v in zip(x, y))
+    for flags, fails in (((), 0), (("--bad-mac",), 1)):
+        for nfail, got in _run_points(tmp_path, "point_mul", fid, x, y, *flags):
+            assert nfail == fails and got == want
+    want = b"".join(comp((u - v) % l) for u, v in zip(x, y))
+    for nfail, got in _run_points(tmp_path, "point_sub_public", fid, x, y):
+        assert nfail == 0 and got == want
+    want = comp(sum(u * v for u, v in zip(x, y)) % l)
+    for nfail, got in _run_points(tmp_path, "msm", fid, x, y):
+        assert nfail == 0 and got == want
