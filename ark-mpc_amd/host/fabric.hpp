@@ -894,13 +894,34 @@ template <class Cv> class AuthenticatedPointBatchT {
     }
 
     // ---- multiscalar multiplication (:787-806): batch_mul, then one gate summing the PointShares ----
-    static Self msm(const AuthenticatedScalarBatch& scalars, const Self& points) {
+    // With the regrouped batch_mul above, sum_i [x_i * Y_i] = sum_i ([a_i] + d_i) * eG_i + sum_i ([c_i] + d_i [b_i]) * G: the first sum is an
+    // authenticated MSM over the opened points (the bucket method on BN254, arkmpc_g1_msm_authenticated), the second a sum of generator
+    // multiples.  Same group elements, share by share; `literal` = batch_mul + sum as the reference writes it.
+    static Self msm(const AuthenticatedScalarBatch& scalars, const Self& points, bool literal = point_mul_literal()) {
         if (scalars.n != points.n) throw std::invalid_argument("multiscalar_mul requires equal length vectors");
         if (scalars.n == 0) throw std::invalid_argument("multiscalar_mul requires non-empty vectors");
-        Self prod = batch_mul(scalars, points);
-        Self r = alloc(points.fabric, 1);
-        check(c(points), Cv::share_sum(c(points), prod.n, prod.buf.ptr(), r.buf.ptr()), "pointshare_sum");
-        return r;
+        const size_t n = scalars.n;
+        auto f = scalars.fabric;
+        if (literal) {
+            Self prod = batch_mul(scalars, points, true);
+            Self r = alloc(f, 1);
+            check(c(points), Cv::share_sum(c(points), prod.n, prod.buf.ptr(), r.buf.ptr()), "pointshare_sum");
+            return r;
+        }
+        AuthenticatedScalarBatch ta, tb, tc;
+        f->next_triple_batch(n, ta, tb, tc);
+        Self beaver_b_gen = batch_mul_generator(tb);                                               // :696
+        AuthenticatedScalarBatch masked_rhs = AuthenticatedScalarBatch::batch_sub(scalars, ta);    // :698
+        Self masked_lhs = batch_sub(points, beaver_b_gen);                                         // :699
+        PointBatch eG_open = masked_lhs.open_batch();                                              // :701
+        ScalarBatch d_open = masked_rhs.open_batch();                                              // :702
+        AuthenticatedScalarBatch on_eG = AuthenticatedScalarBatch::batch_add_public(ta, d_open);
+        AuthenticatedScalarBatch on_G = AuthenticatedScalarBatch::batch_add(tc, AuthenticatedScalarBatch::batch_mul_public(tb, d_open));
+        Self over_eG = msm_authenticated(on_eG, eG_open);
+        Self gen = batch_mul_generator(on_G);
+        Self over_G = alloc(f, 1);
+        check(f->ctx(), Cv::share_sum(f->ctx(), n, gen.buf.ptr(), over_G.buf.ptr()), "pointshare_sum");
+        return batch_add(over_eG, over_G);
     }
     // CurvePoint::msm / CurvePointResult::msm_results (curve.rs:549-560, :588-603): public scalars x public points -> one point
     static PointBatch point_msm(const std::shared_ptr<MpcFabric>& f, const ScalarBatch& scalars, const PointBatch& points) {
