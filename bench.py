@@ -398,6 +398,7 @@ def leg_config4(eng):
     smuls = 2 * n / (ms * 1e-3)
     per_smul, st = ec_mult_instrs()
     return {"workload": "2^18 PointShare x Scalar over BN254 G1 = 2^19 scalar-muls (BASELINE.json configs[3])", "ms": ms,
+            "secondary_op": config4_secondary(),
             "scalar_muls_per_s": smuls, "bound": "integer ALU",
             "algorithm": "GLV + signed 5-bit windows; effective-affine window table (common Z), blinded accumulator, mixed additions, "
                          "squaring rows; digits / table / window loop / finish kernels, table + loop hand-scheduled (tools/gen_ec_asm.py)",
@@ -410,6 +411,28 @@ def leg_config4(eng):
                                "frac_of_mad_only_peak": smuls * FQ_MULS_PER_SMUL_R01 * MADS_PER_FQ_MUL / MAD_PEAK_PER_S,
                                "note": "round 1's work definition (2004 general multiplications per scalar-mul) at this round's speed"},
             "results_check": "affine coords == fixed-base [(s*k)]G on all 2^19 points: %s" % ("ok" if ok else "FAILED")}, ok
+
+
+def config4_secondary():
+    """BASELINE config 4's secondary op, AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714) at 2^18, through the C++ host
+    mirror (two parties in one process, dummy Beaver source, device link): the mirror's own bench binary, run as a subprocess."""
+    import subprocess
+    exe = os.path.join(ROOT, "ark-mpc_amd", "lib", "arkmpc_host_bench")
+    if not os.path.exists(exe):
+        return {"note": "arkmpc_host_bench not built"}
+    out = {}
+    for name, literal in (("regrouped", "0"), ("literal_sequence", "1")):
+        try:
+            r = subprocess.run([exe, "point_batch_mul", str(1 << 18), "2"], capture_output=True, text=True, timeout=120,
+                               env=dict(os.environ, ARKMPC_MOCK_LINK="device", ARKMPC_POINT_MUL_LITERAL=literal))
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out[name] = {"ms_both_parties": d["seconds"] * 1e3, "elements_per_s": d["elements_per_s"]}
+        except Exception as ex:      # noqa: BLE001
+            out[name] = {"error": repr(ex)[:200]}
+    out["what"] = ("[x * yG] by a Beaver triple for 2^18 elements, both parties on one GPU; regrouped = ([a]+d) eG + ([c]+d[b]) G, 2 variable-base + 4 generator "
+                   "scalar-muls per element and party (the form the engine's host mirror runs); literal_sequence = the reference's 6 + 4; "
+                   "equal share by share (tests/test_host_fabric.py::test_point_beaver_mul_regrouped_equals_literal_sequence)")
+    return out
 
 
 def leg_config5(pkg, dev):
