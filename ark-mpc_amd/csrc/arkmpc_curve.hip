@@ -473,20 +473,23 @@ __device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& in
 
 // ---------------------------------------------------------------------------------------------
 // Fixed-base multiplication by the generator (CurvePointResult / AuthenticatedPointResult::batch_mul_generator,
-// authenticated_curve.rs:754-780; 4 of the 10 scalar-muls of the Beaver point multiplication :696-708; input sharing of
+// authenticated_curve.rs:754-780; 4 of the scalar-muls of the Beaver point multiplication :696-708; input sharing of
 // points, fabric.rs:622-649).  The base never changes, so its multiples are tabulated once per device:
-// T[w][d-1] = d * 2^(8w) * G for the 32 byte positions w and d = 1..255, affine, 8160 x 64 B = 510 KiB (L2-resident).
-// [s]G is then 32 table lookups and at most 32 mixed additions -- no doublings: ~350 Fq multiplications instead of
-// ~2200 for the variable-base GLV path.
+// T[w][d-1] = d * 2^(12w) * G for the 22 window positions w and d = 1..2048, affine: 45 056 x 64 B = 2.75 MiB, which stays in
+// each XCD's 4 MiB L2.  [s]G is then 22 SIGNED 12-bit digits, 22 table lookups and at most 22 mixed additions -- no doublings
+// (round 1: 8-bit unsigned digits, 32 additions, 510 KiB).  The additions run on the hand-scheduled mixed-addition body of the
+// scalar-mul loop (g1_msm_acc_asm, the bucket fold of the MSM: the digit list of a lane IS a bucket run); a chain that meets
+// H = 0 only flags its lane and k_gen_mul_chain redoes it with the complete compiled addition.
 // ---------------------------------------------------------------------------------------------
-#define GEN_WINDOWS 32
-#define GEN_ENTRIES 255
-__global__ void __launch_bounds__(64) k_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(8w) G
+#define GEN_C 12
+#define GEN_WINDOWS 22                      // ceil(254 / 12); the top window holds 2 scalar bits + carry
+#define GEN_ENTRIES (1u << (GEN_C - 1))     // |digit| = 1 .. 2048
+__global__ void __launch_bounds__(64) k_gen_table_bases(u64* bases) {           // one thread: B_w = 2^(12w) G
     if (blockIdx.x | threadIdx.x) return;
     G1 b = g1_generator();
     for (int w = 0; w < GEN_WINDOWS; ++w) {
         g1_store(bases + 12 * w, b);
-        for (int k = 0; k < 8; ++k) b = g1_double(b);
+        for (int k = 0; k < GEN_C; ++k) b = g1_double(b);
     }
 }
 __global__ void __launch_bounds__(TPB_EC) k_gen_table_fill(const u64* bases, u64* table) {     // thread (w, d): d * B_w, normalised
@@ -495,34 +498,47 @@ __global__ void __launch_bounds__(TPB_EC) k_gen_table_fill(const u64* bases, u64
     const u32 w = t / GEN_ENTRIES, d = t % GEN_ENTRIES + 1;
     const G1 b = g1_load(bases + 12 * w);
     G1 acc = g1_identity();
-    for (int bit = 7; bit >= 0; --bit) {
+    for (int bit = GEN_C - 1; bit >= 0; --bit) {
         acc = g1_double(acc);
         if ((d >> bit) & 1u) acc = g1_add(acc, b);
     }
     Fe x, y; bool inf;
-    g1_to_affine(acc, x, y, inf);                        // never the identity: d * 2^(8w) < r
+    g1_to_affine(acc, x, y, inf);                        // never the identity: d * 2^(12w) < r
     fe_store(table + 8 * (size_t)t, x);
     fe_store(table + 8 * (size_t)t + 4, y);
 }
-__global__ void __launch_bounds__(TPB_EC) k_g1_generator_mul_fixed(size_t n, const u64* scalars, u32 s_stride, u32 s_div, const u64* table, u64* out) {
-    size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+// signed 12-bit digits of the canonical scalar as a compacted member list: vals[GEN_WINDOWS * i + j] = table index | sign << 31 for the
+// j-th NON-ZERO digit, lens[i] = how many there are
+__global__ void __launch_bounds__(256) k_gen_digits(size_t n, const u64* scalars, u32 s_stride, u32 s_div, u32* vals, u32* lens) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Fe s = fe_to_canonical<FR>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
-    G1 acc = g1_identity();
-#pragma unroll 1
-    for (int limb = 0; limb < 8; ++limb) {
-        u32 wv = 0;
+    u32 carry = 0, cnt = 0;
+    for (u32 w = 0; w < GEN_WINDOWS; ++w) {
+        const u32 bit = GEN_C * w, limb = bit >> 5, sh = bit & 31;
+        u32 lo = 0, hi = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wv = (limb == k) ? s.v[k] : wv;
-#pragma unroll 1
-        for (int by = 0; by < 4; ++by) {
-            const u32 d = (wv >> (8 * by)) & 255u;
-            if (__any(d != 0)) {
-                const u64* q = table + 8 * ((size_t)(4 * limb + by) * GEN_ENTRIES + (d ? d - 1 : 0));
-                const G1 sum = g1_madd(acc, fe_load(q), fe_load(q + 4));
-                acc = g1_select(d != 0, sum, acc);
-            }
-        }
+        for (int k = 0; k < 8; ++k) { lo = (limb == (u32)k) ? s.v[k] : lo; hi = (limb + 1 == (u32)k) ? s.v[k] : hi; }
+        const u64 both = ((u64)hi << 32) | lo;
+        u32 d = ((u32)(both >> sh) & ((1u << GEN_C) - 1u)) + carry, neg = 0;
+        if (d > GEN_ENTRIES) { d = (1u << GEN_C) - d; neg = 1; carry = 1; } else carry = 0;
+        if (d) vals[(size_t)GEN_WINDOWS * i + cnt++] = (w * GEN_ENTRIES + (d - 1)) | (neg << 31);
+    }
+    lens[i] = cnt;
+}
+// the chain with the complete compiled addition: every lane (only == nullptr), or the lanes the asm kernel flagged
+__global__ void __launch_bounds__(TPB_EC) k_gen_mul_chain(size_t n, const u32* vals, const u32* lens, const u64* table, u64* out, const u32* only) {
+    const size_t i = (size_t)blockIdx.x * TPB_EC + threadIdx.x;
+    if (i >= n) return;
+    if (only && !only[i]) return;
+    const u32 len = lens[i];
+    G1 acc = g1_identity();
+    for (u32 j = 0; j < len; ++j) {
+        const u32 v = vals[(size_t)GEN_WINDOWS * i + j];
+        const u64* q = table + 8 * (size_t)(v & 0x7fffffffu);
+        Fe y = fe_load(q + 4);
+        if (v >> 31) y = FQ_NEG(y);
+        acc = g1_madd(acc, fe_load(q), y);
     }
     g1_store(out + 12 * i, acc);
 }
@@ -576,6 +592,18 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* p
 // ---------------------------------------------------------------------------------------------
 #include "ec_asm_kernels.inc"
 #define TPB_LOOP 256
+// fixed-base chain on the hand-scheduled mixed-addition body (see the generator-table section above)
+__global__ void __launch_bounds__(TPB_LOOP) k_gen_mul_chain_asm(u32 n, const u32* vals, const u32* lens, const u64* table, u64* out, u32* exc) {
+    const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
+    const bool valid = i < n;
+    const u32 len = valid ? lens[i] : 0u;
+    u32 m = len;
+    for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)m, o); m = other > m ? other : m; }
+    const u32 maxlen = __builtin_amdgcn_readfirstlane(m);
+    if (!valid) return;
+    if (len == 0) { g1_store(out + 12 * (size_t)i, g1_identity()); exc[i] = 0; return; }     // zero scalar
+    g1_msm_acc_asm(i * (GEN_WINDOWS * 4u), len, maxlen, vals, table, out + 12 * (size_t)i, i * 4u, exc);
+}
 struct G1AsmWs {
     u64* jtab;      // [16][n] Jacobian multiples (scratch of prep; window table of the fallback in finish)
     u64* tab;       // [18][n] affine entries on the isomorphic curve, 64 B each
@@ -923,7 +951,7 @@ static int gen_table(arkmpc_ctx* ctx, const u64** out) {
     if (!g_gen_table[dev]) {
         u64 *bases = nullptr, *table = nullptr;
         ARK_HIP(ctx, hipMalloc((void**)&bases, GEN_WINDOWS * 96));
-        ARK_HIP(ctx, hipMalloc((void**)&table, (size_t)GEN_WINDOWS * GEN_ENTRIES * 64));
+        ARK_HIP(ctx, hipMalloc((void**)&table, (size_t)GEN_WINDOWS * GEN_ENTRIES * 64));       // 2.75 MiB
         hipLaunchKernelGGL(k_gen_table_bases, dim3(1), dim3(64), 0, ctx->stream, bases);
         hipLaunchKernelGGL(k_gen_table_fill, dim3(blocks_for(GEN_WINDOWS * GEN_ENTRIES, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, bases, table);
         ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1019,15 +1047,28 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
     static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
     // variable-base path: the hand-scheduled window loop (prep / loop / finish kernels) unless ARKMPC_EC_ASM=0
     const bool asm_loop = g1_asm_enabled();
-    int iw = -1;
+    int iw = -1, igv = -1, igl = -1, ige = -1;
     if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(g1_smul_ws_bytes(m)) : st.declare_scratch(chunk * 16 * 96);
+    else { igv = st.declare_scratch(chunk * GEN_WINDOWS * 4 + 64); igl = st.declare_scratch(chunk * 4 + 64); ige = st.declare_scratch(chunk * 4 + 64); }
     if (st.commit()) return st.rc;
     if (m && !points && fixed_base) {          // multiplication by the generator: tabulated multiples, no doublings
         const u64* table = nullptr;
         int rc = gen_table(ctx, &table);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_g1_generator_mul_fixed, dim3(blocks_for(m, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, m, st.in<u64>(is), s_stride, s_div, table,
-                           st.out<u64>(io));
+        static const bool fix = !(getenv("ARKMPC_EC_ASM_NOFIX") && getenv("ARKMPC_EC_ASM_NOFIX")[0] == '1');
+        for (size_t lo = 0; lo < m; lo += chunk) {
+            const size_t cnt = (m - lo < chunk) ? (m - lo) : chunk;
+            const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
+            u32 *vals = st.scratch<u32>(igv), *lens = st.scratch<u32>(igl), *exc = st.scratch<u32>(ige);
+            u64* o = st.out<u64>(io) + 12 * lo;
+            hipLaunchKernelGGL(k_gen_digits, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, cnt, sp, s_stride, s_div, vals, lens);
+            if (asm_loop) {
+                hipLaunchKernelGGL(k_gen_mul_chain_asm, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, vals, lens, table, o, exc);
+                if (fix) hipLaunchKernelGGL(k_gen_mul_chain, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, vals, lens, table, o, (const u32*)exc);
+            } else {
+                hipLaunchKernelGGL(k_gen_mul_chain, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, vals, lens, table, o, (const u32*)nullptr);
+            }
+        }
         return st.finish();
     }
     if (m && asm_loop) {
