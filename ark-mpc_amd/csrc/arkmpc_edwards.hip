@@ -492,6 +492,58 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_generator_mul_fixed(size_t n, con
     ed_store(out + 16 * i, acc);
 }
 
+// ---- the same multiplication on the plain-arithmetic asm body (ed_asm_kernels.inc, ed_gen_chain_asm): signed 11-bit digits, 23 window
+// positions, table T2[w][k] = Niels form (y+x, y-x, 2dxy) of k * 2^(11w) * B as PLAIN canonical field elements (k = 0 is the identity (1, 1, 0),
+// so a zero digit needs no predication; k = 1025 exists for the top window's carry): 23 x 1026 x 96 B = 2.2 MiB, L2-resident.
+__global__ void __launch_bounds__(64) k_ed_gen2_bases(u64* bases) {           // one thread: B_w = 2^(11w) B
+    if (blockIdx.x | threadIdx.x) return;
+    Ed b = ed_generator();
+    for (int w = 0; w < ED_GEN_ASM_WINDOWS; ++w) {
+        ed_store(bases + 16 * w, b);
+        for (int k = 0; k < ED_GEN_ASM_C; ++k) b = ed_double(b);
+    }
+}
+__global__ void __launch_bounds__(TPB_ED) k_ed_gen2_fill(const u64* bases, u64* table) {
+    const u32 t = blockIdx.x * TPB_ED + threadIdx.x;
+    if (t >= ED_GEN_ASM_WINDOWS * ED_GEN_ASM_ENTRIES) return;
+    const u32 w = t / ED_GEN_ASM_ENTRIES, d = t % ED_GEN_ASM_ENTRIES;
+    const Ed b = ed_load(bases + 16 * w);
+    Ed acc = ed_identity();
+    for (int bit = ED_GEN_ASM_C; bit >= 0; --bit) {
+        acc = ed_double(acc);
+        if ((d >> bit) & 1u) acc = ed_add(acc, b);
+    }
+    const Fe zi = fe_inv_fermat<EQ>(acc.z);
+    const Fe x = EQ_MUL(acc.x, zi), y = EQ_MUL(acc.y, zi);
+    // Montgomery form -> the canonical integer itself: the asm chain multiplies plain field elements
+    fe_store(table + 12 * (size_t)t, fe_to_canonical<EQ>(fe_add<EQ>(y, x)));
+    fe_store(table + 12 * (size_t)t + 4, fe_to_canonical<EQ>(fe_sub<EQ>(y, x)));
+    fe_store(table + 12 * (size_t)t + 8, fe_to_canonical<EQ>(EQ_MUL(EQ_MUL(x, y), ed_const(ED_D2_MONT))));
+}
+// records [w][n]: table entry index | sign << 31, signed 11-bit digits LSB window first (the chain has no doublings: any order works)
+__global__ void __launch_bounds__(256) k_ed_gen_digits(u32 n, const u64* scalars, u32 s_stride, u32 s_div, u32* dig) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Fe s = fe_to_canonical<ER>(fe_load(scalars + (size_t)s_stride * (i / s_div)));
+    u32 carry = 0;
+    for (u32 w = 0; w < ED_GEN_ASM_WINDOWS; ++w) {
+        const u32 bit = ED_GEN_ASM_C * w, limb = bit >> 5, sh = bit & 31;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lo = (limb == (u32)k) ? s.v[k] : lo; hi = (limb + 1 == (u32)k) ? s.v[k] : hi; }
+        const u64 both = ((u64)hi << 32) | lo;
+        u32 d = ((u32)(both >> sh) & ((1u << ED_GEN_ASM_C) - 1u)) + carry, neg = 0;
+        // the top window is never recoded: the scalar is below the group order, so its top digit is at most 1024 + carry = 1025
+        if (d > (1u << (ED_GEN_ASM_C - 1)) && w + 1 < ED_GEN_ASM_WINDOWS) { d = (1u << ED_GEN_ASM_C) - d; neg = 1; carry = 1; } else carry = 0;
+        dig[(size_t)w * n + i] = (w * ED_GEN_ASM_ENTRIES + d) | ((d ? neg : 0u) << 31);
+    }
+}
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_gen_chain(u32 n, const u32* dig, const u64* table, u64* res) {
+    const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
+    if (i >= n) return;
+    ed_gen_chain_asm(i, n, dig, table, res);
+}
+static u64* g_ed_gen2_table[16] = {nullptr};
 static std::mutex g_ed_gen_mu;
 static u64* g_ed_gen_table[16] = {nullptr};
 static int ed_gen_table(arkmpc_ctx* ctx, const u64** out) {
@@ -507,6 +559,14 @@ static int ed_gen_table(arkmpc_ctx* ctx, const u64** out) {
         ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ARK_HIP(ctx, hipFree(bases));
         g_ed_gen_table[dev] = table;
+        u64* t2 = nullptr;
+        ARK_HIP(ctx, hipMalloc((void**)&bases, ED_GEN_ASM_WINDOWS * 128));
+        ARK_HIP(ctx, hipMalloc((void**)&t2, (size_t)ED_GEN_ASM_WINDOWS * ED_GEN_ASM_ENTRIES * 96));
+        hipLaunchKernelGGL(k_ed_gen2_bases, dim3(1), dim3(64), 0, ctx->stream, bases);
+        hipLaunchKernelGGL(k_ed_gen2_fill, dim3(blocks_for(ED_GEN_ASM_WINDOWS * ED_GEN_ASM_ENTRIES, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, bases, t2);
+        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ARK_HIP(ctx, hipFree(bases));
+        g_ed_gen2_table[dev] = t2;
     }
     *out = g_ed_gen_table[dev];
     return ARKMPC_OK;
@@ -613,13 +673,25 @@ static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_
     const size_t chunk = m < CH ? m : CH;
     static const bool fixed_base = !(getenv("ARKMPC_NO_FIXED_BASE") && getenv("ARKMPC_NO_FIXED_BASE")[0] == '1');
     const bool asm_loop = ed_asm_enabled();
-    int iw = -1;
+    int iw = -1, igd = -1, igr = -1;
     if (points || !fixed_base) iw = asm_loop ? st.declare_scratch(ed_smul_ws_bytes(m)) : st.declare_scratch(chunk * 15 * 128);
+    else if (asm_loop) { igd = st.declare_scratch(chunk * ED_GEN_ASM_WINDOWS * 4 + 64); igr = st.declare_scratch(chunk * 128 + 64); }
     if (st.commit()) return st.rc;
     if (m && !points && fixed_base) {
         const u64* table = nullptr;
         int rc = ed_gen_table(ctx, &table);
         if (rc) return rc;
+        if (asm_loop) {                                    // signed 11-bit digits, 23 additions on the plain-arithmetic asm body
+            const u64* t2 = g_ed_gen2_table[ctx->device];
+            for (size_t lo = 0; lo < m; lo += chunk) {
+                const size_t cnt = (m - lo < chunk) ? (m - lo) : chunk;
+                const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
+                hipLaunchKernelGGL(k_ed_gen_digits, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, (u32)cnt, sp, s_stride, s_div, st.scratch<u32>(igd));
+                hipLaunchKernelGGL(k_ed_gen_chain, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, st.scratch<u32>(igd), t2, st.scratch<u64>(igr));
+                hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, st.scratch<u64>(igr), st.out<u64>(io) + 16 * lo);
+            }
+            return st.finish();
+        }
         hipLaunchKernelGGL(k_ed_generator_mul_fixed, dim3(blocks_for(m, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, m, st.in<u64>(is), s_stride, s_div, table,
                            st.out<u64>(io));
         return st.finish();

@@ -304,3 +304,28 @@ def test_asm_loop_exceptional_lanes_are_recomputed_exactly(hip, oracle):
         else:
             x, y = limbs_to_ints(xy[8 * i:8 * i + 8])
             assert (pyref.from_mont(3, x), pyref.from_mont(3, y)) == want, (i, k)
+
+
+def test_generator_mul_digit_edges(hip, oracle):
+    """BN254 fixed-base chain (signed 12-bit digits, 22 windows, additions on the hand-scheduled body): 0, +-1, +-2048 (the recoding threshold),
+    2049, all-ones windows, one digit per window position, chains of carries, r - 1 -- against Python's group law on the generator."""
+    r = pyref.RORD
+    ks = [0, 1, 2, r - 1, r - 2, r - 2048, r - 2049, (1 << 253) % r, ((1 << 254) - 1) % r]
+    for w in range(22):
+        for d in (1, 2047, 2048, 2049, 4095):
+            ks.append((d << (12 * w)) % r)
+            ks.append((r - (d << (12 * w))) % r)
+    ks.append(sum(2048 << (12 * w) for w in range(21)))
+    ks.append(sum(2049 << (12 * w) for w in range(21)))
+    ks += rand_values(0, 40, 4343)
+    n = len(ks)
+    S = mont_array(0, ks)
+    got = np.zeros(12 * n, dtype=np.uint64); hip.eng(0).g1_generator_mul(n, S, got)
+    xy, inf = hip.g1_batch_to_affine(got)
+    for i, k in enumerate(ks):
+        want = pyref.g1_mul(pyref.G, k)
+        if want is None:
+            assert inf[i]
+        else:
+            x, y = limbs_to_ints(xy[8 * i:8 * i + 8])
+            assert not inf[i] and (pyref.from_mont(3, x), pyref.from_mont(3, y)) == want, hex(k)

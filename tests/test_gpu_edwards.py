@@ -220,3 +220,28 @@ def test_edshare_mul_public_at_scale_vs_oracle(pkg, oracle):
     bad = np.nonzero((gxy.reshape(-1, 8) != wxy.reshape(-1, 8)).any(axis=1))[0]
     assert bad.size == 0, "%d of %d scalar-muls differ from the oracle, first at %d" % (bad.size, 2 * len(idx), bad[0])
     e.close()
+
+
+def test_generator_mul_digit_edges(eng, oracle):
+    """The fixed-base chain (signed 11-bit digits, 23 windows, plain-arithmetic asm additions): scalars that put every digit at an edge --
+    0, +-1, +-1024 (the recoding threshold), 1025 in the top window (group order - 1 and its neighbours carry into it), all-ones windows,
+    single digits in every window position -- against the oracle's double-and-add on the base point."""
+    l = pyref.EL
+    ks = [0, 1, 2, l - 1, l - 2, l - 1024, l - 1025, 1 << 252, (1 << 252) + 1, (1 << 252) - 1, (1 << 253) % l, ((1 << 253) - 1) % l]
+    for w in range(23):
+        for d in (1, 1023, 1024, 1025, 2047):
+            ks.append((d << (11 * w)) % l)
+            ks.append((l - (d << (11 * w))) % l)
+    ks.append(sum(1024 << (11 * w) for w in range(22)))            # every window at the threshold
+    ks.append(sum(1025 << (11 * w) for w in range(22)))            # every window just above it: a chain of carries
+    ks += rand_values(2, 40, 4242)
+    n = len(ks)
+    S = mont_array(2, ks)
+    o = np.zeros(16 * n, dtype=np.uint64); eng.ed_generator_mul(n, S, o)
+    xa = np.zeros(8 * n, dtype=np.uint64); eng.ed_to_affine(n, o, xa)
+    for i in range(n):
+        x, y = limbs_to_ints(xa[8 * i:8 * i + 8])
+        assert (pyref.from_mont(4, x), pyref.from_mont(4, y)) == pyref.ed_mul(pyref.ED_B, ks[i]), hex(ks[i])
+    # the extended representative must be consistent too: T Z == X Y
+    G = ext([pyref.ED_B] * n, [1] * n)
+    assert aff_equal(eng, oracle, o, oracle.ed_batch_scalar_mul(G, S))

@@ -366,6 +366,29 @@ def selftest(trials=30, seed=11):
             assert (gx * zi % Q, gy * zi % Q) == want, ("add", with_t, t, kind)
             if with_t:
                 assert gt * zi % Q == want[0] * want[1] % Q
+    # Niels addition (fixed-base chain): affine second operand, incl. the identity (1, 1, 0), the same point and the opposite point
+    def gn():
+        rm = RegMap()
+        E = Emitter(); E.schedule(seq_add_niels(rm))
+        return E, rm
+    En_, rmn = _with_globals(gn)
+    for t in range(trials):
+        P = ed_mul_aff(ED_B, rng.randrange(1, L_ORD)) if t % 7 else (0, 1)
+        z = rng.randrange(1, Q)
+        X, Y, Z, T = (P[0] * z % Q, P[1] * z % Q, z, P[0] * P[1] * z % Q)
+        kind = t % 5
+        Qp = (0, 1) if kind == 0 else (P if kind == 1 else ((Q - P[0]) % Q, P[1]) if kind == 2 else ed_mul_aff(ED_B, rng.randrange(1, L_ORD)))
+        em = _emu(rmn)
+        for regs, v in ((rmn.X1, X), (rmn.Y1, Y), (rmn.Z1, Z), (rmn.T1, T)):
+            em.setv(regs, _lazy(rng, v))
+        for regs, v in ((rmn.QP, (Qp[1] + Qp[0]) % Q), (rmn.QM, (Qp[1] - Qp[0]) % Q), (rmn.QT, 2 * D_ED * Qp[0] * Qp[1] % Q)):
+            em.setv(regs, _lazy(rng, v))
+        em.run(En_.order)
+        gx, gy, gz, gt = (em.getv(r_) % Q for r_ in (rmn.X1, rmn.Y1, rmn.Z1, rmn.T1))
+        assert max(em.getv(r_) for r_ in (rmn.X1, rmn.Y1, rmn.Z1, rmn.T1)) < LIM
+        zi = pow(gz, -1, Q)
+        want = ed_add_aff(P, Qp)
+        assert (gx * zi % Q, gy * zi % Q) == want and gt * zi % Q == want[0] * want[1] % Q, ("niels", t, kind)
     return out
 
 
@@ -455,6 +478,100 @@ def emit_loop():
         A("s_waitcnt vmcnt(0)")
         st = dict(double=len(Ed.order), double_nops=Ed.nops, add=len(Ea.order), add_nops=Ea.nops, vgpr_end=rm.end)
         return L, rm, st
+    return _with_globals(go)
+
+
+def seq_add_niels(rm):
+    """Accumulator += an AFFINE point in Niels form (y+x, y-x, 2dxy) held in QP, QM, QT (madd-2008-hwcd-3, Z2 = 1: D = 2 Z1 is a doubling, not a
+    product): 7 products, T included.  Complete like seq_add; the identity's Niels form is (1, 1, 0).  In place."""
+    X, Y, Z, T = rm.X1, rm.Y1, rm.Z1, rm.T1
+    A, B, t = rm.A, rm.Bv, rm.Cv
+    s = []
+    s += sub_lz(rm, Y, X, A, t)
+    s += add_lz(rm, Y, X, B, t)
+    s += pmul(rm, A, rm.QM, A)
+    s += pmul(rm, B, rm.QP, B)
+    s += pmul(rm, T, rm.QT, rm.QT)               # C
+    s += add_lz(rm, Z, Z, rm.QZ, t)              # D = 2 Z1
+    E, H, F, Gv = rm.QP, rm.QM, X, Y
+    s += sub_lz(rm, B, A, E, t)
+    s += add_lz(rm, B, A, H, t)
+    s += sub_lz(rm, rm.QZ, rm.QT, F, t)
+    s += add_lz(rm, rm.QZ, rm.QT, Gv, t)
+    s += pmul(rm, F, Gv, Z)
+    s += pmul(rm, E, H, T)
+    s += pmul(rm, E, F, X)
+    s += pmul(rm, Gv, H, Y)
+    return s
+
+
+GEN_C = 11                           # signed 11-bit digits of the 253-bit scalars
+GEN_WINDOWS = 23
+GEN_ENTRIES = (1 << (GEN_C - 1)) + 2  # index 0 = the identity (a zero digit adds it: no predication), 1 .. 1025 = |digit| * 2^(11 w) * B (1025: the top window's carry)
+
+
+def emit_gen_chain():
+    """Fixed-base multiplication by the base point: 23 additions of tabulated affine multiples (plain-domain Niels entries of 96 B, table
+    [23][1025] = 2.2 MiB, L2-resident), no doublings.  Operands: %[tid] (VGPR), %[n] (SGPR), %[dig] (SGPR pair: [23][n] records = table entry
+    index | sign << 31), %[tab] %[res] (SGPR pairs; res: [n] (X, Y, T, Z) of 128 B, plain values below the loop's bound)."""
+    def go():
+        rm = RegMap()
+        L = []
+        A = L.append
+        lbl = lambda s_: "%s_%%=" % s_
+        quad = G.quad
+        A("s_nop 1")
+        for j in range(8):
+            A("v_mov_b32_e32 %s, 0x%08x" % (rm.TWOQ[j], ((2 * Q) >> (32 * j)) & M32))
+        for t in rm.C:
+            A("v_mov_b32_e32 %s, 0" % t[1])
+        A("v_lshlrev_b32_e32 %s, 2, %%[tid]" % rm.tid4)
+        A("v_lshlrev_b32_e32 %s, 7, %%[tid]" % rm.tid128)
+        A("s_lshl_b32 %s, %%[n], 2" % S_N4)
+        for j in range(8):                                            # accumulator = identity (0, 1, 1, 0)
+            A("v_mov_b32_e32 %s, 0" % rm.X1[j])
+            A("v_mov_b32_e32 %s, %d" % (rm.Y1[j], 1 if j == 0 else 0))
+            A("v_mov_b32_e32 %s, %d" % (rm.Z1[j], 1 if j == 0 else 0))
+            A("v_mov_b32_e32 %s, 0" % rm.T1[j])
+        A("s_mov_b32 %s, 0" % S_STEP)
+        A("global_load_dword %s, %s, %%[dig]" % (rm.rec, rm.tid4))
+        EC.align_head(A)
+        A(lbl("G_step") + ":")
+        A("s_waitcnt vmcnt(0)")
+        A("v_and_b32_e32 %s, 0x7fffffff, %s" % (rm.tmp, rm.rec))
+        A("v_mul_u32_u24_e32 %s, 96, %s" % (rm.off, rm.tmp))
+        for k, regs in enumerate((rm.QP, rm.QM, rm.QT)):
+            A("global_load_dwordx4 %s, %s, %%[tab] offset:%d" % (quad(regs[:4]), rm.off, 32 * k))
+            A("global_load_dwordx4 %s, %s, %%[tab] offset:%d" % (quad(regs[4:]), rm.off, 32 * k + 16))
+        A("v_cmp_gt_i32_e64 %s, 0, %s" % (S_NEG, rm.rec))
+        # the next window's record travels while this addition runs
+        A("s_add_u32 %s, %s, 1" % (S_TMP, S_STEP))
+        A("s_min_u32 %s, %s, %d" % (S_TMP, S_TMP, GEN_WINDOWS - 1))
+        A("s_mul_i32 %s, %s, %s" % (S_TMP, S_TMP, S_N4))
+        A("v_add_u32_e32 %s, %s, %s" % (rm.tmp, S_TMP, rm.tid4))
+        A("global_load_dword %s, %s, %%[dig]" % (rm.rec, rm.tmp))
+        A("s_waitcnt vmcnt(1)")
+        # negative digit: -(x, y) has the Niels form (y-x, y+x, -2dxy)
+        En = Emitter()
+        seq = [i_subco(rm.A[0], rm.TWOQ[0], rm.QT[0], "vcc")] + [i_subb(rm.A[j], rm.TWOQ[j], rm.QT[j], "vcc") for j in range(1, 8)]
+        seq += fold(rm, rm.A, None, rm.A, S_CY2)
+        seq += EC.movs(rm.Bv, rm.QP)
+        En.lastw[S_NEG] = -1
+        seq += [i_cnd(rm.QP[j], rm.QP[j], rm.QM[j], S_NEG) for j in range(8)]
+        seq += [i_cnd(rm.QM[j], rm.QM[j], rm.Bv[j], S_NEG) for j in range(8)]
+        seq += [i_cnd(rm.QT[j], rm.QT[j], rm.A[j], S_NEG) for j in range(8)]
+        En.schedule(seq); L.extend(En.lines)
+        Ea = Emitter(); Ea.schedule(seq_add_niels(rm)); L.extend(Ea.lines)
+        A("s_add_u32 %s, %s, 1" % (S_STEP, S_STEP))
+        A("s_cmp_lt_u32 %s, %d" % (S_STEP, GEN_WINDOWS))
+        A("s_cbranch_scc1 " + lbl("G_step"))
+        A("s_waitcnt vmcnt(0)")
+        for k, regs in enumerate((rm.X1, rm.Y1, rm.T1, rm.Z1)):
+            A("global_store_dwordx4 %s, %s, %%[res] offset:%d" % (rm.tid128, quad(regs[:4]), 32 * k))
+            A("global_store_dwordx4 %s, %s, %%[res] offset:%d" % (rm.tid128, quad(regs[4:]), 32 * k + 16))
+        A("s_waitcnt vmcnt(0)")
+        mult = sum(1 for i in Ea.order if i.op in ("mad", "mul_lo"))
+        return L, rm, dict(add=len(Ea.order), chain_mults=GEN_WINDOWS * mult, vgpr_end=rm.end)
     return _with_globals(go)
 
 
@@ -563,6 +680,14 @@ def emit_header(path):
             "__device__ __forceinline__ void ed_smul_table_asm(u32 tid, u32 poff, u32 n, const u64* pts, u64* tab) {", "    asm volatile(",
             G.c_string(tlines), "        :", '        : [tid] "v"(tid), [poff] "v"(poff), [n] "s"(n), [pts] "s"(pts), [tab] "s"(tab)']
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(trm.first, trm.end)]
+    out += ["        : " + ", ".join(clob) + ");", "}"]
+    glines, grm, gst = emit_gen_chain()
+    out += ["// fixed-base multiplication by the base point: %d additions of tabulated affine multiples (plain Niels entries), %d asm lines, %d multiplier instructions" %
+            (GEN_WINDOWS, len(glines), gst["chain_mults"]),
+            "#define ED_GEN_ASM_C %d" % GEN_C, "#define ED_GEN_ASM_WINDOWS %d" % GEN_WINDOWS, "#define ED_GEN_ASM_ENTRIES %d" % GEN_ENTRIES,
+            "__device__ __forceinline__ void ed_gen_chain_asm(u32 tid, u32 n, const u32* dig, const u64* tab, u64* res) {", "    asm volatile(",
+            G.c_string(glines), "        :", '        : [tid] "v"(tid), [n] "s"(n), [dig] "s"(dig), [tab] "s"(tab), [res] "s"(res)']
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(grm.first, grm.end)]
     out += ["        : " + ", ".join(clob) + ");", "}"]
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
