@@ -368,3 +368,40 @@ def test_config3_all_2p24_gates_in_8_ranges_bitexact_vs_oracle(pkg, oracle):
         assert bad.size == 0, "party %d: %d of %d gates differ from the oracle, first at %d" % (p, bad.size, n, bad[0])
         del want, got
     e.close()
+
+
+def test_point_pipelines_across_launch_chunks(pkg):
+    """The scalar-mul pipelines run in chunks (2^19 lanes for the variable-base asm loops, 2^20 for the fixed-base chains); lane indices,
+    workspace strides and the point / scalar divisors restart at every chunk.  Batches a few elements ABOVE those sizes, checked with
+    size-independent properties on every element (affine coordinates):
+      * PointShare x Scalar, P_i = k_i G with known k_i: result == [(s_i k_i)] G through the fixed-base path (both curves);
+      * generator multiplication: [(a + b)] G == [a] G + [b] G (both curves)."""
+    n = (1 << 18) + 3                                                # 2n = 2^19 + 6 scalar-muls: two chunks, the split inside a PointShare pair range
+    for field, pw, names in (("bn254_fr", 12, ("scalarshare_mul_generator", "pointshare_mul_public", "g1_generator_mul", "g1_to_affine", "g1_add")),
+                             ("curve25519_fr", 16, ("scalarshare_mul_ed_generator", "edshare_mul_public", "ed_generator_mul", "ed_to_affine", "ed_add"))):
+        e = pkg.Engine(field, device=0, stream=torch.cuda.current_stream().cuda_stream)
+        ss_gen, sh_mul, gen_mul, to_aff, add = (getattr(e, nm) for nm in names)
+        g = torch.Generator(device="cuda"); g.manual_seed(0xC0FFEE)
+
+        def affine(pts, m):
+            xy = torch.empty(8 * m, dtype=torch.int64, device="cuda")
+            if pw == 12:
+                inf = torch.empty(m + 16, dtype=torch.uint8, device="cuda"); to_aff(m, pts, xy, inf); return torch.cat([xy, inf[:m].to(torch.int64)])
+            to_aff(m, pts, xy); return xy
+
+        k = _rnd(e, 2 * n, g)
+        shares = torch.empty(2 * pw * n, dtype=torch.int64, device="cuda"); ss_gen(n, k, shares)
+        sc = _rnd(e, n, g)
+        out = torch.empty_like(shares); sh_mul(n, shares, sc, out)
+        sk = torch.empty_like(k); e.scalar_mul(2 * n, k, sc.view(n, 1, 4).expand(n, 2, 4).contiguous().view(-1), sk)
+        want = torch.empty(pw * 2 * n, dtype=torch.int64, device="cuda"); gen_mul(2 * n, sk, want)
+        assert torch.equal(affine(out, 2 * n), affine(want, 2 * n)), field + ": PointShare x Scalar across the chunk boundary"
+        del shares, out, want, sk, k
+        m = (1 << 20) + 5                                            # fixed-base chain: two chunks
+        a, b = _rnd(e, m, g), _rnd(e, m, g)
+        ab = torch.empty_like(a); e.scalar_add(m, a, b, ab)
+        pa, pb, pab = (torch.empty(pw * m, dtype=torch.int64, device="cuda") for _ in range(3))
+        gen_mul(m, a, pa); gen_mul(m, b, pb); gen_mul(m, ab, pab)
+        s = torch.empty_like(pa); add(m, pa, pb, s)
+        assert torch.equal(affine(s, m), affine(pab, m)), field + ": generator multiplication is not additive somewhere"
+        e.close()
