@@ -10,6 +10,7 @@
 // that share the parent's storage and keep it alive.
 #include "arkmpc_internal.hpp"
 #include <atomic>
+#include <cstdlib>
 
 struct arkmpc_batch {
     std::atomic<int> refs{1};
@@ -202,6 +203,52 @@ int arkmpc_batch_beaver_finish(arkmpc_ctx* ctx, int party_id, const uint64_t mac
                                       c->share, c->mac, c->stride, r->share, r->mac, r->stride);
     if (rc) { arkmpc_batch_destroy(ctx, r); *out = nullptr; }
     return rc;
+}
+
+// ---- composite gate: the point-side K3 (authenticated_curve.rs:703-713), regrouped -- see include/arkmpc.h --------------------------------
+}  // extern "C"
+namespace {
+// scratch in the address space the context's buffers live in (device memory, or host memory for a host-buffer context)
+struct Tmp {
+    arkmpc_ctx* ctx; void* p = nullptr; int rc = ARKMPC_OK;
+    Tmp(arkmpc_ctx* c, size_t bytes) : ctx(c) {
+        if (c->host_buffers) { p = std::malloc(bytes ? bytes : 16); if (!p) rc = ARKMPC_ERR_BAD_ARG; }
+        else rc = arkmpc_malloc(c, bytes ? bytes : 16, &p);
+    }
+    ~Tmp() { if (p) { if (ctx->host_buffers) std::free(p); else arkmpc_free(ctx, p); } }
+    u64* u() const { return (u64*)p; }
+};
+typedef int (*MulPointFn)(arkmpc_ctx*, size_t, const uint64_t*, const uint64_t*, uint64_t*);
+typedef int (*MulGenFn)(arkmpc_ctx*, size_t, const uint64_t*, uint64_t*);
+typedef int (*AddFn)(arkmpc_ctx*, size_t, const uint64_t*, const uint64_t*, uint64_t*);
+int point_beaver_finish(arkmpc_ctx* ctx, size_t n, int party, const uint64_t key[4], const uint64_t* d, const uint64_t* eG, const uint64_t* a,
+                        const uint64_t* b, const uint64_t* c, uint64_t* out, size_t pw, MulPointFn mul_point, MulGenFn mul_gen, AddFn add) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (party != 0 && party != 1) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!key) return ark_bad(ctx, "null mac_key");
+    if (n && (!d || !eG || !a || !b || !c || !out)) return ark_bad(ctx, "null buffer");
+    if (!n) return ARKMPC_OK;
+    Tmp on_eG(ctx, n * 64), on_G(ctx, n * 64), t1(ctx, n * 2 * pw * 8);
+    if (on_eG.rc || on_G.rc || t1.rc) return on_eG.rc ? on_eG.rc : (on_G.rc ? on_G.rc : t1.rc);
+    int rc = arkmpc_share_add_public(ctx, n, party, key, a, d, on_eG.u());                     // [a] + d
+    if (!rc) rc = arkmpc_share_mul_public(ctx, n, b, d, on_G.u());                             // d [b]
+    if (!rc) rc = arkmpc_share_add(ctx, n, on_G.u(), c, on_G.u());                             // [c] + d [b]
+    if (!rc) rc = mul_point(ctx, n, on_eG.u(), eG, t1.u());                                    // ([a] + d) * eG
+    if (!rc) rc = mul_gen(ctx, n, on_G.u(), out);                                              // ([c] + d [b]) * G
+    if (!rc) rc = add(ctx, n, t1.u(), out, out);
+    return rc;
+}
+}  // namespace
+extern "C" {
+int arkmpc_point_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d_open, const uint64_t* eG_open,
+                               const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out_shares) {
+    return point_beaver_finish(ctx, n, party_id, mac_key, d_open, eG_open, a, b, c, out_shares, 12, arkmpc_scalarshare_mul_point,
+                               arkmpc_scalarshare_mul_generator, arkmpc_pointshare_add);
+}
+int arkmpc_edpoint_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d_open, const uint64_t* eG_open,
+                                 const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out_shares) {
+    return point_beaver_finish(ctx, n, party_id, mac_key, d_open, eG_open, a, b, c, out_shares, 16, arkmpc_scalarshare_mul_ed_point,
+                               arkmpc_scalarshare_mul_ed_generator, arkmpc_edshare_add);
 }
 
 // ---- events: device-side ordering between the streams of two contexts ---------------------------------------------------------

@@ -251,6 +251,8 @@ class Engine:
     def scalarshare_mul_point(self, n, ss, pts, out): self.call("scalarshare_mul_point", ("size", n), ss, pts, out)
     def pointshare_extract(self, n, shares, out): self.call("pointshare_extract", ("size", n), shares, out)
     def point_mac_check_shares(self, n, key, opened, shares, out): self.call("point_mac_check_shares", ("size", n), ("key", key), opened, shares, out)
+    def point_beaver_finish(self, n, party, key, d_open, eG_open, a, b, c, out, ed=False):
+        self.call("edpoint_beaver_finish" if ed else "point_beaver_finish", ("size", n), ("int", party), ("key", key), d_open, eG_open, a, b, c, out)
     def fill(self, n, record, out):
         rec = np.ascontiguousarray(record, dtype=np.uint64)
         self._ck(self.lib.arkmpc_fill(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(rec.size), ctypes.c_void_p(rec.ctypes.data), _ptr(out)))

@@ -361,6 +361,8 @@ struct Bn254G1 {                      // ark_bn254::G1Projective: short-Weierstr
     static int commit_points(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* bl, uint64_t* o) { return arkmpc_commit_points_sha3(c, n, p, bl, o); }
     static int mac_verify(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint8_t* ok) { return arkmpc_point_mac_verify(c, n, a, b, ok); }
     static int share_sum(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_pointshare_sum(c, n, a, o); }
+    static int beaver_finish(arkmpc_ctx* c, size_t n, int party, const uint64_t* k, const uint64_t* d, const uint64_t* eG, const uint64_t* ta, const uint64_t* tb,
+                             const uint64_t* tc, uint64_t* o) { return arkmpc_point_beaver_finish(c, n, party, k, d, eG, ta, tb, tc, o); }
     // CurvePoint::msm / msm_authenticated (curve.rs:549-560, :618-642): the bucket method on the GPU
     static int msm(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) { return arkmpc_g1_msm(c, n, p, s, o); }
     static int msm_authenticated(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* ss, uint64_t* o) { return arkmpc_g1_msm_authenticated(c, n, p, ss, o); }
@@ -387,6 +389,8 @@ struct Curve25519 {                   // ark_curve25519::EdwardsProjective (READ
     static int commit_points(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* bl, uint64_t* o) { return arkmpc_commit_ed_points_sha3(c, n, p, bl, o); }
     static int mac_verify(arkmpc_ctx* c, size_t n, const uint64_t* a, const uint64_t* b, uint8_t* ok) { return arkmpc_ed_mac_verify(c, n, a, b, ok); }
     static int share_sum(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_edshare_sum(c, n, a, o); }
+    static int beaver_finish(arkmpc_ctx* c, size_t n, int party, const uint64_t* k, const uint64_t* d, const uint64_t* eG, const uint64_t* ta, const uint64_t* tb,
+                             const uint64_t* tc, uint64_t* o) { return arkmpc_edpoint_beaver_finish(c, n, party, k, d, eG, ta, tb, tc, o); }
     // no bucket-method MSM on this curve: CurvePoint::msm as n scalar-muls + one sum (the definition, curve.rs:549-560)
     static int msm(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) {
         void* t = nullptr;
@@ -875,10 +879,11 @@ template <class Cv> class AuthenticatedPointBatchT {
         Self masked_lhs = batch_sub(b, beaver_b_gen);                                              // :699
         PointBatch eG_open = masked_lhs.open_batch();                                              // :701
         ScalarBatch d_open = masked_rhs.open_batch();                                              // :702
-        if (!literal) {
-            AuthenticatedScalarBatch on_eG = AuthenticatedScalarBatch::batch_add_public(ta, d_open);                       // [a] + d
-            AuthenticatedScalarBatch on_G = AuthenticatedScalarBatch::batch_add(tc, AuthenticatedScalarBatch::batch_mul_public(tb, d_open));   // [c] + d[b]
-            return batch_add(batch_mul_authenticated(on_eG, eG_open), batch_mul_generator(on_G));
+        if (!literal) {                                                                            // one gate of the C ABI: the point-side K3
+            Self r = alloc(f, n);
+            check(f->ctx(), Cv::beaver_finish(f->ctx(), n, (int)f->party_id(), f->mac_key().l, d_open.buf.ptr(), eG_open.buf.ptr(), ta.buf.ptr(),
+                                              tb.buf.ptr(), tc.buf.ptr(), r.buf.ptr()), "point_beaver_finish");
+            return r;
         }
         PointBatch deG = point_batch_mul(f, d_open, eG_open);                                      // :705
         Self dbG = batch_mul_public(d_open, beaver_b_gen);                                         // :706

@@ -256,6 +256,16 @@ int arkmpc_pointshare_add_public(arkmpc_ctx* ctx, size_t n, int party_id, const 
 int arkmpc_pointshare_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
                                  const uint64_t* shares, const uint64_t* pub_points, uint64_t* out);
 int arkmpc_scalarshare_mul_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, uint64_t* out);      /* :754-780 */
+/* The point-side K3 as ONE gate: AuthenticatedPointResult::batch_mul after the openings (authenticated_curve.rs:703-713).  Given the opened
+ * d = x - a (n Scalars), the opened eG = yG - [b]G (n points) and this party's triple shares a, b, c (n ScalarShares each),
+ *     out = ([a] + d) * eG + ([c] + d [b]) * G
+ * which equals the reference's deG + d[bG] + [a]eG + [c]G share by share and MAC by MAC ([bG] = [b]G; "[a] + d" is
+ * ScalarShare::add_public, share.rs:74-77): 2 variable-base + 2 generator scalar-muls per element instead of 6 + 2.
+ * out: n PointShares.  arkmpc_edpoint_beaver_finish is the same gate on a CURVE25519_FR context (16-word points). */
+int arkmpc_point_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d_open,
+                               const uint64_t* eG_open, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out_shares);
+int arkmpc_edpoint_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d_open,
+                                 const uint64_t* eG_open, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out_shares);
 int arkmpc_scalarshare_mul_point(arkmpc_ctx* ctx, size_t n, const uint64_t* scalar_shares, const uint64_t* points,
                                  uint64_t* out);                                                                     /* curve.rs:483-517 */
 /* sums: the reduction gate of AuthenticatedPointResult::msm (authenticated_curve.rs:796-805) / PointShare::sum

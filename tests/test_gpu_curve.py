@@ -329,3 +329,40 @@ def test_generator_mul_digit_edges(hip, oracle):
         else:
             x, y = limbs_to_ints(xy[8 * i:8 * i + 8])
             assert not inf[i] and (pyref.from_mont(3, x), pyref.from_mont(3, y)) == want, hex(k)
+
+
+@pytest.mark.parametrize("party", [0, 1])
+@pytest.mark.parametrize("host_mode", [True, False])
+def test_point_beaver_finish_equals_the_references_four_terms(pkg, hip, oracle, party, host_mode):
+    """arkmpc_point_beaver_finish (the point-side K3, regrouped to ([a] + d) eG + ([c] + d[b]) G) against the reference's literal terms
+    deG + d[bG] + [a]eG + [c]G (authenticated_curve.rs:703-713) evaluated with the ORACLE's per-op functions, on affine coordinates, for
+    random opened values, triple shares and MAC key; host-pointer and device-pointer contexts."""
+    n = 21
+    r = pyref.RORD
+    key = mont_array(0, rand_values(0, 1, 600 + party))
+    d = mont_array(0, [0, 1, r - 1] + rand_values(0, n - 3, 601))
+    _, eG = random_points(n, 602, with_identity=True)
+    ta, tb, tc = (mont_array(0, rand_values(0, 2 * n, 603 + k)) for k in range(3))           # n ScalarShares each (share, mac interleaved)
+    # literal sequence on the oracle
+    bG = oracle.scalarshare_mul_generator(tb)                                                  # [b]G            (:696)
+    deG = oracle.g1_batch_scalar_mul(eG, d)                                                    # d * eG          (:705)
+    d2 = np.repeat(d.reshape(n, 4), 2, axis=0).reshape(-1)
+    dbG = oracle.pointshare_mul_public(bG, d)                                                  # d [bG]          (:706)
+    aeG = oracle.scalarshare_mul_point(ta, eG)                                                 # [a] eG          (:707)
+    cG = oracle.scalarshare_mul_generator(tc)                                                  # [c] G           (:708)
+    want = oracle.pointshare_add(oracle.pointshare_add_public(party, key, dbG, deG), oracle.pointshare_add(aeG, cG))     # (:710-713)
+    e = pkg.Engine(0, device=0, host_buffers=host_mode)
+    out = np.zeros(24 * n, dtype=np.uint64)
+    if host_mode:
+        e.point_beaver_finish(n, party, key, d, eG, ta, tb, tc, out)
+    else:
+        import torch
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+        o = torch.zeros(24 * n, dtype=torch.int64, device="cuda")
+        e.point_beaver_finish(n, party, key, dev(d), dev(eG), dev(ta), dev(tb), dev(tc), o)
+        e.sync()                                              # the context has its own stream
+        out = o.cpu().numpy().view(np.uint64)
+    assert affine_equal(hip, oracle, out, want)
+    with pytest.raises(pkg.ArkMpcError):
+        e.point_beaver_finish(n, 2, key, d, eG, ta, tb, tc, out)
+    e.close()
