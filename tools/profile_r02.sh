@@ -23,9 +23,13 @@ rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_ec -o trace -- env REPS=5 
 cd $REPO
 REPS=5 LOG2N=18 python tools/ec_bench.py > $OUT/ec_bench.json 2>/dev/null
 ./probes/mulrate 2000 > $OUT/mulrate.jsonl 2>&1
+python tools/genmul_bench.py > $OUT/genmul_bench.json 2>/dev/null
+python tools/ed_bench.py > $OUT/ed_bench.json 2>/dev/null
+SKIP_NAIVE=1 LOG2N=10,12,14,16,18,20,22 python tools/msm_bench.py 2>/dev/null > $REPO/gpurun_out/msm_bench_r02.jsonl
 python tools/kernel_suite.py 2>/dev/null | grep -v "^\[" > $OUT/kernel_suite.txt
 FID=1 python tools/kernel_suite.py 2>/dev/null | grep -v "^\[" > $OUT/kernel_suite_bls12_381.txt
 ARKMPC_MOCK_LINK=device ./ark-mpc_amd/lib/arkmpc_host_bench point_batch_mul 262144 3 > $OUT/host_point_batch_mul.jsonl 2>&1
+ARKMPC_POINT_MUL_LITERAL=1 ARKMPC_MOCK_LINK=device ./ark-mpc_amd/lib/arkmpc_host_bench point_batch_mul 262144 3 >> $OUT/host_point_batch_mul.jsonl 2>&1
 bash tools/host_bench.sh > $OUT/host_bench.jsonl 2>&1
 python bench.py --layout aos --no-extras > $OUT/bench_aos.json 2>/dev/null
 python tools/summarize_prof_r02.py $OUT > $OUT/summary.txt 2>&1
