@@ -690,18 +690,20 @@ __global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_digits(u32 n, const u64* p
     // (the loop would end on acc == 2^130 R0 and flag the lane; zero shares / MACs are common: a party's MAC-key share can be 0)
     exc0[i] = (fe_is_zero(fe_load(points + (size_t)p_stride * (i / p_div) + 8)) || fe_is_zero(s)) ? 1u : 0u;
 }
-__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_table(u32 n, const u64* points, u32 p_stride, u32 p_div, u64* jtab, u64* tab, u64* zc) {
+// one table column per lane of THIS launch: the launcher passes the number of columns (= lanes / tdiv when tdiv lanes share a point)
+__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_table(u32 ncol, const u64* points, u32 p_stride, u32 p_div, u64* jtab, u64* tab, u64* zc) {
     const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
-    if (i >= n) return;
-    g1_smul_table_asm(i, p_stride * 8u * (i / p_div), n, points, jtab, tab, zc);
+    if (i >= ncol) return;
+    g1_smul_table_asm(i, p_stride * 8u * (i / p_div), ncol, points, jtab, tab, zc);
 }
-__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_loop(u32 n, const u64* tab, const u32* dig, u64* res, u32* exc) {
+// tdiv lanes share one table column (ScalarShare x point: the share lane and the MAC lane multiply the same point)
+__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_loop(u32 n, u32 tdiv, const u64* tab, const u32* dig, u64* res, u32* exc) {
     const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
     if (i >= n) return;
-    g1_smul_loop_asm(i, n, tab, dig, res, exc);
+    g1_smul_loop_asm(i, n, i / tdiv, n / tdiv, tab, dig, res, exc);
 }
 __global__ void __launch_bounds__(TPB_EC) k_g1_smul_finish(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride,
-                                                            u32 s_div, G1AsmWs ws, u64* out, u32 recompute_flagged) {
+                                                            u32 s_div, G1AsmWs ws, u64* out, u32 recompute_flagged, u32 tdiv) {
     const u32 i = blockIdx.x * TPB_EC + threadIdx.x;
     if (i >= n) return;
     if (ws.exc0[i]) { g1_store(out + 12 * (size_t)i, g1_identity()); return; }        // identity in / zero scalar: nothing to compute
@@ -712,7 +714,7 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_smul_finish(u32 n, const u64* poi
         return;
     }
     G1 r = g1_load(ws.res + 12 * (size_t)i);
-    r.z = FQ_MUL(r.z, fe_load(ws.zc + 4 * (size_t)i));
+    r.z = FQ_MUL(r.z, fe_load(ws.zc + 4 * (size_t)(i / tdiv)));
     g1_store(out + 12 * (size_t)i, r);
 }
 #define G1_ASM_WS_BYTES (16 * 96 + G1_ASM_TABLE * 64 + G1_ASM_STEPS * 4 + 96 + 32 + 8)
@@ -982,19 +984,23 @@ static void g1_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_s
         const u64* pp = points ? points + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
         const u64* sp = scalars + (size_t)s_stride * (lo / s_div);
         const G1AsmWs ws = g1_asm_carve(wsbase, cnt);
+        u32 tdiv = 1;
         if (pp && asm_prep) {
             hipLaunchKernelGGL(k_g1_smul_digits, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div,
                                ws.dig, ws.exc0);
-            hipLaunchKernelGGL(k_g1_smul_table, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, ws.jtab, ws.tab, ws.zc);
+            // p_div lanes multiply the same point: one table column serves them all (the table is a sixth of a scalar-mul's work)
+            if (p_div > 1 && cnt % p_div == 0) tdiv = p_div;
+            const u32 ncol = (u32)(cnt / tdiv);
+            hipLaunchKernelGGL(k_g1_smul_table, dim3(blocks_for(ncol, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.jtab, ws.tab, ws.zc);
         } else {
             hipLaunchKernelGGL(k_g1_smul_prep, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
         }
-        hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res, ws.exc1);
+        hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res, ws.exc1);
         // test hook: ARKMPC_EC_ASM_NOFIX=1 leaves flagged lanes as the loop produced them (garbage), which is how the tests prove that the
         // crafted inputs really reach the exceptional path
         static const u32 recompute = (getenv("ARKMPC_EC_ASM_NOFIX") && getenv("ARKMPC_EC_ASM_NOFIX")[0] == '1') ? 0u : 1u;
         hipLaunchKernelGGL(k_g1_smul_finish, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws,
-                           out + 12 * lo, recompute);
+                           out + 12 * lo, recompute, tdiv);
     }
 }
 static inline size_t g1_smul_ws_bytes(size_t m) { return (m < G1_ASM_CHUNK ? m : G1_ASM_CHUNK) * G1_ASM_WS_BYTES + 256; }

@@ -186,10 +186,11 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_smul_prep(u32 n, const u64* point
         ed_store_cached(ws.tab + ((size_t)k * n + i) * 16, acc);
     }
 }
-__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_loop(u32 n, const u64* tab, const u32* dig, u64* res) {
+// tdiv lanes share one table column (ScalarShare x point: the share lane and the MAC lane multiply the same point)
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_loop(u32 n, u32 tdiv, const u64* tab, const u32* dig, u64* res) {
     const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
     if (i >= n) return;
-    ed_smul_loop_asm(i, n, tab, dig, res);
+    ed_smul_loop_asm(i, n, i / tdiv, n / tdiv, tab, dig, res);
 }
 __global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_finish(u32 n, const u64* res, u64* out) {
     const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
@@ -595,13 +596,16 @@ static void ed_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_s
         const u64* sp = scalars + (size_t)s_stride * (lo / s_div);
         const EdAsmWs ws = ed_asm_carve(wsbase, cnt);
         static const bool asm_prep = !(getenv("ARKMPC_ED_ASM_PREP") && getenv("ARKMPC_ED_ASM_PREP")[0] == '0');
+        u32 tdiv = 1;
         if (asm_prep && pp && (size_t)p_stride * 8 * (cnt / p_div + 1) < ((size_t)1 << 32)) {
             hipLaunchKernelGGL(k_ed_smul_digits, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, (u32)cnt, sp, s_stride, s_div, ws.dig);
-            hipLaunchKernelGGL(k_ed_smul_table, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, ws.tab);
+            if (p_div > 1 && cnt % p_div == 0) tdiv = p_div;          // p_div lanes multiply the same point: one table column serves them
+            const u32 ncol = (u32)(cnt / tdiv);
+            hipLaunchKernelGGL(k_ed_smul_table, dim3(blocks_for(ncol, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.tab);
         } else {
             hipLaunchKernelGGL(k_ed_smul_prep, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
         }
-        hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.tab, ws.dig, ws.res);
+        hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res);
         hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.res, out + 16 * lo);
     }
 }

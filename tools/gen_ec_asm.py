@@ -393,7 +393,9 @@ LOOP_ALIGN = "6:2"        # measured on MI355X (config 4): "6:0" 8.15 ms, none 7
 
 def emit_loop():
     """Returns (lines, regmap, stats): the whole step loop as assembler text.
-    Operands: %[tid] (VGPR, lane's index in the launch), %[n] (SGPR, lanes in the launch), %[tab] %[dig] %[res] %[exc] (SGPR pairs)."""
+    Operands: %[tid] (VGPR, lane's index in the launch), %[n] (SGPR, lanes in the launch), %[tab] %[dig] %[res] %[exc] (SGPR pairs);
+    %[ptid] (VGPR) / %[np] (SGPR): the lane's column in the window table and the number of columns -- lanes that multiply the SAME point
+    (ScalarShare x point: two lanes per point) share one table column."""
     def go():
         rm = RegMap()
         L = []
@@ -410,10 +412,10 @@ def emit_loop():
         for t in rm.Tz:
             A("v_mov_b32_e32 %s, 0" % t[1])
         A("v_lshlrev_b32_e32 %s, 2, %%[tid]" % rm.tid4)
-        A("v_lshlrev_b32_e32 %s, 6, %%[tid]" % rm.tid64)
+        A("v_lshlrev_b32_e32 %s, 6, %%[ptid]" % rm.tid64)
         A("v_mul_u32_u24_e32 %s, 96, %%[tid]" % rm.tid96)
         A("s_lshl_b32 %s, %%[n], 2" % S_N4)
-        A("s_lshl_b32 %s, %%[n], 6" % S_N64)
+        A("s_lshl_b32 %s, %%[np], 6" % S_N64)
         A("s_mov_b64 %s, 0" % S_EXC)
         # accumulator = table entry 16 (R0 on the isomorphic curve), Z = 1 (Montgomery form)
         A("s_mul_i32 %s, %s, 16" % (S_TMP, S_N64))
@@ -772,11 +774,11 @@ def emit_header(path):
         out.append("__device__ constexpr u32 G1_ASM_%s[8] = {%s};" % (nm, limbs(v)))
     out.append("#define G1_ASM_STEPS %d" % N_STEPS)
     out.append("#define G1_ASM_TABLE %d" % N_TABLE)
-    out.append("__device__ __forceinline__ void g1_smul_loop_asm(u32 tid, u32 n, const u64* tab, const u32* dig, u64* res, u32* exc) {")
+    out.append("__device__ __forceinline__ void g1_smul_loop_asm(u32 tid, u32 n, u32 ptid, u32 np, const u64* tab, const u32* dig, u64* res, u32* exc) {")
     out.append("    asm volatile(")
     out.append(G.c_string(lines))
     out.append("        :")
-    out.append('        : [tid] "v"(tid), [n] "s"(n), [tab] "s"(tab), [dig] "s"(dig), [res] "s"(res), [exc] "s"(exc)')
+    out.append('        : [tid] "v"(tid), [n] "s"(n), [ptid] "v"(ptid), [np] "s"(np), [tab] "s"(tab), [dig] "s"(dig), [res] "s"(res), [exc] "s"(exc)')
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(rm.first, rm.end)]
     out.append("        : " + ", ".join(clob) + ");")
     out.append("}")

@@ -394,7 +394,8 @@ def selftest(trials=30, seed=11):
 
 # ---- the loop ---------------------------------------------------------------------------------------------------------------
 def emit_loop():
-    """Operands: %[tid] (VGPR), %[n] (SGPR), %[tab] %[dig] %[res] (SGPR pairs).  tab: [17][n] cached entries of 128 B; dig: [51][n] records
+    """Operands: %[tid] (VGPR), %[n] (SGPR), %[ptid] (VGPR) / %[np] (SGPR): the lane's table column and the number of columns (lanes that
+    multiply the same point share one), %[tab] %[dig] %[res] (SGPR pairs).  tab: [17][np] cached entries of 128 B; dig: [51][n] records
     (bits 0-4 table index = |digit|, bit 5 negate); res: [n] (X, Y, Z, T) of 128 B, values below 2^255."""
     def go():
         rm = RegMap()
@@ -412,9 +413,9 @@ def emit_loop():
         for t in rm.C:
             A("v_mov_b32_e32 %s, 0" % t[1])
         A("v_lshlrev_b32_e32 %s, 2, %%[tid]" % rm.tid4)
-        A("v_lshlrev_b32_e32 %s, 7, %%[tid]" % rm.tid128)
+        A("v_lshlrev_b32_e32 %s, 7, %%[ptid]" % rm.tid128)          # table column; the result offset is formed at the end
         A("s_lshl_b32 %s, %%[n], 2" % S_N4)
-        A("s_lshl_b32 %s, %%[n], 7" % S_N128)
+        A("s_lshl_b32 %s, %%[np], 7" % S_N128)
         for j in range(8):                                            # accumulator = identity (0, 1, 1, 0)
             A("v_mov_b32_e32 %s, 0" % rm.X1[j])
             A("v_mov_b32_e32 %s, 0x%08x" % (rm.Y1[j], (one >> (32 * j)) & M32))
@@ -472,6 +473,7 @@ def emit_loop():
         A("s_add_u32 %s, %s, 1" % (S_STEP, S_STEP))
         A("s_cmp_lt_u32 %s, %d" % (S_STEP, N_WINDOWS))
         A("s_cbranch_scc1 " + lbl("E_step"))
+        A("v_lshlrev_b32_e32 %s, 7, %%[tid]" % rm.tid128)
         for k, regs in enumerate((rm.X1, rm.Y1, rm.T1, rm.Z1)):        # ark-ec order: x, y, t, z
             A("global_store_dwordx4 %s, %s, %%[res] offset:%d" % (rm.tid128, quad(regs[:4]), 32 * k))
             A("global_store_dwordx4 %s, %s, %%[res] offset:%d" % (rm.tid128, quad(regs[4:]), 32 * k + 16))
@@ -670,8 +672,8 @@ def emit_header(path):
            "// double: %d instructions (%d wait states), add: %d (%d), VGPRs v%d..v%d; %d multiplier instructions per scalar-mul in the loop." %
            (st["double"], st["double_nops"], st["add"], st["add_nops"], rm.first, rm.end - 1, loop_m),
            "#pragma once", "#define ED_ASM_WINDOWS %d" % N_WINDOWS, "#define ED_ASM_TABLE %d" % N_TABLE, "#define ED_ASM_MULT_INSTRS_LOOP %d" % loop_m,
-           "__device__ __forceinline__ void ed_smul_loop_asm(u32 tid, u32 n, const u64* tab, const u32* dig, u64* res) {", "    asm volatile(",
-           G.c_string(lines), "        :", '        : [tid] "v"(tid), [n] "s"(n), [tab] "s"(tab), [dig] "s"(dig), [res] "s"(res)']
+           "__device__ __forceinline__ void ed_smul_loop_asm(u32 tid, u32 n, u32 ptid, u32 np, const u64* tab, const u32* dig, u64* res) {", "    asm volatile(",
+           G.c_string(lines), "        :", '        : [tid] "v"(tid), [n] "s"(n), [ptid] "v"(ptid), [np] "s"(np), [tab] "s"(tab), [dig] "s"(dig), [res] "s"(res)']
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(rm.first, rm.end)]
     out += ["        : " + ", ".join(clob) + ");", "}"]
     tlines, trm, tst = emit_table()
