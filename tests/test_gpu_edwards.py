@@ -245,3 +245,25 @@ def test_generator_mul_digit_edges(eng, oracle):
     # the extended representative must be consistent too: T Z == X Y
     G = ext([pyref.ED_B] * n, [1] * n)
     assert aff_equal(eng, oracle, o, oracle.ed_batch_scalar_mul(G, S))
+
+
+@pytest.mark.parametrize("party", [0, 1])
+def test_edpoint_beaver_finish_equals_the_references_four_terms(eng, oracle, party):
+    """arkmpc_edpoint_beaver_finish (the point-side K3 on Curve25519, regrouped to ([a] + d) eG + ([c] + d[b]) G) against the reference's literal
+    terms deG + d[bG] + [a]eG + [c]G (authenticated_curve.rs:703-713) evaluated with the oracle's per-op functions, on affine coordinates."""
+    n = 13
+    l = pyref.EL
+    key = mont_array(2, rand_values(2, 1, 700 + party))
+    d = mont_array(2, [0, 1, l - 1] + rand_values(2, n - 3, 701))
+    _, eG = rand_points(n, 702)                                                                 # includes the identity
+    ta, tb, tc = (mont_array(2, rand_values(2, 2 * n, 703 + k)) for k in range(3))             # n ScalarShares each
+    G = ext([pyref.ED_B], [1])
+    bG = oracle.ed_batch_scalar_mul(G, tb, n=2 * n, p_div=2 * n)                                # [b]G     as n EdPointShares
+    cG = oracle.ed_batch_scalar_mul(G, tc, n=2 * n, p_div=2 * n)                                # [c]G
+    deG = oracle.ed_batch_scalar_mul(eG, d)                                                     # d * eG
+    dbG = oracle.ed_batch_scalar_mul(bG, d, n=2 * n, s_div=2)                                   # d [bG]
+    aeG = oracle.ed_batch_scalar_mul(eG, ta, n=2 * n, p_div=2)                                  # [a] eG
+    want = oracle.ed_batch_add(oracle.edshare_add_public(party, key, dbG, deG), oracle.ed_batch_add(aeG, cG))
+    out = np.zeros(32 * n, dtype=np.uint64)
+    eng.point_beaver_finish(n, party, key, d, eG, ta, tb, tc, out, ed=True)
+    assert aff_equal(eng, oracle, out, want)
