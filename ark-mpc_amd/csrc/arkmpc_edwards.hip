@@ -373,6 +373,9 @@ template <int NB> __device__ __forceinline__ Fe eq_pow(const Fe& base, const u32
     }
     return acc;
 }
+// CHECK: the prime-order subgroup test inside this kernel (253 compiled doublings per point); the hand-scheduled path runs the kernel
+// with CHECK = false and verifies [l - 1] P == -P through the scalar-mul pipeline instead (k_ed_subgroup_verify)
+template <bool CHECK>
 __global__ void __launch_bounds__(TPB_ED) k_ed_from_bytes(size_t n, const unsigned char* in, u64* out, unsigned char* ok) {
     size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
     if (i >= n) return;
@@ -392,16 +395,17 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_from_bytes(size_t n, const unsign
         const Fe y = fe_from_canonical<EQ>(yc);
         const Fe yy = EQ_SQR(y), one = fe_one<EQ>();
         const Fe u = fe_sub<EQ>(yy, one), v = fe_add<EQ>(EQ_MUL(ed_const(ED_D_MONT), yy), one);
-        const Fe w = EQ_MUL(u, fe_inv_fermat<EQ>(v));
-        u32 e[8], cy = 3;                               // (q + 3) / 8
+        // x = sqrt(u / v) with ONE exponentiation and no inversion (RFC 8032 section 5.1.3): x = u v^3 (u v^7)^((q - 5) / 8), then v x^2 == +-u
+        const Fe v2 = EQ_SQR(v), v3 = EQ_MUL(v2, v), v7 = EQ_MUL(EQ_SQR(v3), v);
+        u32 e[8], bw = 5;                               // (q - 5) / 8
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const u64 t = (u64)PQ::P(k) + cy; e[k] = (u32)t; cy = (u32)(t >> 32); }
+        for (int k = 0; k < 8; ++k) { const u32 pk = PQ::P(k); e[k] = pk - bw; bw = pk < bw ? 1u : 0u; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) e[k] = (e[k] >> 3) | (k < 7 ? e[k + 1] << 29 : 0u);
-        Fe x = eq_pow<8>(w, e);
-        const Fe xx = EQ_SQR(x);
-        if (!fe_eq(xx, w)) {
-            if (fe_eq(xx, fe_neg<EQ>(w))) x = EQ_MUL(x, ed_const(ED_SQRT_M1_MONT));
+        Fe x = EQ_MUL(EQ_MUL(u, v3), eq_pow<8>(EQ_MUL(u, v7), e));
+        const Fe vxx = EQ_MUL(v, EQ_SQR(x));
+        if (!fe_eq(vxx, u)) {
+            if (fe_eq(vxx, fe_neg<EQ>(u))) x = EQ_MUL(x, ed_const(ED_SQRT_M1_MONT));
             else valid = false;
         }
         const Fe nx = fe_neg<EQ>(x);
@@ -411,20 +415,31 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_from_bytes(size_t n, const unsign
         for (int k = 0; k < 8; ++k) { (void)__builtin_subc(nxc.v[k], xc.v[k], b2, &bo); b2 = bo; }     // borrows <=> x > -x
         Ed p;
         p.x = ((b2 != 0) == flag) ? x : nx; p.y = y; p.t = EQ_MUL(p.x, y); p.z = one;
-        // prime-order subgroup: [l]P == identity (x = 0, y = z)
-        Ed acc = ed_identity();
-        for (int limb = 7; limb >= 0; --limb) {
-            const u32 lw = PR::P(limb);
-            for (int bit = 31; bit >= 0; --bit) {
-                acc = ed_double(acc);
-                if ((lw >> bit) & 1u) acc = ed_add(acc, p);       // l is a constant: uniform control flow
+        if (CHECK) {                                    // prime-order subgroup: [l]P == identity (x = 0, y = z)
+            Ed acc = ed_identity();
+            for (int limb = 7; limb >= 0; --limb) {
+                const u32 lw = PR::P(limb);
+                for (int bit = 31; bit >= 0; --bit) {
+                    acc = ed_double(acc);
+                    if ((lw >> bit) & 1u) acc = ed_add(acc, p);       // l is a constant: uniform control flow
+                }
             }
+            valid = valid && fe_is_zero(acc.x) && fe_eq(acc.y, acc.z);
         }
-        valid = valid && fe_is_zero(acc.x) && fe_eq(acc.y, acc.z);
         if (valid) r = p;
     }
     ed_store(out + 16 * i, r);
     ok[i] = valid ? 1 : 0;
+}
+// prime-order subgroup test on decoded points (z = 1), given r = [l - 1] P from the scalar-mul pipeline: P is in the subgroup iff [l] P is the
+// identity iff r == -P, compared projectively (r.x == -x r.z, r.y == y r.z).  A point that fails becomes the identity with ok = 0.
+__global__ void __launch_bounds__(TPB_ED) k_ed_subgroup_verify(size_t n, const u64* r_pts, u64* pts, unsigned char* ok) {
+    size_t i = (size_t)blockIdx.x * TPB_ED + threadIdx.x;
+    if (i >= n) return;
+    if (!ok[i]) return;
+    const Ed p = ed_load(pts + 16 * i), r = ed_load(r_pts + 16 * i);
+    const bool good = fe_eq(r.x, fe_neg<EQ>(EQ_MUL(p.x, r.z))) && fe_eq(r.y, EQ_MUL(p.y, r.z)) && !fe_is_zero(r.z);
+    if (!good) { ed_store(pts + 16 * i, ed_identity()); ok[i] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -844,9 +859,21 @@ int arkmpc_ed_from_bytes(arkmpc_ctx* ctx, size_t n, const uint8_t* bytes, uint64
     ENTER_ED(ctx);
     Stage st(ctx);
     int ib = st.declare_in(bytes, n * 32), io = st.declare_out(out_points, n * 128), ik = st.declare_out(out_ok, n);
+    const bool asm_loop = ed_asm_enabled();
+    int iw = asm_loop ? st.declare_scratch(ed_smul_ws_bytes(n)) : -1, ir = asm_loop ? st.declare_scratch(n * 128 + 128) : -1;
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_ed_from_bytes, dim3(blocks_for(n, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, n, st.in<unsigned char>(ib), st.out<u64>(io),
-                              st.out<unsigned char>(ik));
+    const dim3 g(blocks_for(n, TPB_ED)), t(TPB_ED);
+    if (n && asm_loop) {
+        // decode without the subgroup loop, then [l - 1] P for all points through the hand-scheduled pipeline (one broadcast scalar) and compare with -P
+        hipLaunchKernelGGL(k_ed_from_bytes<false>, g, t, 0, ctx->stream, n, st.in<unsigned char>(ib), st.out<u64>(io), st.out<unsigned char>(ik));
+        u64* dkey = st.scratch<u64>(ir);
+        u64* rp = dkey + 16;
+        hipLaunchKernelGGL(k_ed_store_scalar, dim3(1), dim3(64), 0, ctx->stream, fe_neg<ER>(fe_one<ER>()), dkey);       // l - 1 in Montgomery form
+        ed_smul_launch(ctx, n, st.out<u64>(io), 16, 1, dkey, 0, 1, rp, st.scratch<char>(iw));
+        hipLaunchKernelGGL(k_ed_subgroup_verify, g, t, 0, ctx->stream, n, rp, st.out<u64>(io), st.out<unsigned char>(ik));
+    } else if (n) {
+        hipLaunchKernelGGL(k_ed_from_bytes<true>, g, t, 0, ctx->stream, n, st.in<unsigned char>(ib), st.out<u64>(io), st.out<unsigned char>(ik));
+    }
     return st.finish();
 }
 int arkmpc_ed_to_bytes(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint8_t* out_bytes) {
