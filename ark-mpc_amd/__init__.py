@@ -11,6 +11,7 @@ The directory name carries a hyphen, so import it with
 from .engine import (  # noqa: F401
     ArkMpcError,
     Engine,
+    Group,
     FIELD_IDS,
     FIELD_MODULI,
     lib_path,
@@ -18,4 +19,4 @@ from .engine import (  # noqa: F401
     exported_symbols,
 )
 
-__all__ = ["ArkMpcError", "Engine", "FIELD_IDS", "FIELD_MODULI", "lib_path", "load_library", "exported_symbols"]
+__all__ = ["ArkMpcError", "Engine", "Group", "FIELD_IDS", "FIELD_MODULI", "lib_path", "load_library", "exported_symbols"]

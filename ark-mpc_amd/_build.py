@@ -21,7 +21,7 @@ ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 HOST_CPP_SOURCES = ["keccak_avx512.cpp"]
-ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_curve.hip", "arkmpc_edwards.hip", "arkmpc_wire.hip", "arkmpc_batch.hip", "sha3_host.hip"]
+ENGINE_SOURCES = ["arkmpc_scalar.hip", "arkmpc_group.hip", "arkmpc_curve.hip", "arkmpc_edwards.hip", "arkmpc_wire.hip", "arkmpc_batch.hip", "sha3_host.hip"]
 # every header / include fragment in csrc (a stale .so after editing an .inc is the failure this guards against)
 ENGINE_DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".inc", ".hpp", ".json"))) + [os.path.join("..", "..", "include", "arkmpc.h")]
 

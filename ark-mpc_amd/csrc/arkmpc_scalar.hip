@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(TPB) k_share_extract(size_t n, const u64* a, u
 // K1: d_i = x_i.share - a_i.share ; e_i = y_i.share - b_i.share ; out = d || e  (:863-868, :141-145).
 // The MAC halves of d and e are dead in the reference (only `.share()` is sent), so they are not computed.
 template <int F, int NT>   // NT bit0: x,y non-temporal ; bit1: a,b non-temporal ; bit2: d||e stores non-temporal
-__global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col a, Col b, u64* out_de) {
+__global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col a, Col b, u64* out_d, u64* out_e) {
     size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     Fe xs = (NT & 1) ? fe_load_nt(x.p + (size_t)x.stride * i) : fe_load(x.p + (size_t)x.stride * i);
@@ -201,11 +201,11 @@ __global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col
     Fe ys = (NT & 1) ? fe_load_nt(y.p + (size_t)y.stride * i) : fe_load(y.p + (size_t)y.stride * i);
     Fe bs = (NT & 2) ? fe_load_nt(b.p + (size_t)b.stride * i) : fe_load(b.p + (size_t)b.stride * i);
     if (NT & 4) {
-        fe_store_nt(out_de + 4 * i, fe_sub<F>(xs, as));
-        fe_store_nt(out_de + 4 * (n + i), fe_sub<F>(ys, bs));
+        fe_store_nt(out_d + 4 * i, fe_sub<F>(xs, as));
+        fe_store_nt(out_e + 4 * i, fe_sub<F>(ys, bs));
     } else {
-        fe_store(out_de + 4 * i, fe_sub<F>(xs, as));
-        fe_store(out_de + 4 * (n + i), fe_sub<F>(ys, bs));
+        fe_store(out_d + 4 * i, fe_sub<F>(xs, as));
+        fe_store(out_e + 4 * i, fe_sub<F>(ys, bs));
     }
 }
 // K2: open_batch combine gate (:161-171)
@@ -217,17 +217,17 @@ __global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col
 // All sums are mod-p sums of canonical residues, so any association order is bit-identical to the
 // reference's ((db + de) + (ea + c)).
 template <int F, bool FUSED>
-__global__ void __launch_bounds__(TPB) k_beaver_finish(size_t n, int party, Fe key, const u64* de0, const u64* de1,
-                                                       const u64* e0, Col a_s, Col a_m, Col b_s, Col b_m, Col c_s, Col c_m,
+__global__ void __launch_bounds__(TPB) k_beaver_finish(size_t n, int party, Fe key, const u64* d0, const u64* e0, const u64* d1,
+                                                       const u64* e1, Col a_s, Col a_m, Col b_s, Col b_m, Col c_s, Col c_m,
                                                        ColOut o_s, ColOut o_m) {
     size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     Fe d, e;
-    if (FUSED) {  // de0 = my d||e, de1 = peer d||e
-        d = fe_add<F>(fe_load(de0 + 4 * i), fe_load(de1 + 4 * i));
-        e = fe_add<F>(fe_load(de0 + 4 * (n + i)), fe_load(de1 + 4 * (n + i)));
-    } else {  // de0 = opened d, e0 = opened e
-        d = fe_load(de0 + 4 * i);
+    if (FUSED) {  // d0, e0 = my d, e ; d1, e1 = the peer's
+        d = fe_add<F>(fe_load(d0 + 4 * i), fe_load(d1 + 4 * i));
+        e = fe_add<F>(fe_load(e0 + 4 * i), fe_load(e1 + 4 * i));
+    } else {  // d0 = opened d, e0 = opened e
+        d = fe_load(d0 + 4 * i);
         e = fe_load(e0 + 4 * i);
     }
     const Fe bs = fe_load(b_s.p + (size_t)b_s.stride * i), bm = fe_load(b_m.p + (size_t)b_m.stride * i);
@@ -374,18 +374,19 @@ static int k1_nt_mode() {
     return v;
 }
 template <int F>
-static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u64* out) {
+static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u64* out, u64* out_e = nullptr) {
+    if (!out_e) out_e = out + 4 * n;                     // d||e in one buffer unless the caller places e itself
     dim3 g(blocks_for(n, TPB)), t(TPB);
     const bool split = x.stride == 4 && y.stride == 4 && a.stride == 4 && b.stride == 4;
     static const int aos_mode = getenv("ARKMPC_K1_NT_AOS") ? atoi(getenv("ARKMPC_K1_NT_AOS")) & 7 : 0;
     switch (split ? k1_nt_mode() : aos_mode) {
-        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out); break;
-        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out); break;
-        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out); break;
-        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out); break;
-        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out); break;
-        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out); break;
-        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out); break;
+        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out, out_e); break;
+        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out, out_e); break;
+        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out, out_e); break;
+        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out, out_e); break;
+        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out, out_e); break;
+        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out, out_e); break;
+        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out, out_e); break;
     }
 }
 
@@ -399,7 +400,10 @@ static bool use_asm_path() {
 // triple columns share a stride; otherwise the C++ kernel.
 template <int F>
 static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& k, const u64* my_de, const u64* peer_de, Col a_s, Col a_m,
-                                Col b_s, Col b_m, Col c_s, Col c_m, ColOut o_s, ColOut o_m) {
+                                Col b_s, Col b_m, Col c_s, Col c_m, ColOut o_s, ColOut o_m, const u64* my_e = nullptr, const u64* peer_e = nullptr) {
+    const u64* my_d = my_de; const u64* peer_d = peer_de;
+    if (!my_e) my_e = my_de + 4 * n;                     // d||e in one buffer unless the caller addresses e itself (a range of a larger batch)
+    if (!peer_e) peer_e = peer_de + 4 * n;
     if constexpr (HasAsmFinish<F>::value) {
         // the hand-scheduled body addresses with 32-bit byte offsets inside a chunk of 2^25 gates: (2^25 - 1) * stride * 8 fits only
         // for strides up to 16 u64 (AoS = 8, split = 4); wider views take the 64-bit C++ kernel below
@@ -415,23 +419,23 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                 const bool aos_records = a_s.stride == 8 && o_s.stride == 8 && a_m.p == a_s.p + 4 && b_m.p == b_s.p + 4 && c_m.p == c_s.p + 4 &&
                                          o_m.p == o_s.p + 4;
                 if (aos_records && aos_lds) {
-                    launch_k(ctx, k_beaver_finish_asm_aos<F>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_de + 4 * lo,
-                             my_de + 4 * (n + lo), peer_de + 4 * lo, peer_de + 4 * (n + lo), a_s.p + cs, b_s.p + cs, c_s.p + cs, o_s.p + os);
+                    launch_k(ctx, k_beaver_finish_asm_aos<F>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_d + 4 * lo,
+                             my_e + 4 * lo, peer_d + 4 * lo, peer_e + 4 * lo, a_s.p + cs, b_s.p + cs, c_s.p + cs, o_s.p + os);
                     continue;
                 }
                 if (a_s.stride == 4 && o_s.stride == 4 && k3_nt)
                     launch_k(ctx, k_beaver_finish_asm<F, 1>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k,
-                                       my_de + 4 * lo, my_de + 4 * (n + lo), peer_de + 4 * lo, peer_de + 4 * (n + lo), a_s.p + cs, a_m.p + cs,
+                                       my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo, peer_e + 4 * lo, a_s.p + cs, a_m.p + cs,
                                        b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u, o_s.stride * 8u);
                 else
                     launch_k(ctx, k_beaver_finish_asm<F, 0>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k,
-                                       my_de + 4 * lo, my_de + 4 * (n + lo), peer_de + 4 * lo, peer_de + 4 * (n + lo), a_s.p + cs, a_m.p + cs,
+                                       my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo, peer_e + 4 * lo, a_s.p + cs, a_m.p + cs,
                                        b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u, o_s.stride * 8u);
             }
             return;
         }
     }
-    launch_k(ctx, k_beaver_finish<F, true>, dim3(blocks_for(n, TPB)), dim3(TPB), n, party, k, my_de, peer_de, (const u64*)nullptr, a_s, a_m,
+    launch_k(ctx, k_beaver_finish<F, true>, dim3(blocks_for(n, TPB)), dim3(TPB), n, party, k, my_d, my_e, peer_d, peer_e, a_s, a_m,
              b_s, b_m, c_s, c_m, o_s, o_m);
 }
 
@@ -938,7 +942,7 @@ int arkmpc_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t
         const u64 *pa = st.in<u64>(ia), *pb = st.in<u64>(ib), *pc = st.in<u64>(ic);
         u64* po = st.out<u64>(io);
         DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_finish<F, false>), g, t, 0, ctx->stream, n, party_id, k, st.in<u64>(id),
-                                               (const u64*)nullptr, st.in<u64>(ie), Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8}, Col{pb + 4, 8},
+                                               st.in<u64>(ie), (const u64*)nullptr, (const u64*)nullptr, Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8}, Col{pb + 4, 8},
                                                Col{pc, 8}, Col{pc + 4, 8}, ColOut{po, 8}, ColOut{po + 4, 8}));
     }
     return st.finish();
@@ -987,6 +991,50 @@ int arkmpc_beaver_finish_fused_v(arkmpc_ctx* ctx, size_t n, int party_id, const 
                                                    Col{c_mac, (u32)c_stride}, ColOut{out_share, (u32)out_stride}, ColOut{out_mac, (u32)out_stride}));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { ark_set_err(ctx, hipGetErrorString(le)); return ARKMPC_ERR_HIP; }
+    }
+    return ARKMPC_OK;
+}
+
+// Range forms: the gates [lo, lo + n) of a larger batch.  d and e are addressed separately, so a shard can write its slice of the
+// FULL d||e buffer (d at +4 lo, e at +4 (N + lo)) -- on its own device or, with peer access, straight into another device's
+// buffer -- and read the peer party's slice from wherever it lies.  This is what the multi-device group (arkmpc_group.hip) and the
+// one-process-per-GPU sharding launch per device.
+int arkmpc_beaver_mask_to(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share, size_t y_stride,
+                          const uint64_t* a_share, size_t a_stride, const uint64_t* b_share, size_t b_stride, uint64_t* out_d, uint64_t* out_e) {
+    ENTER(ctx);
+    if (!stride_ok(x_stride) || !stride_ok(y_stride) || !stride_ok(a_stride) || !stride_ok(b_stride)) return ark_bad(ctx, "bad stride");
+    if (ctx->host_buffers) return ark_bad(ctx, "range entry points take device pointers only");
+    if (n && (!x_share || !y_share || !a_share || !b_share || !out_d || !out_e)) return ark_bad(ctx, "null pointer");
+    if (((uintptr_t)x_share | (uintptr_t)y_share | (uintptr_t)a_share | (uintptr_t)b_share | (uintptr_t)out_d | (uintptr_t)out_e) & 15)
+        return ark_bad(ctx, "device pointer not 16-byte aligned");
+    if (n) {
+        Col x{x_share, (u32)x_stride}, y{y_share, (u32)y_stride}, a{a_share, (u32)a_stride}, b{b_share, (u32)b_stride};
+        DISPATCH_FIELD(ctx, launch_mask<F>(ctx, n, x, y, a, b, out_d, out_e));
+        ARK_HIP(ctx, hipGetLastError());
+    }
+    return ARKMPC_OK;
+}
+int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* my_d, const uint64_t* my_e,
+                                    const uint64_t* peer_d, const uint64_t* peer_e, const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                                    const uint64_t* b_share, const uint64_t* b_mac, size_t b_stride, const uint64_t* c_share,
+                                    const uint64_t* c_mac, size_t c_stride, uint64_t* out_share, uint64_t* out_mac, size_t out_stride) {
+    ENTER(ctx);
+    if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (!mac_key) return ark_bad(ctx, "null mac_key");
+    if (!stride_ok(a_stride) || !stride_ok(b_stride) || !stride_ok(c_stride) || !stride_ok(out_stride)) return ark_bad(ctx, "bad stride");
+    if (ctx->host_buffers) return ark_bad(ctx, "range entry points take device pointers only");
+    if (n && (!my_d || !my_e || !peer_d || !peer_e || !a_share || !a_mac || !b_share || !b_mac || !c_share || !c_mac || !out_share || !out_mac))
+        return ark_bad(ctx, "null pointer");
+    if (((uintptr_t)my_d | (uintptr_t)my_e | (uintptr_t)peer_d | (uintptr_t)peer_e | (uintptr_t)a_share | (uintptr_t)a_mac | (uintptr_t)b_share |
+         (uintptr_t)b_mac | (uintptr_t)c_share | (uintptr_t)c_mac | (uintptr_t)out_share | (uintptr_t)out_mac) & 15)
+        return ark_bad(ctx, "device pointer not 16-byte aligned");
+    if (n) {
+        Fe k = fe_from_host(mac_key);
+        DISPATCH_FIELD(ctx, launch_finish_fused<F>(ctx, n, party_id, k, my_d, peer_d, Col{a_share, (u32)a_stride}, Col{a_mac, (u32)a_stride},
+                                                   Col{b_share, (u32)b_stride}, Col{b_mac, (u32)b_stride}, Col{c_share, (u32)c_stride},
+                                                   Col{c_mac, (u32)c_stride}, ColOut{out_share, (u32)out_stride}, ColOut{out_mac, (u32)out_stride},
+                                                   my_e, peer_e));
+        ARK_HIP(ctx, hipGetLastError());
     }
     return ARKMPC_OK;
 }
@@ -1059,8 +1107,11 @@ static int mac_verify_collect(arkmpc_ctx* ctx, int* out_ok) {
     const int failed = __atomic_load_n(ctx->h_vflag, __ATOMIC_ACQUIRE);
     *out_ok = failed == 0 ? 1 : 0;
     if (failed) {
-        __atomic_store_n(ctx->h_vflag, 0, __ATOMIC_RELEASE);
+        // re-open the device-side gate FIRST: were the host flag cleared and the memset then to fail, the gate would stay shut with the
+        // flag at 0 and every later failed verification on this context would go unreported (fail-open).  On error the flag stays set.
         ARK_HIP(ctx, hipMemsetAsync(ctx->d_vgate, 0, sizeof(int), ctx->stream));
+        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        __atomic_store_n(ctx->h_vflag, 0, __ATOMIC_RELEASE);
     }
     return ARKMPC_OK;
 }

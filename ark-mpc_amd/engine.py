@@ -313,6 +313,146 @@ class Engine:
     def edshare_sum(self, n, shares, out): self.call("edshare_sum", ("size", n), shares, out)
 
 
+class Group:
+    """arkmpc_group: ONE process, G members (device ids may repeat).  Sharded vectors are lists of G device pointers (ints or torch
+    tensors living on the member's device); see include/arkmpc.h for the segment convention."""
+
+    AOS, SPLIT = 0, 1
+
+    def __init__(self, field, device_ids):
+        self.lib = load_library()
+        self.lib.arkmpc_group_last_error.restype = ctypes.c_char_p
+        self.lib.arkmpc_group_ctx.restype = ctypes.c_void_p
+        self.field_id = FIELD_IDS[field] if isinstance(field, str) else int(field)
+        ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = ctypes.c_void_p()
+        rc = self.lib.arkmpc_group_create(self.field_id, len(device_ids), ids, ctypes.byref(h))
+        if rc != 0:
+            raise ArkMpcError("arkmpc_group_create failed with status %d (no GPU => no engine; there is no CPU fallback)" % rc)
+        self.h = h
+        self.G = len(device_ids)
+        self.devices = [int(d) for d in device_ids]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.arkmpc_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self.lib.arkmpc_group_last_error(self.h)
+            raise ArkMpcError("arkmpc group status %d: %s" % (rc, msg.decode() if msg else ""))
+
+    def _sh(self, shards):
+        if len(shards) != self.G:
+            raise ArkMpcError("a sharded vector has one pointer per member")
+        return (ctypes.c_void_p * self.G)(*[_ptr(x).value or 0 for x in shards])
+
+    def shard_range(self, n, member):
+        lo, cnt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._ck(self.lib.arkmpc_group_shard_range(self.h, ctypes.c_size_t(int(n)), int(member), ctypes.byref(lo), ctypes.byref(cnt)))
+        return int(lo.value), int(cnt.value)
+
+    def peer_access(self, a, b):
+        return bool(self.lib.arkmpc_group_peer_access(self.h, int(a), int(b)))
+
+    def member_ctx(self, member):
+        return ctypes.c_void_p(self.lib.arkmpc_group_ctx(self.h, int(member)))
+
+    def sync(self):
+        self._ck(self.lib.arkmpc_group_sync(self.h))
+
+    def malloc(self, n, segs, elem_words):
+        out = (ctypes.c_void_p * self.G)()
+        self._ck(self.lib.arkmpc_group_malloc(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(int(segs)), ctypes.c_size_t(int(elem_words)), out))
+        return [int(v or 0) for v in out]
+
+    def free(self, shards):
+        self._ck(self.lib.arkmpc_group_free(self.h, self._sh(shards)))
+
+    def scatter_h2d(self, n, segs, ew, host, shards):
+        self._ck(self.lib.arkmpc_group_scatter_h2d(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(int(segs)), ctypes.c_size_t(int(ew)), _ptr(host), self._sh(shards)))
+
+    def gather_d2h(self, n, segs, ew, shards, host):
+        self._ck(self.lib.arkmpc_group_gather_d2h(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(int(segs)), ctypes.c_size_t(int(ew)), self._sh(shards), _ptr(host)))
+
+    def shares_from_host(self, layout, n, host_records, shards):
+        self._ck(self.lib.arkmpc_group_shares_from_host(self.h, int(layout), ctypes.c_size_t(int(n)), _ptr(host_records), self._sh(shards)))
+
+    def shares_to_host(self, layout, n, shards, host_records):
+        self._ck(self.lib.arkmpc_group_shares_to_host(self.h, int(layout), ctypes.c_size_t(int(n)), self._sh(shards), _ptr(host_records)))
+
+    def gather(self, n, segs, ew, shards, root, out_on_root):
+        self._ck(self.lib.arkmpc_group_gather(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(int(segs)), ctypes.c_size_t(int(ew)), self._sh(shards), int(root), _ptr(out_on_root)))
+
+    def allgather(self, n, segs, ew, shards, outs):
+        self._ck(self.lib.arkmpc_group_allgather(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(int(segs)), ctypes.c_size_t(int(ew)), self._sh(shards), self._sh(outs)))
+
+    def scatter(self, n, segs, ew, src_on_root, root, shards):
+        self._ck(self.lib.arkmpc_group_scatter(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(int(segs)), ctypes.c_size_t(int(ew)), _ptr(src_on_root), int(root), self._sh(shards)))
+
+    def beaver_mask(self, layout, n, x, y, a, b, out_de):
+        self._ck(self.lib.arkmpc_group_beaver_mask(self.h, int(layout), ctypes.c_size_t(int(n)), self._sh(x), self._sh(y), self._sh(a), self._sh(b), self._sh(out_de)))
+
+    def beaver_mask_gathered(self, layout, n, x, y, a, b, root, out_de_on_root):
+        self._ck(self.lib.arkmpc_group_beaver_mask_gathered(self.h, int(layout), ctypes.c_size_t(int(n)), self._sh(x), self._sh(y), self._sh(a), self._sh(b), int(root),
+                                                            _ptr(out_de_on_root)))
+
+    def beaver_finish_fused(self, layout, n, party, key, my_de, peer_de, a, b, c, out):
+        arr, kp = _key(key)
+        self._ck(self.lib.arkmpc_group_beaver_finish_fused(self.h, int(layout), ctypes.c_size_t(int(n)), int(party), kp, self._sh(my_de), self._sh(peer_de), self._sh(a),
+                                                           self._sh(b), self._sh(c), self._sh(out)))
+
+    def prepare_beaver(self, layout, n, party, key, x, y, a, b, c, my_de, peer_de, out):
+        """Pre-marshalled K1 and K2+K3 group calls (replayed in timing loops)."""
+        arr, kp = _key(key)
+        lib, h = self.lib, self.h
+        a1 = (h, int(layout), ctypes.c_size_t(int(n)), self._sh(x), self._sh(y), self._sh(a), self._sh(b), self._sh(my_de))
+        a3 = (h, int(layout), ctypes.c_size_t(int(n)), int(party), kp, self._sh(my_de), self._sh(peer_de), self._sh(a), self._sh(b), self._sh(c), self._sh(out))
+        ck = self._ck
+
+        def k1(_a=a1, _keep=arr):
+            rc = lib.arkmpc_group_beaver_mask(*_a)
+            if rc:
+                ck(rc)
+
+        def k3(_a=a3, _keep=arr):
+            rc = lib.arkmpc_group_beaver_finish_fused(*_a)
+            if rc:
+                ck(rc)
+        return k1, k3
+
+    def share_extract(self, layout, n, shares, out_values):
+        self._ck(self.lib.arkmpc_group_share_extract(self.h, int(layout), ctypes.c_size_t(int(n)), self._sh(shares), self._sh(out_values)))
+
+    def open_and_mac_check(self, layout, n, key, shares, peer_values, out_opened, out_chk):
+        arr, kp = _key(key)
+        self._ck(self.lib.arkmpc_group_open_and_mac_check(self.h, int(layout), ctypes.c_size_t(int(n)), kp, self._sh(shares), self._sh(peer_values), self._sh(out_opened),
+                                                          self._sh(out_chk)))
+
+    def mac_verify(self, n, mine, peer):
+        ok = ctypes.c_int(-1)
+        self._ck(self.lib.arkmpc_group_mac_verify(self.h, ctypes.c_size_t(int(n)), self._sh(mine), self._sh(peer), ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def commit_sha3(self, n, values, blinder):
+        out = np.zeros(4, dtype=np.uint64)
+        arr, kp = _key(blinder)
+        self._ck(self.lib.arkmpc_group_commit_sha3(self.h, ctypes.c_size_t(int(n)), self._sh(values), kp, ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def g1_msm(self, n, points, scalars):
+        out = np.zeros(12, dtype=np.uint64)
+        self._ck(self.lib.arkmpc_group_g1_msm(self.h, ctypes.c_size_t(int(n)), self._sh(points), self._sh(scalars), ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+
 def sha3_256(data: bytes) -> bytes:
     lib = load_library()
     out = (ctypes.c_uint8 * 32)()

@@ -198,6 +198,19 @@ int arkmpc_beaver_finish_fused_v(arkmpc_ctx* ctx, size_t n, int party_id, const 
                                  const uint64_t* c_share, const uint64_t* c_mac, size_t c_stride,
                                  uint64_t* out_share, uint64_t* out_mac, size_t out_stride);
 
+/* range forms: gates [lo, lo + n) of a larger batch of N.  d and e are addressed separately, so a shard writes its slice of the FULL
+ * d||e buffer (out_d = full + 4 lo, out_e = full + 4 (N + lo)) -- on its own device or, with peer access, in another device's memory --
+ * and K2+K3 reads the two parties' d / e slices from wherever they lie.  Device pointers only. */
+int arkmpc_beaver_mask_to(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share,
+                          size_t y_stride, const uint64_t* a_share, size_t a_stride, const uint64_t* b_share, size_t b_stride,
+                          uint64_t* out_d, uint64_t* out_e);
+int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
+                                    const uint64_t* my_d, const uint64_t* my_e, const uint64_t* peer_d, const uint64_t* peer_e,
+                                    const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                                    const uint64_t* b_share, const uint64_t* b_mac, size_t b_stride,
+                                    const uint64_t* c_share, const uint64_t* c_mac, size_t c_stride,
+                                    uint64_t* out_share, uint64_t* out_mac, size_t out_stride);
+
 /* ---- batch open + MAC check, authenticated_scalar.rs:278-354 ------------------------------- */
 /* the `.share()` projection sent by open_batch (:141-145): n ScalarShares -> n Scalars */
 int arkmpc_share_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share_values);
@@ -365,6 +378,77 @@ int arkmpc_wire_decode_scalar_batch(arkmpc_ctx* ctx, const uint8_t* frame, size_
 /* Parse a ScalarBatch / PointBatch frame into raw 32-byte records; *out_kind = ARKMPC_WIRE_* */
 int arkmpc_wire_decode_bytes32(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, uint8_t* out_records, size_t* out_n,
                                uint64_t* out_result_id, int* out_kind);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Multi-device group: ONE process drives N GPUs of one node (csrc/arkmpc_group.hip).
+ * A party of the reference is one process (MpcFabric::new, fabric.rs:402-466), so the 8-GPU form of the path has to live behind
+ * the FFI: a group owns one context (device + stream) per member and range-shards every batch of n independent gates as
+ * member g <- [g*n/G, (g+1)*n/G) (authenticated_scalar.rs:677-687, :904-913: element i depends on element i only).  No collective
+ * in the arithmetic.  Device ids may repeat (members then share a GPU): that is how the path is tested on a one-GPU box.
+ *
+ * A SHARDED VECTOR is an array of G device pointers; member g's pointer addresses `segs` consecutive segments of cnt_g elements on
+ * ITS device:  Scalars: 1 segment of 4 words;  d||e: 2 segments of 4 words (d_g then e_g);  ScalarShares in ARKMPC_LAYOUT_AOS:
+ * 1 segment of 8 words;  in ARKMPC_LAYOUT_SPLIT: 2 segments of 4 words (share column, then MAC column).  The corresponding FULL
+ * vector (host or one device) is `segs` segments of n elements.
+ *
+ * Ordering: group calls enqueue on the members' streams and return (unless noted "blocks"); work of one member is ordered by its
+ * stream, cross-member movement by events the group inserts.  Group calls are serialised by a group mutex; the member contexts
+ * (arkmpc_group_ctx) remain usable with every single-device entry point above. */
+typedef struct arkmpc_group arkmpc_group;
+int arkmpc_group_create(int field_id, int n_devices, const int* device_ids, arkmpc_group** out_group);
+int arkmpc_group_destroy(arkmpc_group* grp);
+int arkmpc_group_size(const arkmpc_group* grp);
+int arkmpc_group_device(const arkmpc_group* grp, int member);
+arkmpc_ctx* arkmpc_group_ctx(arkmpc_group* grp, int member);
+/* member's index range of a batch of n: lo = member*n/G, count = (member+1)*n/G - lo (= ark-mpc_amd/sharding.py shard_range) */
+int arkmpc_group_shard_range(const arkmpc_group* grp, size_t n, int member, size_t* out_lo, size_t* out_count);
+/* 1 if member `from` can address member `to`'s memory (same device, or xGMI peer mapping enabled at group creation) */
+int arkmpc_group_peer_access(const arkmpc_group* grp, int from_member, int to_member);
+int arkmpc_group_sync(arkmpc_group* grp);                       /* blocks until every member's stream has drained */
+const char* arkmpc_group_last_error(arkmpc_group* grp);
+/* sharded storage: out_shards / shards = arrays of G pointers */
+int arkmpc_group_malloc(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, uint64_t** out_shards);
+int arkmpc_group_free(arkmpc_group* grp, uint64_t* const* shards);
+/* host full vector <-> shards; every member's DMA runs on its own stream / PCIe link; blocks */
+int arkmpc_group_scatter_h2d(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, const uint64_t* host, uint64_t* const* shards);
+int arkmpc_group_gather_d2h(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, const uint64_t* const* shards, uint64_t* host);
+/* host Vec<ScalarShare> (n arkworks records) <-> sharded ScalarShare vector in `layout`; blocks */
+int arkmpc_group_shares_from_host(arkmpc_group* grp, int layout, size_t n, const uint64_t* host_records, uint64_t* const* shards);
+int arkmpc_group_shares_to_host(arkmpc_group* grp, int layout, size_t n, const uint64_t* const* shards, uint64_t* host_records);
+/* device <-> device over xGMI as DIRECT PEER WRITES (no ring): gather = every member pushes its range into the full buffer on
+ * member `root`; allgather = every member pushes its range into every member's full buffer (G*(G-1) point-to-point copies, all
+ * links busy at once); scatter = root pushes each member its range of a full buffer.  The consumers' streams wait on the device. */
+int arkmpc_group_gather(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, const uint64_t* const* shards, int root_member,
+                        uint64_t* out_on_root);
+int arkmpc_group_allgather(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, const uint64_t* const* shards, uint64_t* const* outs);
+int arkmpc_group_scatter(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, const uint64_t* src_on_root, int root_member,
+                         uint64_t* const* shards);
+/* Beaver multiplication, range-sharded (authenticated_scalar.rs:848-879): x, y, a, b, c, out = sharded ScalarShare vectors in
+ * `layout`; my_de / peer_de / out_de = sharded d||e vectors.  In a two-party deployment the d||e payload leaves through
+ * arkmpc_group_gather_d2h and the peer's arrives through arkmpc_group_scatter_h2d; two in-process parties built on the same devices
+ * hand each other their shard pointers member by member (the device form of network/mock.rs). */
+int arkmpc_group_beaver_mask(arkmpc_group* grp, int layout, size_t n, const uint64_t* const* x, const uint64_t* const* y,
+                             const uint64_t* const* a, const uint64_t* const* b, uint64_t* const* out_de);
+/* K1 whose stores ARE the gather: every member's kernel writes its d / e range straight into the full 2n-Scalar buffer on `root`
+ * through the peer mapping.  ARKMPC_ERR_UNSUPPORTED without peer access to root (use _mask + _gather). */
+int arkmpc_group_beaver_mask_gathered(arkmpc_group* grp, int layout, size_t n, const uint64_t* const* x, const uint64_t* const* y,
+                                      const uint64_t* const* a, const uint64_t* const* b, int root_member, uint64_t* out_de_on_root);
+int arkmpc_group_beaver_finish_fused(arkmpc_group* grp, int layout, size_t n, int party_id, const uint64_t mac_key[4],
+                                     const uint64_t* const* my_de, const uint64_t* const* peer_de, const uint64_t* const* a,
+                                     const uint64_t* const* b, const uint64_t* const* c, uint64_t* const* out);
+/* batch open + MAC check, range-sharded (authenticated_scalar.rs:278-354) */
+int arkmpc_group_share_extract(arkmpc_group* grp, int layout, size_t n, const uint64_t* const* shares, uint64_t* const* out_values);
+int arkmpc_group_open_and_mac_check(arkmpc_group* grp, int layout, size_t n, const uint64_t mac_key[4], const uint64_t* const* shares,
+                                    const uint64_t* const* peer_values, uint64_t* const* out_opened, uint64_t* const* out_chk);
+/* K5 on every range, one synchronisation per member, AND of the members' flags; blocks */
+int arkmpc_group_mac_verify(arkmpc_group* grp, size_t n, const uint64_t* const* mine, const uint64_t* const* peer, int* out_ok);
+/* H1 over a sharded Scalar vector: the sponge absorbs member 0's range, then member 1's, ... (= the full vector in index order);
+ * each member converts and DMAs its own range to pinned host memory, so no device gather is needed; blocks */
+int arkmpc_group_commit_sha3(arkmpc_group* grp, size_t n, const uint64_t* const* values, const uint64_t blinder[4],
+                             uint64_t out_commitment[4]);
+/* CurvePoint::msm over sharded (point, scalar) pairs (curve.rs:549-560): one bucket MSM per member, the G partial points added on
+ * member 0; out_point = HOST pointer to 12 x u64; blocks.  BN254 groups only. */
+int arkmpc_group_g1_msm(arkmpc_group* grp, size_t n, const uint64_t* const* points, const uint64_t* const* scalars, uint64_t out_point[12]);
 
 #ifdef __cplusplus
 }
