@@ -113,6 +113,25 @@ int arkmpc_batch_slice(arkmpc_ctx* ctx, arkmpc_batch* b, size_t lo, size_t count
     return ARKMPC_OK;
 }
 
+int arkmpc_batch_column(arkmpc_ctx* ctx, arkmpc_batch* b, int which, arkmpc_batch** out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (!out) return ark_bad(ctx, "null out");
+    *out = nullptr;
+    int rc = batch_check(ctx, b);
+    if (rc) return rc;
+    if (b->kind != ARKMPC_KIND_SCALAR_SHARE || (which != 0 && which != 1)) return ark_bad(ctx, "column of a ScalarShare batch: which = 0 (share) or 1 (MAC)");
+    if (b->layout != ARKMPC_LAYOUT_SPLIT) { ark_set_err(ctx, "columns of an AoS batch are strided: use arkmpc_share_extract"); return ARKMPC_ERR_UNSUPPORTED; }
+    arkmpc_batch* s = new arkmpc_batch();
+    s->kind = ARKMPC_KIND_SCALAR; s->layout = ARKMPC_LAYOUT_AOS; s->field_id = b->field_id; s->device = b->device; s->n = b->n; s->words = 4;
+    s->stride = 4;
+    s->share = which ? b->mac : b->share;
+    arkmpc_batch* owner = b->parent ? b->parent : b;
+    owner->refs.fetch_add(1, std::memory_order_relaxed);
+    s->parent = owner;
+    *out = s;
+    return ARKMPC_OK;
+}
+
 size_t arkmpc_batch_len(const arkmpc_batch* b) { return b ? b->n : 0; }
 int arkmpc_batch_kind(const arkmpc_batch* b) { return b ? b->kind : -1; }
 int arkmpc_batch_layout(const arkmpc_batch* b) { return b ? b->layout : -1; }
@@ -212,7 +231,7 @@ namespace {
 struct Tmp {
     arkmpc_ctx* ctx; void* p = nullptr; int rc = ARKMPC_OK;
     Tmp(arkmpc_ctx* c, size_t bytes) : ctx(c) {
-        if (c->host_buffers) { p = std::malloc(bytes ? bytes : 16); if (!p) rc = ARKMPC_ERR_BAD_ARG; }
+        if (c->host_buffers) { p = std::malloc(bytes ? bytes : 16); if (!p) { ark_set_err(c, "out of host memory for a temporary of the composite gate"); rc = ARKMPC_ERR_BAD_ARG; } }
         else rc = arkmpc_malloc(c, bytes ? bytes : 16, &p);
     }
     ~Tmp() { if (p) { if (ctx->host_buffers) std::free(p); else arkmpc_free(ctx, p); } }
@@ -228,6 +247,7 @@ int point_beaver_finish(arkmpc_ctx* ctx, size_t n, int party, const uint64_t key
     if (!key) return ark_bad(ctx, "null mac_key");
     if (n && (!d || !eG || !a || !b || !c || !out)) return ark_bad(ctx, "null buffer");
     if (!n) return ARKMPC_OK;
+    if (n > (((size_t)1 << 48) / (2 * pw))) return ark_bad(ctx, "batch too large");           // the guard of arkmpc_batch_create: n * 2 * pw * 8 cannot wrap
     Tmp on_eG(ctx, n * 64), on_G(ctx, n * 64), t1(ctx, n * 2 * pw * 8);
     if (on_eG.rc || on_G.rc || t1.rc) return on_eG.rc ? on_eG.rc : (on_G.rc ? on_G.rc : t1.rc);
     int rc = arkmpc_share_add_public(ctx, n, party, key, a, d, on_eG.u());                     // [a] + d

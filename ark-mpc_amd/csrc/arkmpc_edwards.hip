@@ -567,22 +567,31 @@ static int ed_gen_table(arkmpc_ctx* ctx, const u64** out) {
     if (dev < 0 || dev >= 16) return ark_bad(ctx, "device index");
     std::lock_guard<std::mutex> lk(g_ed_gen_mu);
     if (!g_ed_gen_table[dev]) {
-        u64 *bases = nullptr, *table = nullptr;
-        ARK_HIP(ctx, hipMalloc((void**)&bases, EDG_WINDOWS * 128));
-        ARK_HIP(ctx, hipMalloc((void**)&table, (size_t)EDG_WINDOWS * EDG_ENTRIES * 96));
-        hipLaunchKernelGGL(k_ed_gen_table_bases, dim3(1), dim3(64), 0, ctx->stream, bases);
-        hipLaunchKernelGGL(k_ed_gen_table_fill, dim3(blocks_for(EDG_WINDOWS * EDG_ENTRIES, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, bases, table);
-        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ARK_HIP(ctx, hipFree(bases));
-        g_ed_gen_table[dev] = table;
-        u64* t2 = nullptr;
-        ARK_HIP(ctx, hipMalloc((void**)&bases, ED_GEN_ASM_WINDOWS * 128));
-        ARK_HIP(ctx, hipMalloc((void**)&t2, (size_t)ED_GEN_ASM_WINDOWS * ED_GEN_ASM_ENTRIES * 96));
-        hipLaunchKernelGGL(k_ed_gen2_bases, dim3(1), dim3(64), 0, ctx->stream, bases);
-        hipLaunchKernelGGL(k_ed_gen2_fill, dim3(blocks_for(ED_GEN_ASM_WINDOWS * ED_GEN_ASM_ENTRIES, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, bases, t2);
-        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ARK_HIP(ctx, hipFree(bases));
+        // both tables are built into locals and published together: a failure half way must not leave g_ed_gen_table set with
+        // g_ed_gen2_table null (later calls would skip this block and launch the generator chain on a null table)
+        u64 *b1 = nullptr, *b2 = nullptr, *t1 = nullptr, *t2 = nullptr;
+        hipError_t e = hipMalloc((void**)&b1, EDG_WINDOWS * 128);
+        if (e == hipSuccess) e = hipMalloc((void**)&t1, (size_t)EDG_WINDOWS * EDG_ENTRIES * 96);
+        if (e == hipSuccess) e = hipMalloc((void**)&b2, ED_GEN_ASM_WINDOWS * 128);
+        if (e == hipSuccess) e = hipMalloc((void**)&t2, (size_t)ED_GEN_ASM_WINDOWS * ED_GEN_ASM_ENTRIES * 96);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_ed_gen_table_bases, dim3(1), dim3(64), 0, ctx->stream, b1);
+            hipLaunchKernelGGL(k_ed_gen_table_fill, dim3(blocks_for(EDG_WINDOWS * EDG_ENTRIES, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, b1, t1);
+            hipLaunchKernelGGL(k_ed_gen2_bases, dim3(1), dim3(64), 0, ctx->stream, b2);
+            hipLaunchKernelGGL(k_ed_gen2_fill, dim3(blocks_for(ED_GEN_ASM_WINDOWS * ED_GEN_ASM_ENTRIES, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, b2, t2);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        if (b1) (void)hipFree(b1);
+        if (b2) (void)hipFree(b2);
+        if (e != hipSuccess) {
+            if (t1) (void)hipFree(t1);
+            if (t2) (void)hipFree(t2);
+            ark_set_err(ctx, std::string("generator tables: ") + hipGetErrorString(e));
+            return ARKMPC_ERR_HIP;
+        }
         g_ed_gen2_table[dev] = t2;
+        g_ed_gen_table[dev] = t1;
     }
     *out = g_ed_gen_table[dev];
     return ARKMPC_OK;

@@ -143,6 +143,33 @@ __global__ void __launch_bounds__(TPB) k_scan_apply(size_t n, u64* out, const u6
     fe_store(out + 4 * i, fe_mul<F>(fe_load(scanned_totals + 4 * (blk - 1)), fe_load(out + 4 * i)));
 }
 
+// Reductions: Sum for ScalarShare / AuthenticatedScalarResult (share.rs:103-111, authenticated_scalar.rs:563-575: component-wise sums of
+// shares and MACs) and Sum / Product for ScalarResult (scalar_result.rs:325-338; Iterator::sum over Scalars).  Field addition and
+// multiplication are associative and commutative and results are canonical residues, so any tree gives the reference's value bit for
+// bit.  Level 1: a grid-strided fold per thread and an LDS tree per workgroup -> one partial per workgroup; level 2: one workgroup over
+// the partials.  blockIdx.y selects the column of a strided record (ScalarShare records: column 0 = shares, 1 = MACs).
+#define RED_MAX_BLOCKS 1024
+template <int F, int OP>   // OP_ADD or OP_MUL
+__global__ void __launch_bounds__(TPB) k_reduce(size_t n, const u64* in, u32 stride, u32 col_off, u64* out, u32 out_stride) {
+    __shared__ u64 sm[TPB * 4];
+    const u64* src = in + (size_t)blockIdx.y * col_off;
+    Fe acc = (OP == OP_MUL) ? fe_one<F>() : fe_zero<F>();
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) {
+        const Fe v = fe_load(src + (size_t)stride * i);
+        acc = (OP == OP_MUL) ? fe_mul<F>(acc, v) : fe_add<F>(acc, v);
+    }
+    fe_store(sm + 4 * threadIdx.x, acc);
+    __syncthreads();
+    for (int off = TPB / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < (unsigned)off) {
+            const Fe a = fe_load(sm + 4 * threadIdx.x), b = fe_load(sm + 4 * (threadIdx.x + off));
+            fe_store(sm + 4 * threadIdx.x, (OP == OP_MUL) ? fe_mul<F>(a, b) : fe_add<F>(a, b));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fe_store(out + (size_t)out_stride * blockIdx.x + (size_t)blockIdx.y * 4, fe_load(sm));
+}
+
 // ---------------------------------------------------------------------------------------------
 // ScalarShare kernels (share.rs:72-133)
 // ---------------------------------------------------------------------------------------------
@@ -166,6 +193,23 @@ __global__ void __launch_bounds__(TPB) k_share_addsub_public_flat(size_t m, int 
     if (j & 1) v = fe_add<F>(v, fe_mul<F>(key, r));          // mac element
     else if (party == 0) v = fe_add<F>(v, r);                // share element
     fe_store(out + 4 * j, v);
+}
+// column forms of the public-operand share ops (share.rs:74-82, :125-131): one thread per ScalarShare, share and MAC addressed through
+// (pointer, stride) views -- the engine-native split columns, slices of them, or AoS records (stride 8, mac = share + 4)
+template <int F, int OP>   // OP_ADD / OP_SUB: add_public / sub_public; OP_MUL: mul(Scalar)
+__global__ void __launch_bounds__(TPB) k_share_public_v(size_t n, int party, Fe key, Col a_s, Col a_m, const u64* pub, ColOut o_s, ColOut o_m) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fe r = fe_load(pub + 4 * i);
+    const Fe s = fe_load(a_s.p + (size_t)a_s.stride * i), m = fe_load(a_m.p + (size_t)a_m.stride * i);
+    if (OP == OP_MUL) {
+        fe_store(o_s.p + (size_t)o_s.stride * i, fe_mul<F>(s, r));
+        fe_store(o_m.p + (size_t)o_m.stride * i, fe_mul<F>(m, r));
+    } else {
+        if (OP == OP_SUB) r = fe_neg<F>(r);
+        fe_store(o_s.p + (size_t)o_s.stride * i, party == 0 ? fe_add<F>(s, r) : s);
+        fe_store(o_m.p + (size_t)o_m.stride * i, fe_add<F>(m, fe_mul<F>(key, r)));
+    }
 }
 // layout converters between arkworks' AoS records and the engine-native split columns (field-independent copies)
 __global__ void __launch_bounds__(TPB) k_share_split(size_t n, const u64* aos, u64* share_col, u64* mac_col) {
@@ -414,7 +458,8 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                 const size_t cnt = (n - lo < CH) ? (n - lo) : CH;
                 const size_t cs = (size_t)a_s.stride * lo, os = (size_t)o_s.stride * lo;
                 // split-column layout (stride 4): once-streamed data carries non-temporal hints; AoS: none (halves share lines)
-                static const bool k3_nt = !(getenv("ARKMPC_K3_NT") && getenv("ARKMPC_K3_NT")[0] == '0');     // A/B switch for the cache-policy measurement
+                // ARKMPC_K3_NT: 0 = no hints, 1 = hints on once-streamed loads AND on the result stores, 2 (default) = on the loads only
+                static const int k3_nt = getenv("ARKMPC_K3_NT") ? atoi(getenv("ARKMPC_K3_NT")) : 2;     // A/B switch for the cache-policy measurement
                 static const bool aos_lds = !(getenv("ARKMPC_K3_AOS_LDS") && getenv("ARKMPC_K3_AOS_LDS")[0] == '0');
                 const bool aos_records = a_s.stride == 8 && o_s.stride == 8 && a_m.p == a_s.p + 4 && b_m.p == b_s.p + 4 && c_m.p == c_s.p + 4 &&
                                          o_m.p == o_s.p + 4;
@@ -423,14 +468,15 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                              my_e + 4 * lo, peer_d + 4 * lo, peer_e + 4 * lo, a_s.p + cs, b_s.p + cs, c_s.p + cs, o_s.p + os);
                     continue;
                 }
-                if (a_s.stride == 4 && o_s.stride == 4 && k3_nt)
-                    launch_k(ctx, k_beaver_finish_asm<F, 1>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k,
-                                       my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo, peer_e + 4 * lo, a_s.p + cs, a_m.p + cs,
-                                       b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u, o_s.stride * 8u);
-                else
-                    launch_k(ctx, k_beaver_finish_asm<F, 0>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k,
-                                       my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo, peer_e + 4 * lo, a_s.p + cs, a_m.p + cs,
-                                       b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u, o_s.stride * 8u);
+                const int nt = (a_s.stride == 4 && o_s.stride == 4) ? k3_nt : 0;
+#define ARK_K3_LAUNCH(NT)                                                                                                                           \
+    launch_k(ctx, k_beaver_finish_asm<F, NT>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo,   \
+             peer_e + 4 * lo, a_s.p + cs, a_m.p + cs, b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u,          \
+             o_s.stride * 8u)
+                if (nt == 1) ARK_K3_LAUNCH(1);
+                else if (nt == 2) ARK_K3_LAUNCH(2);
+                else ARK_K3_LAUNCH(0);
+#undef ARK_K3_LAUNCH
             }
             return;
         }
@@ -770,6 +816,35 @@ int arkmpc_scalar_batch_inverse(arkmpc_ctx* ctx, size_t n, const uint64_t* a, ui
     }
     return st.finish();
 }
+// sum / product over n elements of `cols` interleaved columns (element i of column c at in + stride * i + 4 c); out = cols elements
+static int scalar_reduce(arkmpc_ctx* ctx, int op, size_t n, const uint64_t* in, u32 cols, uint64_t* out) {
+    ENTER(ctx);
+    Stage st(ctx);
+    const u32 stride = 4 * cols;
+    int ia = st.declare_in(in, n * stride * 8), io = st.declare_out(out, (size_t)cols * 32);
+    const unsigned nb = (unsigned)((n + TPB - 1) / TPB < RED_MAX_BLOCKS ? (n + TPB - 1) / TPB : RED_MAX_BLOCKS);
+    int iw = st.declare_scratch((size_t)(nb ? nb : 1) * cols * 32);
+    if (st.commit()) return st.rc;
+    DISPATCH_FIELD(ctx, {
+        u64* part = st.scratch<u64>(iw);
+        if (nb <= 1) {                                      // one workgroup folds everything (n = 0: the empty sum / product)
+            if (op == OP_ADD) hipLaunchKernelGGL((k_reduce<F, OP_ADD>), dim3(1, cols), dim3(TPB), 0, ctx->stream, n, st.in<u64>(ia), stride, 4u, st.out<u64>(io), 0u);
+            else hipLaunchKernelGGL((k_reduce<F, OP_MUL>), dim3(1, cols), dim3(TPB), 0, ctx->stream, n, st.in<u64>(ia), stride, 4u, st.out<u64>(io), 0u);
+        } else {
+            if (op == OP_ADD) {
+                hipLaunchKernelGGL((k_reduce<F, OP_ADD>), dim3(nb, cols), dim3(TPB), 0, ctx->stream, n, st.in<u64>(ia), stride, 4u, part, stride);
+                hipLaunchKernelGGL((k_reduce<F, OP_ADD>), dim3(1, cols), dim3(TPB), 0, ctx->stream, (size_t)nb, (const u64*)part, stride, 4u, st.out<u64>(io), 0u);
+            } else {
+                hipLaunchKernelGGL((k_reduce<F, OP_MUL>), dim3(nb, cols), dim3(TPB), 0, ctx->stream, n, st.in<u64>(ia), stride, 4u, part, stride);
+                hipLaunchKernelGGL((k_reduce<F, OP_MUL>), dim3(1, cols), dim3(TPB), 0, ctx->stream, (size_t)nb, (const u64*)part, stride, 4u, st.out<u64>(io), 0u);
+            }
+        }
+    });
+    return st.finish();
+}
+int arkmpc_scalar_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return scalar_reduce(ctx, OP_ADD, n, a, 1, out); }
+int arkmpc_scalar_product(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return scalar_reduce(ctx, OP_MUL, n, a, 1, out); }
+int arkmpc_share_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share) { return scalar_reduce(ctx, OP_ADD, n, shares, 2, out_share); }
 int arkmpc_scalar_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out) { return scalar_unop(ctx, 0, n, a, out, 32); }
 int arkmpc_scalar_from_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out) { return scalar_unop(ctx, 1, n, in, out, 32); }
 int arkmpc_scalar_to_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out) { return scalar_unop(ctx, 2, n, in, out, 32); }
@@ -892,6 +967,42 @@ int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const 
 // C ABI: Beaver multiplication
 // ---------------------------------------------------------------------------------------------
 static bool stride_ok(size_t s) { return s >= 4 && (s % 2) == 0 && s <= 0xffffffffu; }
+
+static int share_public_v(arkmpc_ctx* ctx, int op, size_t n, int party, const uint64_t key[4], const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                          const uint64_t* pub, uint64_t* out_share, uint64_t* out_mac, size_t out_stride) {
+    ENTER(ctx);
+    if (op != OP_MUL && !party_ok(party)) return ark_bad(ctx, "party_id must be 0 or 1");
+    if (op != OP_MUL && !key) return ark_bad(ctx, "null mac_key");
+    if (!stride_ok(a_stride) || !stride_ok(out_stride)) return ark_bad(ctx, "bad stride");
+    if (ctx->host_buffers) return ark_bad(ctx, "share-view entry points take device pointers only");
+    if (n && (!a_share || !a_mac || !pub || !out_share || !out_mac)) return ark_bad(ctx, "null pointer");
+    if (((uintptr_t)a_share | (uintptr_t)a_mac | (uintptr_t)pub | (uintptr_t)out_share | (uintptr_t)out_mac) & 15) return ark_bad(ctx, "device pointer not 16-byte aligned");
+    if (n) {
+        const Fe k = key ? fe_from_host(key) : Fe{};
+        dim3 g(blocks_for(n, TPB)), t(TPB);
+        const Col as{a_share, (u32)a_stride}, am{a_mac, (u32)a_stride};
+        const ColOut os{out_share, (u32)out_stride}, om{out_mac, (u32)out_stride};
+        DISPATCH_FIELD(ctx, {
+            if (op == OP_ADD) hipLaunchKernelGGL((k_share_public_v<F, OP_ADD>), g, t, 0, ctx->stream, n, party, k, as, am, pub, os, om);
+            else if (op == OP_SUB) hipLaunchKernelGGL((k_share_public_v<F, OP_SUB>), g, t, 0, ctx->stream, n, party, k, as, am, pub, os, om);
+            else hipLaunchKernelGGL((k_share_public_v<F, OP_MUL>), g, t, 0, ctx->stream, n, party, k, as, am, pub, os, om);
+        });
+        ARK_HIP(ctx, hipGetLastError());
+    }
+    return ARKMPC_OK;
+}
+int arkmpc_share_add_public_v(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                              const uint64_t* pub, uint64_t* out_share, uint64_t* out_mac, size_t out_stride) {
+    return share_public_v(ctx, OP_ADD, n, party_id, mac_key, a_share, a_mac, a_stride, pub, out_share, out_mac, out_stride);
+}
+int arkmpc_share_sub_public_v(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                              const uint64_t* pub, uint64_t* out_share, uint64_t* out_mac, size_t out_stride) {
+    return share_public_v(ctx, OP_SUB, n, party_id, mac_key, a_share, a_mac, a_stride, pub, out_share, out_mac, out_stride);
+}
+int arkmpc_share_mul_public_v(arkmpc_ctx* ctx, size_t n, const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride, const uint64_t* pub,
+                              uint64_t* out_share, uint64_t* out_mac, size_t out_stride) {
+    return share_public_v(ctx, OP_MUL, n, 0, nullptr, a_share, a_mac, a_stride, pub, out_share, out_mac, out_stride);
+}
 
 int arkmpc_beaver_mask_v(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share,
                          size_t y_stride, const uint64_t* a_share, size_t a_stride, const uint64_t* b_share, size_t b_stride,

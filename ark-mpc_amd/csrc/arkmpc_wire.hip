@@ -266,6 +266,7 @@ static bool normalise_ws(const std::vector<unsigned char>& in, std::vector<unsig
     for (size_t i = 8; i < n; ++i) {
         const unsigned char c = in[i];
         const bool ws = c == 0x20 || c == 0x09 || c == 0x0a || c == 0x0d;
+        if (in_string && c == '\\' && i + 1 < n) { out.push_back(c); out.push_back(in[++i]); continue; }     // an escape (\" does not close the string)
         if (c == '"') in_string = !in_string;
         if (!ws || in_string) { out.push_back(c); continue; }
         size_t j = i;
@@ -362,7 +363,7 @@ int arkmpc_wire_encode_bytes32(arkmpc_ctx* ctx, int kind, uint64_t result_id, si
 
 static int decode_strict(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
                          size_t* out_n, uint64_t* out_result_id, int* out_kind);
-// Entry: frames that contain JSON whitespace are normalised first (host, rare), everything else goes straight to the strict GPU parser.
+// Entry: the strict GPU parser; a frame it rejects that contains JSON whitespace is normalised (host, rare) and parsed again.
 static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
                        size_t* out_n, uint64_t* out_result_id, int* out_kind) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
@@ -370,18 +371,25 @@ static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, 
     if (guard.rc) return guard.rc;
     if (!frame || !out_n) return ark_bad(ctx, "null frame / out_n");
     if (frame_len < 8 + 30) return ark_bad(ctx, "frame too short");
+    // The strict GPU parser runs FIRST: serde_json::to_vec -- what a reference peer sends -- never emits whitespace, so the common frame
+    // costs no whitespace scan, no extra launch and no extra synchronisation.  Only a frame the strict parser rejects is examined for
+    // JSON whitespace (which serde_json::from_slice accepts) and, if it has any, normalised on the host and parsed again.
+    if (!ctx->host_buffers && ((uintptr_t)frame & 15)) return ark_bad(ctx, "device pointer not 16-byte aligned");
+    const int strict_rc = decode_strict(ctx, frame, frame_len, max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
+    if (strict_rc != ARKMPC_ERR_BAD_ARG) return strict_rc;
+    std::string strict_err;
+    { std::lock_guard<std::mutex> lk(ctx->err_mu); strict_err = ctx->err; }
     bool ws = false;
     if (ctx->host_buffers) {
         ws = host_has_ws(frame, frame_len);
     } else {
-        if ((uintptr_t)frame & 15) return ark_bad(ctx, "device pointer not 16-byte aligned");
         ARK_HIP(ctx, hipMemsetAsync(ctx->d_flag + 4, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_wire_has_ws, dim3(blocks_for((frame_len + 15) / 16, WIRE_TPB)), dim3(WIRE_TPB), 0, ctx->stream, frame, frame_len, ctx->d_flag + 4);
         ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag + 12, ctx->d_flag + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ws = ctx->h_flag[12] != 0;
     }
-    if (!ws) return decode_strict(ctx, frame, frame_len, max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
+    if (!ws) { ark_set_err(ctx, strict_err); return strict_rc; }
     // the declared length covers the text as sent, whitespace included
     std::vector<unsigned char> raw(frame_len), norm;
     if (ctx->host_buffers) memcpy(raw.data(), frame, frame_len);

@@ -182,6 +182,9 @@ class Engine:
     def scalar_sub(self, n, a, b, out): self.call("scalar_sub", ("size", n), a, b, out)
     def scalar_mul(self, n, a, b, out): self.call("scalar_mul", ("size", n), a, b, out)
     def scalar_neg(self, n, a, out): self.call("scalar_neg", ("size", n), a, out)
+    def scalar_sum(self, n, a, out): self.call("scalar_sum", ("size", n), a, out)
+    def scalar_product(self, n, a, out): self.call("scalar_product", ("size", n), a, out)
+    def share_sum(self, n, a, out): self.call("share_sum", ("size", n), a, out)
     def scalar_prefix_product(self, n, a, out): self.call("scalar_prefix_product", ("size", n), a, out)
     def scalar_batch_inverse(self, n, a, out): self.call("scalar_batch_inverse", ("size", n), a, out)
     def scalar_from_canonical(self, n, a, out): self.call("scalar_from_canonical", ("size", n), a, out)

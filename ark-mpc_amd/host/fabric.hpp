@@ -99,9 +99,13 @@ class DeviceBuf {
   public:
     DeviceBuf() = default;
     DeviceBuf(std::shared_ptr<Engine> e, size_t words) : DeviceBuf(std::move(e), ARKMPC_KIND_WORDS, words) {}
-    DeviceBuf(std::shared_ptr<Engine> e, int kind, size_t n) : e_(std::move(e)) {
-        check(e_->dev(), arkmpc_batch_create(e_->dev(), kind, ARKMPC_LAYOUT_AOS, n, &b_), "batch_create");
+    DeviceBuf(std::shared_ptr<Engine> e, int kind, size_t n, int layout = ARKMPC_LAYOUT_AOS) : e_(std::move(e)) {
+        check(e_->dev(), arkmpc_batch_create(e_->dev(), kind, layout, n, &b_), "batch_create");
         words_ = n * arkmpc_batch_elem_words(b_);
+    }
+    // take over a handle the C ABI returned (arkmpc_batch_from_host, arkmpc_batch_column, ...)
+    static DeviceBuf adopt(std::shared_ptr<Engine> e, arkmpc_batch* b) {
+        DeviceBuf d; d.e_ = std::move(e); d.b_ = b; d.words_ = arkmpc_batch_len(b) * arkmpc_batch_elem_words(b); return d;
     }
     ~DeviceBuf() { if (b_) arkmpc_batch_destroy(e_->dev(), b_); }
     DeviceBuf(DeviceBuf&& o) noexcept { *this = std::move(o); }
@@ -111,6 +115,9 @@ class DeviceBuf {
     }
     DeviceBuf(const DeviceBuf&) = delete;
     uint64_t* ptr() const { return arkmpc_batch_data(b_); }
+    uint64_t* mac_ptr() const { return arkmpc_batch_mac_data(b_); }      // ScalarShare batches: the MAC half / column
+    size_t stride() const { return arkmpc_batch_stride(b_); }           // u64 units between consecutive elements
+    int layout() const { return arkmpc_batch_layout(b_); }
     arkmpc_batch* handle() const { return b_; }
     int kind() const { return arkmpc_batch_kind(b_); }
     size_t words() const { return words_; }
@@ -422,6 +429,21 @@ struct ScalarBatch {
     std::vector<Scalar> to_host() const { std::vector<Scalar> v(n); buf.download(v.data(), n * 32); return v; }
 };
 
+// Sum / Product for ScalarResult (scalar_result.rs:325-338 and Iterator::sum): one gate over n public scalars -> a batch of ONE
+inline ScalarBatch scalar_batch_reduce(const std::shared_ptr<Engine>& e, const ScalarBatch& v, bool product) {
+    if (product && v.n == 0) throw std::invalid_argument("Cannot compute product of empty iterator");     // assert! scalar_result.rs:328
+    ScalarBatch r; r.n = 1; r.buf = DeviceBuf(e, ARKMPC_KIND_SCALAR, 1);
+    check(e->dev(), (product ? arkmpc_scalar_product : arkmpc_scalar_sum)(e->dev(), v.n, v.buf.ptr(), r.buf.ptr()), product ? "scalar_product" : "scalar_sum");
+    return r;
+}
+// ScalarResult::batch_add_constant / batch_sub_constant (scalar_result.rs:119-137, :205-223): public batch (+|-) plain Scalars
+inline ScalarBatch scalar_batch_addsub(const std::shared_ptr<Engine>& e, const ScalarBatch& a, const ScalarBatch& b, bool sub) {
+    if (a.n != b.n) throw std::invalid_argument("Batch add constant requires equal length inputs");
+    ScalarBatch r; r.n = a.n; r.buf = DeviceBuf(e, ARKMPC_KIND_SCALAR, a.n);
+    if (a.n) check(e->dev(), (sub ? arkmpc_scalar_sub : arkmpc_scalar_add)(e->dev(), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "scalar add/sub constant");
+    return r;
+}
+
 class AuthenticatedScalarBatch;
 struct AuthenticatedOpenResult {   // AuthenticatedScalarOpenResult, authenticated_scalar.rs:360-385
     MpcError err = MpcError::None; // AuthenticationError unless the MAC check scalar equals 1
@@ -447,6 +469,11 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // protocol-level scenarios exercise the GPU encoder / validating decoder end to end (env ARKMPC_MOCK_WIRE=1 in
     // execute_mock_mpc).  Off: payloads are handed over as host vectors (network/mock.rs).
     enum class LinkMode { Host, Device, Wire };
+    // HBM layout of every AuthenticatedScalarBatch this fabric creates: the engine-native split columns (default: K1 reads no dead MAC
+    // bytes, the `.share()` payload of an opening IS the share column, once-streamed data carries cache hints) or arkworks' AoS records.
+    // Values cross to the host (to_host, the mock link's host mode) as arkworks records either way.
+    void set_share_layout(int layout) { share_layout_ = layout; }
+    int share_layout() const { return share_layout_; }
     void set_link_mode(LinkMode m) { link_ = m; wire_ = (m == LinkMode::Wire); }
     LinkMode link_mode() const { return link_; }
     void set_wire_frames(bool on) { set_link_mode(on ? LinkMode::Wire : LinkMode::Host); }
@@ -593,6 +620,8 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     AuthenticatedScalarBatch batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender);
     AuthenticatedScalarBatch allocate_scalar_shares(const std::vector<ScalarShare>& s);
     AuthenticatedScalarBatch fill_scalar_shares(const ScalarShare& s, size_t n);     // vec![s; n] on the GPU
+    AuthenticatedScalarBatch zeros_authenticated(size_t n);                          // fabric.rs:513-515: n references to the shared zero wire (0, 0)
+    AuthenticatedScalarBatch ones_authenticated(size_t n);                           // fabric.rs:531-534: (party_id, mac_key), fabric.rs:234-235
     // fabric.rs:622-649: share public-format points (12 x u64 Jacobian each) held by `sender`
     template <class APB> APB batch_share_point(const std::vector<uint64_t>& points, size_t n, PartyId sender);
 
@@ -603,11 +632,14 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     std::unique_ptr<PreprocessingPhase> prep_;
     Scalar mac_key_;
     bool wire_ = false;
+    int share_layout_ = ARKMPC_LAYOUT_SPLIT;
     LinkMode link_ = LinkMode::Host;
     uint64_t next_id_ = 6;   // N_CONSTANT_RESULTS (fabric.rs:55-70)
 };
 
-// Vec<AuthenticatedScalarResult<C>>: n ScalarShares resident on the GPU (arkworks AoS layout)
+// Vec<AuthenticatedScalarResult<C>>: n ScalarShares resident on the GPU, in the fabric's share layout (split columns by default,
+// arkworks AoS records on request).  Every op goes through the share / MAC column view of the batch handle (pointer + stride), so
+// the same code drives both layouts.
 class AuthenticatedScalarBatch {
   public:
     size_t n = 0;
@@ -615,41 +647,88 @@ class AuthenticatedScalarBatch {
     std::shared_ptr<MpcFabric> fabric;
 
     static AuthenticatedScalarBatch alloc(const std::shared_ptr<MpcFabric>& f, size_t n) {
-        AuthenticatedScalarBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR_SHARE, n); return r;
+        AuthenticatedScalarBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR_SHARE, n, f->share_layout()); return r;
     }
-    std::vector<ScalarShare> to_host() const { std::vector<ScalarShare> v(n); buf.download(v.data(), n * 64); return v; }
+    uint64_t* s() const { return buf.ptr(); }            // share of element i at s() + st() * i
+    uint64_t* m() const { return buf.mac_ptr(); }        // MAC   of element i at m() + st() * i
+    size_t st() const { return buf.stride(); }
+    bool split() const { return buf.layout() == ARKMPC_LAYOUT_SPLIT; }
+    // always arkworks records, whatever the device layout (arkmpc_batch_to_host)
+    std::vector<ScalarShare> to_host() const {
+        std::vector<ScalarShare> v(n);
+        check(ctx(*this), arkmpc_batch_to_host(ctx(*this), buf.handle(), v.data()), "batch_to_host");
+        return v;
+    }
+    // n arkworks ScalarShare records on the device, for the entry points that take records (the point side of the ABI): the batch
+    // itself if it is AoS, else a joined temporary
+    struct Records {
+        DeviceBuf tmp; const uint64_t* p = nullptr;
+        const uint64_t* ptr() const { return p; }
+    };
+    Records records() const {
+        Records r;
+        if (!split()) { r.p = s(); return r; }
+        r.tmp = DeviceBuf(fabric->engine(), ARKMPC_KIND_SCALAR_SHARE, n, ARKMPC_LAYOUT_AOS);
+        if (n) check(ctx(*this), arkmpc_share_join(ctx(*this), n, s(), m(), r.tmp.ptr()), "share_join");
+        r.p = r.tmp.ptr();
+        return r;
+    }
 
     // ---- linear ops (authenticated_scalar.rs:457-765) -------------------------------------------------------
+    // component-wise on (share, mac): both operands are whole batches of one layout, i.e. 2n consecutive field elements each
     static AuthenticatedScalarBatch batch_add(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {       // :457-489
-        same(a, b); auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_add(ctx(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_add"); return r;
+        same(a, b); auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_add(ctx(a), a.n, a.s(), b.s(), r.s()), "share_add"); return r;
     }
     static AuthenticatedScalarBatch batch_sub(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {       // :662-688
-        same(a, b); auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_sub(ctx(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_sub"); return r;
+        same(a, b); auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_sub(ctx(a), a.n, a.s(), b.s(), r.s()), "share_sub"); return r;
     }
     static AuthenticatedScalarBatch batch_neg(const AuthenticatedScalarBatch& a) {                                          // :745-765
-        auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_neg(ctx(a), a.n, a.buf.ptr(), r.buf.ptr()), "share_neg"); return r;
+        auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_neg(ctx(a), a.n, a.s(), r.s()), "share_neg"); return r;
     }
     static AuthenticatedScalarBatch batch_add_public(const AuthenticatedScalarBatch& a, const ScalarBatch& b) {             // :493-528
         if (a.n != b.n) throw std::invalid_argument("Cannot add batches of different sizes");
         auto r = alloc(a.fabric, a.n);
-        check(ctx(a), arkmpc_share_add_public(ctx(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_add_public");
+        check(ctx(a), arkmpc_share_add_public_v(ctx(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.s(), a.m(), a.st(), b.buf.ptr(), r.s(), r.m(), r.st()), "share_add_public");
         return r;
     }
     static AuthenticatedScalarBatch batch_sub_public(const AuthenticatedScalarBatch& a, const ScalarBatch& b) {             // :691-733
         if (a.n != b.n) throw std::invalid_argument("Cannot add batches of different sizes");
         auto r = alloc(a.fabric, a.n);
-        check(ctx(a), arkmpc_share_sub_public(ctx(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_sub_public");
+        check(ctx(a), arkmpc_share_sub_public_v(ctx(a), a.n, (int)a.fabric->party_id(), a.fabric->mac_key().l, a.s(), a.m(), a.st(), b.buf.ptr(), r.s(), r.m(), r.st()), "share_sub_public");
         return r;
     }
     static AuthenticatedScalarBatch batch_mul_public(const AuthenticatedScalarBatch& a, const ScalarBatch& b) {             // :883-916
         if (a.n != b.n) throw std::invalid_argument("Cannot multiply batches of different sizes");
-        auto r = alloc(a.fabric, a.n); check(ctx(a), arkmpc_share_mul_public(ctx(a), a.n, a.buf.ptr(), b.buf.ptr(), r.buf.ptr()), "share_mul_public"); return r;
+        auto r = alloc(a.fabric, a.n);
+        check(ctx(a), arkmpc_share_mul_public_v(ctx(a), a.n, a.s(), a.m(), a.st(), b.buf.ptr(), r.s(), r.m(), r.st()), "share_mul_public");
+        return r;
     }
-    // batch_mul_constant (:919-949): constants are plain Scalars broadcast by the caller -- same kernel as mul_public
+    // batch_mul_constant (:919-949), batch_add_constant (:531-560): constants are plain Scalars the caller holds -- the public-operand
+    // kernels after an upload (ScalarShare::add_public / Mul<Scalar>, share.rs:74-77, :125-131)
     static AuthenticatedScalarBatch batch_mul_constant(const AuthenticatedScalarBatch& a, const std::vector<Scalar>& consts) {
         if (a.n != consts.size()) throw std::invalid_argument("Cannot multiply batches of different sizes");
         ScalarBatch c = a.fabric->allocate_scalars(consts);
         return batch_mul_public(a, c);
+    }
+    static AuthenticatedScalarBatch batch_add_constant(const AuthenticatedScalarBatch& a, const std::vector<Scalar>& consts) {
+        if (a.n != consts.size()) throw std::invalid_argument("Cannot add batches of different sizes");
+        ScalarBatch c = a.fabric->allocate_scalars(consts);
+        return batch_add_public(a, c);
+    }
+    // Sum for AuthenticatedScalarResult (:563-575) -> ScalarShare::sum (share.rs:103-111): one gate, a batch of ONE element
+    static AuthenticatedScalarBatch sum(const AuthenticatedScalarBatch& a) {
+        if (a.n == 0) throw std::invalid_argument("sum of an empty iterator");           // `values[0]` panics in the reference
+        ScalarBatch t; t.n = 2; t.buf = DeviceBuf(a.fabric->engine(), ARKMPC_KIND_SCALAR, 2);
+        if (a.split()) {
+            check(ctx(a), arkmpc_scalar_sum(ctx(a), a.n, a.s(), t.buf.ptr()), "scalar_sum(shares)");
+            check(ctx(a), arkmpc_scalar_sum(ctx(a), a.n, a.m(), t.buf.ptr() + 4), "scalar_sum(macs)");
+        } else {
+            check(ctx(a), arkmpc_share_sum(ctx(a), a.n, a.s(), t.buf.ptr()), "share_sum");
+        }
+        auto r = alloc(a.fabric, 1);                                                        // one element: (share, mac) in either layout
+        check(ctx(a), arkmpc_memcpy_d2d(ctx(a), r.s(), t.buf.ptr(), 32), "d2d");
+        check(ctx(a), arkmpc_memcpy_d2d(ctx(a), r.m(), t.buf.ptr() + 4, 32), "d2d");
+        return r;
     }
     // ---- Beaver multiplication (:848-879) -------------------------------------------------------------------
     static AuthenticatedScalarBatch batch_mul(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {
@@ -661,12 +740,22 @@ class AuthenticatedScalarBatch {
         f->next_triple_batch(n, ta, tb, tc);                                                  // :859
         // masked_lhs = a - beaver_a, masked_rhs = b - beaver_b, all_masks = lhs || rhs; open_batch sends `.share()` (:863-868, :141-145)
         ScalarBatch my_de; my_de.n = 2 * n; my_de.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, 2 * n);
-        check(f->ctx(), arkmpc_beaver_mask(f->ctx(), n, a.buf.ptr(), b.buf.ptr(), ta.buf.ptr(), tb.buf.ptr(), my_de.buf.ptr()), "beaver_mask");
+        check(f->ctx(), arkmpc_beaver_mask_v(f->ctx(), n, a.s(), a.st(), b.s(), b.st(), ta.s(), ta.st(), tb.s(), tb.st(), my_de.buf.ptr()), "beaver_mask");
         ScalarBatch peer_de = f->exchange_values(my_de);                                      // the one network round (length-checked: 2n)
         auto r = alloc(f, n);                                                                 // combine (:161-171) + de + d[b] + e[a] + [c] (:871-878)
-        check(f->ctx(), arkmpc_beaver_finish_fused(f->ctx(), n, (int)f->party_id(), f->mac_key().l, my_de.buf.ptr(), peer_de.buf.ptr(),
-                                                   ta.buf.ptr(), tb.buf.ptr(), tc.buf.ptr(), r.buf.ptr()), "beaver_finish_fused");
+        check(f->ctx(), arkmpc_beaver_finish_fused_v(f->ctx(), n, (int)f->party_id(), f->mac_key().l, my_de.buf.ptr(), peer_de.buf.ptr(),
+                                                     ta.s(), ta.m(), ta.st(), tb.s(), tb.m(), tb.st(), tc.s(), tc.m(), tc.st(), r.s(), r.m(), r.st()), "beaver_finish_fused");
         return r;
+    }
+    // pow (:86-100): recursive squaring, element-wise over the batch; pow(0) is the fabric's SHARED ZERO wire in the reference
+    // (`zero_authenticated()`, fabric.rs:507-509 -- not one), pow(1) a clone
+    static AuthenticatedScalarBatch pow(const AuthenticatedScalarBatch& a, uint64_t exp) {
+        if (exp == 0) return a.fabric->zeros_authenticated(a.n);
+        if (exp == 1) return a.slice(0, a.n);
+        AuthenticatedScalarBatch rec = pow(a, exp / 2);
+        AuthenticatedScalarBatch res = batch_mul(rec, rec);
+        if (exp % 2 == 1) res = batch_mul(res, a);
+        return res;
     }
     // ---- inversion (:55-82): mask with a shared random r, open authenticated, invert in public, multiply back ----
     static AuthenticatedScalarBatch batch_inverse(const AuthenticatedScalarBatch& values, const Scalar& blinder, MpcError* err = nullptr) {
@@ -686,10 +775,24 @@ class AuthenticatedScalarBatch {
         return batch_mul(a, b_inv);
     }
     // ---- opening (:129-172, :278-354) -----------------------------------------------------------------------
+    // the `.share()` projection a party sends (:141-145): with split columns it IS the share column -- a view that shares the storage,
+    // no kernel; with AoS records an extraction pass
+    ScalarBatch share_values() const {
+        ScalarBatch mine; mine.n = n;
+        arkmpc_ctx* c = fabric->ctx();
+        if (split()) {
+            arkmpc_batch* col = nullptr;
+            check(c, arkmpc_batch_column(c, buf.handle(), 0, &col), "batch_column");
+            mine.buf = DeviceBuf::adopt(fabric->engine(), col);
+        } else {
+            mine.buf = DeviceBuf(fabric->engine(), ARKMPC_KIND_SCALAR, n);
+            if (n) check(c, arkmpc_share_extract(c, n, s(), mine.buf.ptr()), "share_extract");
+        }
+        return mine;
+    }
     ScalarBatch open_batch() const {
-        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(fabric->engine(), ARKMPC_KIND_SCALAR, n);
-        if (n == 0) return mine;
-        check(fabric->ctx(), arkmpc_share_extract(fabric->ctx(), n, buf.ptr(), mine.buf.ptr()), "share_extract");
+        if (n == 0) { ScalarBatch e; e.buf = DeviceBuf(fabric->engine(), ARKMPC_KIND_SCALAR, 0); return e; }
+        ScalarBatch mine = share_values();
         ScalarBatch peer = fabric->exchange_values(mine);
         ScalarBatch out; out.n = n; out.buf = DeviceBuf(fabric->engine(), ARKMPC_KIND_SCALAR, n);
         check(fabric->ctx(), arkmpc_open_combine(fabric->ctx(), n, mine.buf.ptr(), peer.buf.ptr(), out.buf.ptr()), "open_combine");
@@ -701,12 +804,11 @@ class AuthenticatedScalarBatch {
         auto f = fabric;
         if (n == 0) return res;                                                                   // :279-281
         arkmpc_ctx* c = f->ctx();
-        ScalarBatch mine; mine.n = n; mine.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
-        check(c, arkmpc_share_extract(c, n, buf.ptr(), mine.buf.ptr()), "share_extract");
+        ScalarBatch mine = share_values();
         ScalarBatch peer = f->exchange_values(mine);                                              // round 1: open_batch
         ScalarBatch opened; opened.n = n; opened.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
         ScalarBatch chk; chk.n = n; chk.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, n);
-        check(c, arkmpc_open_and_mac_check(c, n, f->mac_key().l, buf.ptr(), peer.buf.ptr(), opened.buf.ptr(), chk.buf.ptr()), "open_and_mac_check");   // :161-171 + :299-311
+        check(c, arkmpc_open_and_mac_check_v(c, n, f->mac_key().l, s(), m(), st(), peer.buf.ptr(), opened.buf.ptr(), chk.buf.ptr()), "open_and_mac_check");   // :161-171 + :299-311
         Scalar my_comm;
         check(c, arkmpc_commit_sha3(c, n, chk.buf.ptr(), blinder.l, my_comm.l), "commit_sha3");  // batch_commit (commitment.rs:63-89)
         ScalarBatch peer_comm = f->exchange_values(f->allocate_scalars({my_comm}));               // round 2: commitments
@@ -722,17 +824,24 @@ class AuthenticatedScalarBatch {
         res.value = std::move(opened);
         return res;
     }
-    // elements [lo, lo+cnt) as a new batch (a Rust slice &v[lo..lo+cnt])
+    // elements [lo, lo+cnt) as a new batch (a Rust slice &v[lo..lo+cnt], materialised: whole batches stay 2n consecutive elements)
     AuthenticatedScalarBatch slice(size_t lo, size_t cnt) const {
         if (lo + cnt > n) throw std::out_of_range("slice");
         auto r = alloc(fabric, cnt);
-        if (cnt) check(fabric->ctx(), arkmpc_memcpy_d2d(fabric->ctx(), r.buf.ptr(), buf.ptr() + 8 * lo, cnt * 64), "d2d");
+        if (!cnt) return r;
+        arkmpc_ctx* c = fabric->ctx();
+        if (split()) {
+            check(c, arkmpc_memcpy_d2d(c, r.s(), s() + 4 * lo, cnt * 32), "d2d");
+            check(c, arkmpc_memcpy_d2d(c, r.m(), m() + 4 * lo, cnt * 32), "d2d");
+        } else {
+            check(c, arkmpc_memcpy_d2d(c, r.s(), s() + 8 * lo, cnt * 64), "d2d");
+        }
         return r;
     }
     // iter::repeat(v[idx]).take(cnt)
     AuthenticatedScalarBatch repeat(size_t idx, size_t cnt) const {
         std::vector<ScalarShare> h = to_host();
-        return fabric->allocate_scalar_shares(std::vector<ScalarShare>(cnt, h.at(idx)));
+        return fabric->fill_scalar_shares(h.at(idx), cnt);
     }
     // test helpers (authenticated_scalar.rs:1079-1111): overwrite the MAC / the share of element idx
     void modify_mac(size_t idx, const Scalar& v) { poke(idx, 1, v); }
@@ -742,11 +851,12 @@ class AuthenticatedScalarBatch {
     static arkmpc_ctx* ctx(const AuthenticatedScalarBatch& a) { return a.fabric->ctx(); }
     static void same(const AuthenticatedScalarBatch& a, const AuthenticatedScalarBatch& b) {
         if (a.n != b.n) throw std::invalid_argument("Cannot operate on batches of different sizes");   // assert_eq! in the reference
+        if (a.buf.layout() != b.buf.layout()) throw std::invalid_argument("batches of one fabric share one layout");
     }
     void poke(size_t idx, int half, const Scalar& v) {
-        std::vector<ScalarShare> h = to_host();
-        (half ? h.at(idx).mac : h.at(idx).share) = v;
-        buf.upload(h.data(), n * 64);
+        if (idx >= n) throw std::out_of_range("poke");
+        check(ctx(*this), arkmpc_sync(ctx(*this)), "sync");
+        check(ctx(*this), arkmpc_memcpy_h2d(ctx(*this), (half ? m() : s()) + st() * idx, v.l, 32), "h2d");
     }
 };
 
@@ -805,14 +915,16 @@ template <class Cv> class AuthenticatedPointBatchT {
         same(s.n, b.n); auto r = alloc(b.fabric, b.n); check(c(b), Cv::share_mul_public(c(b), b.n, b.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "pointshare_mul_public"); return r;
     }
     static Self batch_mul_generator(const AuthenticatedScalarBatch& a) {                                              // :754-780
-        auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), Cv::scalarshare_mul_generator(a.fabric->ctx(), a.n, a.buf.ptr(), r.buf.ptr()), "mul_generator"); return r;
+        auto r = alloc(a.fabric, a.n); auto ar = a.records();
+        check(a.fabric->ctx(), Cv::scalarshare_mul_generator(a.fabric->ctx(), a.n, ar.ptr(), r.buf.ptr()), "mul_generator"); return r;
     }
     // CurvePointResult::batch_mul (curve.rs:459-479) and batch_mul_authenticated (curve.rs:483-517)
     static PointBatch point_batch_mul(const std::shared_ptr<MpcFabric>& f, const ScalarBatch& s, const PointBatch& p) {
         same(s.n, p.n); auto r = alloc_points(f, p.n); check(f->ctx(), Cv::scalar_mul(f->ctx(), p.n, p.buf.ptr(), s.buf.ptr(), r.buf.ptr()), "scalar_mul"); return r;
     }
     static Self batch_mul_authenticated(const AuthenticatedScalarBatch& a, const PointBatch& p) {
-        same(a.n, p.n); auto r = alloc(a.fabric, a.n); check(a.fabric->ctx(), Cv::scalarshare_mul_point(a.fabric->ctx(), a.n, a.buf.ptr(), p.buf.ptr(), r.buf.ptr()), "scalarshare_mul_point"); return r;
+        same(a.n, p.n); auto r = alloc(a.fabric, a.n); auto ar = a.records();
+        check(a.fabric->ctx(), Cv::scalarshare_mul_point(a.fabric->ctx(), a.n, ar.ptr(), p.buf.ptr(), r.buf.ptr()), "scalarshare_mul_point"); return r;
     }
     // ---- opening (:66-109) ----
     PointBatch open_batch() const {
@@ -881,8 +993,9 @@ template <class Cv> class AuthenticatedPointBatchT {
         ScalarBatch d_open = masked_rhs.open_batch();                                              // :702
         if (!literal) {                                                                            // one gate of the C ABI: the point-side K3
             Self r = alloc(f, n);
-            check(f->ctx(), Cv::beaver_finish(f->ctx(), n, (int)f->party_id(), f->mac_key().l, d_open.buf.ptr(), eG_open.buf.ptr(), ta.buf.ptr(),
-                                              tb.buf.ptr(), tc.buf.ptr(), r.buf.ptr()), "point_beaver_finish");
+            auto ra = ta.records(), rb = tb.records(), rc = tc.records();            // the point side of the ABI takes arkworks ScalarShare records
+            check(f->ctx(), Cv::beaver_finish(f->ctx(), n, (int)f->party_id(), f->mac_key().l, d_open.buf.ptr(), eG_open.buf.ptr(), ra.ptr(),
+                                              rb.ptr(), rc.ptr(), r.buf.ptr()), "point_beaver_finish");
             return r;
         }
         PointBatch deG = point_batch_mul(f, d_open, eG_open);                                      // :705
@@ -940,7 +1053,8 @@ template <class Cv> class AuthenticatedPointBatchT {
     static Self msm_authenticated(const AuthenticatedScalarBatch& scalars, const PointBatch& points) {
         if (scalars.n != points.n) throw std::invalid_argument("msm cannot compute on vectors of unequal length");
         auto r = alloc(scalars.fabric, 1);
-        check(scalars.fabric->ctx(), Cv::msm_authenticated(scalars.fabric->ctx(), points.n, points.buf.ptr(), scalars.buf.ptr(), r.buf.ptr()), "msm_authenticated");
+        auto sr = scalars.records();
+        check(scalars.fabric->ctx(), Cv::msm_authenticated(scalars.fabric->ctx(), points.n, points.buf.ptr(), sr.ptr(), r.buf.ptr()), "msm_authenticated");
         return r;
     }
 
@@ -984,15 +1098,24 @@ inline APB MpcFabric::batch_share_point(const std::vector<uint64_t>& points, siz
 }
 
 inline AuthenticatedScalarBatch MpcFabric::allocate_scalar_shares(const std::vector<ScalarShare>& s) {
-    auto r = AuthenticatedScalarBatch::alloc(shared_from_this(), s.size());
-    r.buf.upload(s.data(), s.size() * 64);
+    AuthenticatedScalarBatch r; r.n = s.size(); r.fabric = shared_from_this();
+    arkmpc_batch* b = nullptr;
+    check(ctx(), arkmpc_batch_from_host(ctx(), ARKMPC_KIND_SCALAR_SHARE, share_layout_, s.size(), s.data(), &b), "batch_from_host");
+    r.buf = DeviceBuf::adopt(eng_, b);
     return r;
 }
 inline AuthenticatedScalarBatch MpcFabric::fill_scalar_shares(const ScalarShare& s, size_t n) {
     auto r = AuthenticatedScalarBatch::alloc(shared_from_this(), n);
-    check(ctx(), arkmpc_fill(ctx(), n, 8, s.share.l, r.buf.ptr()), "fill");
+    if (r.split()) {
+        check(ctx(), arkmpc_fill(ctx(), n, 4, s.share.l, r.s()), "fill");
+        check(ctx(), arkmpc_fill(ctx(), n, 4, s.mac.l, r.m()), "fill");
+    } else {
+        check(ctx(), arkmpc_fill(ctx(), n, 8, s.share.l, r.s()), "fill");
+    }
     return r;
 }
+inline AuthenticatedScalarBatch MpcFabric::zeros_authenticated(size_t n) { return fill_scalar_shares(ScalarShare{Scalar{{0, 0, 0, 0}}, Scalar{{0, 0, 0, 0}}}, n); }
+inline AuthenticatedScalarBatch MpcFabric::ones_authenticated(size_t n) { return fill_scalar_shares(ScalarShare{eng_->from_u64(party_), mac_key_}, n); }
 inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c) {
     ScalarShare ca, cb, cc;
     if (prep_->constant_triplet(ca, cb, cc)) {
@@ -1098,6 +1221,7 @@ std::pair<T, T> execute_mock_mpc(int field_id, int device,
             MpcNetwork* raw = net.get();
             auto fab = std::make_shared<MpcFabric>(p, eng, std::move(net), make_prep(p, *eng));
             if (const char* w = std::getenv("ARKMPC_MOCK_WIRE")) fab->set_wire_frames(w[0] == '1');
+            if (const char* sl = std::getenv("ARKMPC_SHARE_LAYOUT")) fab->set_share_layout(std::string(sl) == "aos" ? ARKMPC_LAYOUT_AOS : ARKMPC_LAYOUT_SPLIT);
             if (const char* l = std::getenv("ARKMPC_MOCK_LINK")) {            // host | device | wire
                 const std::string v = l;
                 fab->set_link_mode(v == "device" ? MpcFabric::LinkMode::Device : (v == "wire" ? MpcFabric::LinkMode::Wire : MpcFabric::LinkMode::Host));

@@ -154,6 +154,22 @@ int main(int argc, char** argv) {
                 // AuthenticatedScalarResult::batch_inverse (authenticated_scalar.rs:55-82, test :1640-1660): open(inverse(x)) == x^-1
                 auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
                 res = AuthenticatedScalarBatch::batch_inverse(a, eng.from_u64(777 + fabric->party_id()));
+            } else if (scenario == "tail") {
+                // the small API tail in one circuit: pow (authenticated_scalar.rs:86-100, incl. pow(0) = the shared ZERO wire and pow(1) = clone),
+                // batch_add_constant (:531-560), Sum for AuthenticatedScalarResult (:563-575), ones_authenticated (fabric.rs:525-534),
+                // Sum / Product for ScalarResult (scalar_result.rs:325-338), ScalarResult::batch_add_constant / batch_sub_constant (:119, :205)
+                //   res_i = a_i^5 + b_i + S + 0 + 1 + P + T - a_i^1 ... with S = sum_j (a_j^5 + b_j), P = prod_j b_j, T = sum_j b_j
+                auto a = fabric->batch_share_scalar(a_m, n, PARTY0);
+                auto q = AuthenticatedScalarBatch::batch_add_constant(AuthenticatedScalarBatch::pow(a, 5), b_m);
+                auto S = AuthenticatedScalarBatch::sum(q).repeat(0, n);
+                auto z = AuthenticatedScalarBatch::pow(a, 0);
+                auto one = fabric->ones_authenticated(n);
+                ScalarBatch pb = fabric->batch_share_plaintext(b_m, n, PARTY1);
+                const Scalar P = scalar_batch_reduce(fabric->engine(), pb, true).to_host()[0], T = scalar_batch_reduce(fabric->engine(), pb, false).to_host()[0];
+                ScalarBatch Pn = fabric->allocate_scalars(std::vector<Scalar>(n, P)), Tn = fabric->allocate_scalars(std::vector<Scalar>(n, T));
+                ScalarBatch PT = scalar_batch_addsub(fabric->engine(), scalar_batch_addsub(fabric->engine(), Pn, Tn, false), pb, true);       // P + T - b_i
+                auto r1 = AuthenticatedScalarBatch::batch_add(AuthenticatedScalarBatch::batch_add(q, S), AuthenticatedScalarBatch::batch_add(z, one));
+                res = AuthenticatedScalarBatch::batch_sub(AuthenticatedScalarBatch::batch_add_public(r1, PT), AuthenticatedScalarBatch::pow(a, 1));
             } else if (scenario == "short_peer") {
                 // a peer that sends one element fewer than the protocol step requires: must surface as a network error on the
                 // honest side before any kernel reads the short buffer (never an out-of-bounds read)

@@ -55,6 +55,12 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed: run the pipeline for this long BEFORE the W warm-up steps, on every rank, so that the "
                     "timed region does not sit inside the power controller's transient after idle (tools/ramp_probe.py: a cold MI355X runs the first steps fast, "
                     "then creeps from 0.195 to 0.21-0.25 ms per step for several ms before settling at 0.198).  0 disables.  Reported in config.settle_ms.")
+    ap.add_argument("--single-process", action="store_true", help="N GPUs driven by ONE process through the C ABI's multi-device group (arkmpc_group_*): what a "
+                    "Rust party, which is one process, would run.  The driver's N>1 runs use torch.distributed.run (one process per GPU); this mode is the same "
+                    "sharding behind the FFI.  Reports ranks_seen, per-member kernel times and the peer-write gather rate.")
+    ap.add_argument("--devices", default=None, help="--single-process: comma-separated device ids of the members (default 0..N-1); ids may repeat "
+                    "(members then share a GPU: how the mode is exercised on a one-GPU box)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold pass (same W + K region with --settle-ms 0, run first) reported as value_cold / frac_cold")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs reported next to the headline at N=1 (AoS layout, config 4, config 5)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the timed ordered all-gather of opened-value buffers (config 5 shape, 64 MiB per rank)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for launch-path tests)")
@@ -105,10 +111,14 @@ class Party:
     pass
 
 
-def build_workload(eng, n, seed, layout):
+def build_workload(eng, n, seed, layout, key_shares=None):
+    """key_shares: the two parties' MAC key shares (numpy 4 x u64 each) when this batch is one RANGE of a larger one that shares the key
+    (the single-process group); by default they are drawn from the seed."""
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
     key_sh = [rand_field_elems(eng, 1, gen), rand_field_elems(eng, 1, gen)]
+    if key_shares is not None:
+        key_sh = [torch.from_numpy(np.ascontiguousarray(k).view(np.int64)).to(key_sh[0].device) for k in key_shares]
     key = torch.empty_like(key_sh[0])
     eng.scalar_add(1, key_sh[0], key_sh[1], key)
     x = rand_field_elems(eng, n, gen)
@@ -245,7 +255,7 @@ def cpu_baseline(parties, n, log2n_cpu, layout):
     }, res, myde, m
 
 
-def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier):
+def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier, settle_ms=None):
     """`warmup` untimed and `steps` timed passes of the pipeline over the rotated workload sets.  The timed region is
     bracketed by barrier() (dist.barrier + torch.cuda.synchronize) on both sides; on sampled steps every launch carries a
     dispatch-bound HIP event pair (arkmpc_kernel_timer_*, on the context's own stream = torch's current stream)."""
@@ -254,10 +264,11 @@ def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier):
     per_step = 4 * chunks                           # launches per step: per gate range K1(P0), K1(P1), K3(P0), K3(P1)
     barrier()                                       # the FIRST barrier of a process group builds the RCCL communicator (100s of ms with an idle GPU): pay that
                                                     # here, before the settle / warm-up phases, so the barrier that opens the timed region is only a barrier
-    if getattr(args, "settle_ms", 0) > 0:           # disclosed in config.settle_ms: steady-state clocks before the warm-up steps
+    settle_ms = getattr(args, "settle_ms", 0) if settle_ms is None else settle_ms
+    if settle_ms > 0:                               # disclosed in config.settle_ms: steady-state clocks before the warm-up steps
         t_s = time.perf_counter()
         k = 0
-        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+        while (time.perf_counter() - t_s) * 1e3 < settle_ms:
             for _ in range(8):
                 step(call_sets[k % len(call_sets)]); k += 1
             torch.cuda.synchronize()
@@ -395,6 +406,18 @@ def leg_config4(eng):
     eng.g1_to_affine(2 * n, out, xy[0], inf[0]); eng.g1_to_affine(2 * n, want, xy[1], inf[1])
     torch.cuda.synchronize()
     ok = bool(torch.equal(xy[0], xy[1])) and bool(torch.equal(inf[0], inf[1]))
+    # the fixed-base chain shares the hand-scheduled mixed-addition body with the variable-base pipeline, so it is not an independent
+    # witness: a sample of lanes is also compared with the oracle's double-and-add (oracle/ark_oracle.c, a checker outside the timed region)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    ora = oracle_api.load()
+    ns = 1024
+    h_sh = shares[:24 * ns].cpu().numpy().view(np.uint64).copy()
+    h_sc = sc[:4 * ns].cpu().numpy().view(np.uint64).copy()
+    want_o = ora.pointshare_mul_public_mt(h_sh, h_sc)
+    oxy, oinf = ora.g1_batch_to_affine_mt(want_o)
+    ok_oracle = bool(np.array_equal(oxy, xy[0][:16 * ns].cpu().numpy().view(np.uint64))) and bool(np.array_equal(oinf, inf[0][:2 * ns].cpu().numpy()))
+    ok = ok and ok_oracle
     smuls = 2 * n / (ms * 1e-3)
     per_smul, st = ec_mult_instrs()
     return {"workload": "2^18 PointShare x Scalar over BN254 G1 = 2^19 scalar-muls (BASELINE.json configs[3])", "ms": ms,
@@ -410,7 +433,7 @@ def leg_config4(eng):
             "r01_accounting": {"fq_muls_per_scalar_mul": FQ_MULS_PER_SMUL_R01, "fq_muls_per_s": smuls * FQ_MULS_PER_SMUL_R01,
                                "frac_of_mad_only_peak": smuls * FQ_MULS_PER_SMUL_R01 * MADS_PER_FQ_MUL / MAD_PEAK_PER_S,
                                "note": "round 1's work definition (2004 general multiplications per scalar-mul) at this round's speed"},
-            "results_check": "affine coords == fixed-base [(s*k)]G on all 2^19 points: %s" % ("ok" if ok else "FAILED")}, ok
+            "results_check": "affine coords == fixed-base [(s*k)]G on all 2^19 points, and == the oracle's double-and-add on the first 2048 scalar-muls: %s" % ("ok" if ok else "FAILED")}, ok
 
 
 def config4_secondary():
@@ -545,8 +568,180 @@ def leg_gather(dist, world, rank, backend):
             "bus_GBps_per_rank": 32 * per * (world - 1) / (ms * 1e-3) / 1e9, "ordered": ok}
 
 
+def clock_effect():
+    """Measured effect of the profiler on the dominant kernel, from the committed PMC pass (profiles/r03/clock_effect.json, written by
+    tools/profile_r03.sh): GRBM_GUI_ACTIVE cycles / the kernel's wall time under rocprofv3 = the shader clock it ran at while profiled."""
+    f = os.path.join(ROOT, "profiles", "r03", "clock_effect.json")
+    return json.load(open(f)) if os.path.exists(f) else None
+
+
+def main_single_process(args):
+    """N GPUs, ONE process: the multi-device group of the C ABI (include/arkmpc.h arkmpc_group_*).  Each party is a group over the same
+    devices; member g of both parties lives on device g and owns gates [g*n/G, (g+1)*n/G) of a step of n = G * 2^log2n gates (weak
+    scaling: 2^log2n gates per member).  Step = K1(P0), K1(P1), K2+K3(P0), K2+K3(P1) as four group calls; the d||e exchange is the
+    member-by-member pointer hand-over (both parties' member g share device g).  Timing: barrier = group sync of both parties."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    pkg = importlib.import_module("ark-mpc_amd")
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devs) != args.gpus:
+        raise SystemExit("--devices must list --gpus ids")
+    G = len(devs)
+    if args.log2n is None:
+        args.log2n = 21 if G == 8 else 20
+    per = 1 << args.log2n
+    n = per * G
+    layout = args.layout
+    L = pkg.Group.SPLIT if layout == "split" else pkg.Group.AOS
+    grp = [pkg.Group(FID, devs) for _ in (0, 1)]
+    nsets = max(1, args.sets)
+    # per member: the same seeded workload generator as the one-process-per-GPU path (seed + member = seed + rank)
+    sets = []           # sets[k][member] = (parties, truth)
+    engs = []
+    for m, d in enumerate(devs):
+        torch.cuda.set_device(d)
+        engs.append(pkg.Engine(FID, device=d, host_buffers=False, stream=torch.cuda.current_stream().cuda_stream))
+    for k in range(nsets):
+        row = []
+        for m, d in enumerate(devs):
+            torch.cuda.set_device(d)
+            ks = None if m == 0 else [row[0][0][pid].key for pid in (0, 1)]          # one party = one MAC key share, on every member
+            row.append(build_workload(engs[m], per, seed=0xA11CE002 + m + 7919 * k, layout=layout, key_shares=ks))
+        sets.append(row)
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    calls = []          # calls[k] = [k1_p0, k1_p1, k3_p0, k3_p1]
+    for k in range(nsets):
+        sh = lambda pid, nm: [getattr(sets[k][m][0][pid], nm) for m in range(G)]
+        k1k3 = [grp[pid].prepare_beaver(L, n, pid, sets[k][0][0][pid].key, sh(pid, "x"), sh(pid, "y"), sh(pid, "a"), sh(pid, "b"), sh(pid, "c"),
+                                        sh(pid, "de"), sh(1 - pid, "de"), sh(pid, "out")) for pid in (0, 1)]
+        calls.append([k1k3[0][0], k1k3[1][0], k1k3[0][1], k1k3[1][1]])
+    lib = pkg.load_library()
+
+    def barrier():
+        grp[0].sync(); grp[1].sync()
+
+    def step(k, arm_slot=None):
+        for j, c in enumerate(calls[k]):
+            if arm_slot is not None:            # dispatch-bound HIP events on every member's launch of this call
+                g = grp[0 if j in (0, 2) else 1]
+                for m in range(G):
+                    lib.arkmpc_kernel_timer_arm(g.member_ctx(m), ctypes.c_int(arm_slot + j))
+            c()
+
+    def region(settle_ms, warmup, steps):
+        barrier()
+        if settle_ms > 0:
+            t_s = time.perf_counter(); k = 0
+            while (time.perf_counter() - t_s) * 1e3 < settle_ms:
+                for _ in range(8):
+                    step(k % nsets); k += 1
+                barrier()
+        for w in range(warmup):
+            step(w % nsets)
+        barrier()
+        sampled = [s_ for s_ in range(steps) if s_ % max(1, steps // 8) == 0][:8]
+        slot_of = {s_: 4 * i for i, s_ in enumerate(sampled)}
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            step(s_ % nsets, slot_of.get(s_))
+        barrier()
+        elapsed = time.perf_counter() - t0
+        per_member = []
+        for m in range(G):
+            ms = ctypes.c_float(0)
+            acc = [0.0, 0.0]
+            for s_ in sampled:
+                for j in range(4):
+                    g = grp[0 if j in (0, 2) else 1]
+                    lib.arkmpc_kernel_timer_ms(g.member_ctx(m), ctypes.c_int(slot_of[s_] + j), ctypes.byref(ms))
+                    acc[0 if j < 2 else 1] += ms.value
+            cnt = max(1, 2 * len(sampled))
+            per_member.append({"member": m, "device": devs[m], "k1_avg_launch_ms": acc[0] / cnt, "k3_avg_launch_ms": acc[1] / cnt,
+                               "kernel_ms_per_step": (acc[0] + acc[1]) / max(1, len(sampled))})
+        return elapsed, per_member
+
+    cold = None
+    if not args.no_cold and args.settle_ms > 0:
+        cold = region(0, args.warmup, args.steps)
+    elapsed, per_member = region(args.settle_ms, args.warmup, args.steps)
+    # results: every member's range opens to x*y with a valid MAC (engine ops on that member's device)
+    ok = True
+    if not args.no_check:
+        for k in range(min(nsets, args.steps)):
+            for m, d in enumerate(devs):
+                torch.cuda.set_device(d)
+                ps, tr = sets[k][m]
+                ok = ok and check_results(engs[m], per, ps, tr, layout)
+    # gather of opened values in config 5's shape: 2^21 scalars (64 MiB) per member into one ordered buffer on member 0 / on every member
+    gather = None
+    if not args.no_gather:
+        gper = 1 << 21
+        gn = gper * G
+        sh = grp[0].malloc(gn, 1, 4)
+        root_buf = torch.empty(4 * gn, dtype=torch.int64, device="cuda:%d" % devs[0])
+        outs = [torch.empty(4 * gn, dtype=torch.int64, device="cuda:%d" % d) for d in devs]
+        host = np.arange(4 * gn, dtype=np.uint64)
+        grp[0].scatter_h2d(gn, 1, 4, host, sh)
+        res = {}
+        for name, fn in (("gather_to_member0", lambda: grp[0].gather(gn, 1, 4, sh, 0, root_buf)), ("allgather", lambda: grp[0].allgather(gn, 1, 4, sh, outs))):
+            fn(); grp[0].sync()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            grp[0].sync()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            moved = 32 * gper * (G - 1) * (1 if name.startswith("gather") else G)
+            res[name] = {"ms": ms, "bytes_moved_between_members": moved, "GBps": moved / (ms * 1e-3) / 1e9 if ms > 0 else None}
+        ordered = bool(np.array_equal(root_buf.cpu().numpy().view(np.uint64), host)) and all(bool(np.array_equal(o.cpu().numpy().view(np.uint64), host)) for o in outs)
+        res["what"] = "ordered gather of opened values, 64 MiB per member (config 5 shape), as direct peer writes (hipMemcpyPeerAsync pushes on the source's stream)"
+        res["ordered"] = ordered
+        res["peer_access_all_pairs"] = all(grp[0].peer_access(a, b) for a in range(G) for b in range(G))
+        ok = ok and ordered
+        grp[0].free(sh)
+        gather = res
+    gates = n * args.steps
+    k3_ms = float(np.mean([pm["k3_avg_launch_ms"] for pm in per_member]))
+    k1_ms = float(np.mean([pm["k1_avg_launch_ms"] for pm in per_member]))
+    ach = per * ALG_BYTES_K3 / (k3_ms * 1e-3) / 1e9
+    distinct = len(set(devs))
+    out = {
+        "metric": METRIC, "value": gates / elapsed, "unit": "gates/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)", "data": "synthetic",
+        "mode": "single-process: ONE process drives all members through arkmpc_group_* (include/arkmpc.h)",
+        "ranks_seen": G, "devices": devs, "distinct_devices": distinct,
+        "oversubscribed": distinct < G,
+        "per_member": per_member,
+        "config": {"workload": "2^%d AuthenticatedScalar Beaver muls over BN254 Fr per member per step (%d members = %d gates per step), two parties in-process, "
+                               "d||e handed over member by member (BASELINE.json configs[%d] shape)" % (args.log2n, G, n, 2 if (G == 8 and args.log2n == 21) else 1),
+                   "gates_per_gpu": per, "gates_per_step_all_gpus": n, "field": "bn254_fr", "layout": layout, "launches_per_step": 4 * G,
+                   "gates_per_launch": per, "workload_sets_rotated": nsets, "settle_ms": args.settle_ms,
+                   "parallelism": "gate-range sharding inside the C ABI, no data-path collective"},
+        "roofline": {"bound": "hbm", "kernel": "k_beaver_finish_asm (K2+K3 fused, hand-scheduled), mean over members", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": per * ALG_BYTES_K3, "gates_per_launch": per, "avg_launch_ms": k3_ms,
+                     "note": "per-member figure: with members sharing a GPU the launches of different members overlap and each one's duration stretches accordingly"},
+        "pipeline": {"k1_avg_launch_ms": k1_ms, "k3_avg_launch_ms": k3_ms},
+        "results_check": "open(batch_mul(x,y)) == x*y and MAC shares sum to key*x*y on every member's range: %s" % ("ok" if ok else "FAILED"),
+    }
+    if cold is not None:
+        out["value_cold"] = gates / cold[0]
+    if gather is not None:
+        out["gather"] = gather
+    print(json.dumps(out), flush=True)
+    for g in grp:
+        g.close()
+    for e in engs:
+        e.close()
+    if not ok:
+        raise SystemExit("result check failed")
+
+
 def main():
     args = parse()
+    if args.single_process:
+        return main_single_process(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -578,12 +773,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # cold pass FIRST: the same W warm-up + K timed steps with no settle phase -- what the driver's shape measures on a GPU that was idle
+    # while the workload was built (the power controller's transient, profiles/r02/ramp_probe.txt).  Reported beside the headline.
+    cold = None
+    if not args.no_cold and args.settle_ms > 0:
+        rc_ = run_pipeline(eng, n, sets, args.layout, args, args.steps, args.warmup, barrier, settle_ms=0)
+        cold = {"elapsed": max_over_ranks(rc_["elapsed"]), "k3_ms": rc_["k3_ms"], "k1_ms": rc_["k1_ms"], "dev_ms_per_step": rc_["dev_ms_per_step"]}
     r = run_pipeline(eng, n, sets, args.layout, args, args.steps, args.warmup, barrier)
     elapsed, k1_ms, k3_ms, dev_ms_per_step, chunks = r["elapsed"], r["k1_ms"], r["k3_ms"], r["dev_ms_per_step"], r["chunks"]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     ok = True if args.no_check else all(check_results(eng, n, ps, tr, args.layout) for ps, tr in sets[:min(len(sets), args.steps)])
     gather = None
@@ -621,13 +826,24 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": m_launch * ALG_BYTES_K3, "gates_per_launch": m_launch, "avg_launch_ms": k3_ms,
                          "avg_launch_ms_note": "HIP events bound to the kernel dispatch (hipExtLaunchKernelGGL) on sampled steps of the timed region",
-                         "rocprof_avg_launch_ms": rocprof_ms},
+                         "rocprof_avg_launch_ms": rocprof_ms,
+                         "frac_rocprof": (m_launch * ALG_BYTES_K3 / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if rocprof_ms else None,
+                         "frac_rocprof_note": "the same fraction priced with the committed rocprofv3 --kernel-trace average of this kernel (profiles/): the figure that "
+                                              "follows from profiles/ alone.  `frac` uses this run's dispatch-bound HIP events; the two differ by the profiler's own "
+                                              "effect on the kernel (see clock_effect)",
+                         "clock_effect": clock_effect()},
             "pipeline": {"algorithmic_GBps": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9,
                          "frac_of_hbm_peak": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "k1_avg_launch_ms": k1_ms, "k3_avg_launch_ms": k3_ms, "device_ms_per_step": dev_ms_per_step, "steps_with_kernel_events": r["sampled"],
                          "k1_achieved_GBps": m_launch * ALG_BYTES_K1 / (k1_ms * 1e-3) / 1e9},
             "results_check": "open(batch_mul(x,y)) == x*y and MAC shares sum to key*x*y: %s" % ("ok" if ok else "FAILED"),
         }
+        if cold is not None:
+            out["value_cold"] = gates / cold["elapsed"]
+            out["roofline"]["frac_cold"] = m_launch * ALG_BYTES_K3 / (cold["k3_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            out["cold"] = {"what": "the same %d warm-up + %d timed steps run FIRST with no settle phase (--settle-ms 0): the GPU idled while the workload was built" % (args.warmup, args.steps),
+                           "ms_per_step": cold["elapsed"] / args.steps * 1e3, "k1_avg_launch_ms": cold["k1_ms"], "k3_avg_launch_ms": cold["k3_ms"],
+                           "device_ms_per_step": cold["dev_ms_per_step"]}
         if gather is not None:
             out["gather"] = gather
         if not args.no_cpu_baseline and world == 1:

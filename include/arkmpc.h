@@ -119,6 +119,10 @@ int arkmpc_batch_slice(arkmpc_ctx* ctx, arkmpc_batch* batch, size_t lo, size_t c
 int arkmpc_batch_retain(arkmpc_batch* batch);                      /* Clone of the handle: one more reference */
 /* Drop of one handle; the storage returns to the pool (ordered on ctx's stream, like arkmpc_free) with the last reference */
 int arkmpc_batch_destroy(arkmpc_ctx* ctx, arkmpc_batch* batch);
+/* the share (which = 0) or MAC (1) column of a ScalarShare batch in ARKMPC_LAYOUT_SPLIT as a Scalar batch that SHARES the storage:
+ * the `.share()` projection open_batch sends (authenticated_scalar.rs:141-145) without a copy.  AoS batches: ARKMPC_ERR_UNSUPPORTED
+ * (their columns are strided; use arkmpc_share_extract). */
+int arkmpc_batch_column(arkmpc_ctx* ctx, arkmpc_batch* batch, int which, arkmpc_batch** out_batch);
 size_t arkmpc_batch_len(const arkmpc_batch* batch);
 int arkmpc_batch_kind(const arkmpc_batch* batch);
 int arkmpc_batch_layout(const arkmpc_batch* batch);
@@ -148,6 +152,11 @@ int arkmpc_scalar_batch_inverse(arkmpc_ctx* ctx, size_t n, const uint64_t* a, ui
 /* inclusive prefix products out_i = a_0 * ... * a_i: the public scan inside the prefix_product gadget (gadgets.rs:131-137),
  * there a sequential chain of ScalarResult multiplications; here a parallel scan (multiplication is associative). */
 int arkmpc_scalar_prefix_product(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
+/* reductions to ONE element (`out` follows the context's buffer mode like every other buffer): Sum / Product for ScalarResult
+ * (scalar_result.rs:325-338 and Iterator::sum); n = 0 gives 0 / 1.  The reference folds left to right; + and * are associative and
+ * commutative on canonical residues, so the tree used here returns the same words. */
+int arkmpc_scalar_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
+int arkmpc_scalar_product(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out);
 /* canonical little-endian integers (< 2^256, reduced mod p on the way in) <-> Montgomery form */
 int arkmpc_scalar_from_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);
 int arkmpc_scalar_to_canonical(arkmpc_ctx* ctx, size_t n, const uint64_t* in, uint64_t* out);
@@ -164,6 +173,19 @@ int arkmpc_share_sub_public(arkmpc_ctx* ctx, size_t n, int party_id, const uint6
                             const uint64_t* a, const uint64_t* pub, uint64_t* out);                              /* batch_sub_public :691-733 */
 int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* pub, uint64_t* out);  /* batch_mul_public :883-916 */
 
+/* column forms (share / MAC base pointers + element stride in u64 units: 4 = split columns, 8 = AoS view with mac = share + 4) of the
+ * public-operand ops, for ScalarShare batches kept in the engine-native split layout; device pointers only */
+int arkmpc_share_add_public_v(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* a_share,
+                              const uint64_t* a_mac, size_t a_stride, const uint64_t* pub, uint64_t* out_share, uint64_t* out_mac,
+                              size_t out_stride);
+int arkmpc_share_sub_public_v(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* a_share,
+                              const uint64_t* a_mac, size_t a_stride, const uint64_t* pub, uint64_t* out_share, uint64_t* out_mac,
+                              size_t out_stride);
+int arkmpc_share_mul_public_v(arkmpc_ctx* ctx, size_t n, const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
+                              const uint64_t* pub, uint64_t* out_share, uint64_t* out_mac, size_t out_stride);
+/* Sum for ScalarShare / AuthenticatedScalarResult (share.rs:103-111, authenticated_scalar.rs:563-575): n ScalarShares -> ONE
+ * ScalarShare (sum of shares, sum of MACs); n = 0 gives (0, 0) */
+int arkmpc_share_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share);
 /* layout converters: arkworks AoS ScalarShare records <-> engine-native split columns (n shares, then n MACs).
  * Import once, run the _v entry points on the columns (no dead MAC bytes in K1, cacheable re-reads), export at the end. */
 int arkmpc_share_split(arkmpc_ctx* ctx, size_t n, const uint64_t* aos, uint64_t* out_share_col, uint64_t* out_mac_col);
@@ -274,7 +296,9 @@ int arkmpc_scalarshare_mul_generator(arkmpc_ctx* ctx, size_t n, const uint64_t* 
  *     out = ([a] + d) * eG + ([c] + d [b]) * G
  * which equals the reference's deG + d[bG] + [a]eG + [c]G share by share and MAC by MAC ([bG] = [b]G; "[a] + d" is
  * ScalarShare::add_public, share.rs:74-77): 2 variable-base + 2 generator scalar-muls per element instead of 6 + 2.
- * out: n PointShares.  arkmpc_edpoint_beaver_finish is the same gate on a CURVE25519_FR context (16-word points). */
+ * out: n PointShares.  arkmpc_edpoint_beaver_finish is the same gate on a CURVE25519_FR context (16-word points).
+ * A composite of six entry points, each taking the context lock on its own: calls of other threads on the SAME context may interleave
+ * between them (harmless -- they are ordered on the one stream -- but the gate is not atomic with respect to them). */
 int arkmpc_point_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d_open,
                                const uint64_t* eG_open, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out_shares);
 int arkmpc_edpoint_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* d_open,

@@ -183,6 +183,28 @@ void ora_scalar_prefix_product(int fid, size_t n, const u64* a, u64* out) {
     u64 run[4]; memcpy(run, f->r, 32);
     for (size_t i = 0; i < n; ++i) { ora_fp_mul(f, run, a + 4 * i, run); memcpy(out + 4 * i, run, 32); }
 }
+/* Iterator::sum / Product for ScalarResult (scalar_result.rs:325-338 `args.map(Scalar::from).product()`; scalar.rs Sum / Product impls):
+ * a left-to-right fold from 0 / 1 */
+void ora_scalar_sum(int fid, size_t n, const u64* a, u64 out[4]) {
+    const ora_field* f = ora_get_field(fid);
+    u64 run[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; ++i) ora_fp_add(f, run, a + 4 * i, run);
+    memcpy(out, run, 32);
+}
+void ora_scalar_product(int fid, size_t n, const u64* a, u64 out[4]) {
+    const ora_field* f = ora_get_field(fid);
+    u64 run[4]; memcpy(run, f->r, 32);
+    for (size_t i = 0; i < n; ++i) ora_fp_mul(f, run, a + 4 * i, run);
+    memcpy(out, run, 32);
+}
+/* Sum for ScalarShare (share.rs:103-111): unzip into shares and macs, sum each; the gate of Sum for AuthenticatedScalarResult
+ * (authenticated_scalar.rs:563-575) */
+void ora_share_sum(int fid, size_t n, const u64* shares, u64 out[8]) {
+    const ora_field* f = ora_get_field(fid);
+    u64 s[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; ++i) { ora_fp_add(f, s, shares + 8 * i, s); ora_fp_add(f, m, shares + 8 * i + 4, m); }
+    memcpy(out, s, 32); memcpy(out + 4, m, 32);
+}
 /* scalar.rs:93-100 -> ark_ff::batch_inversion: non-zero elements inverted, zeros unchanged */
 void ora_scalar_batch_inverse(int fid, size_t n, const u64* a, u64* out) {
     const ora_field* f = ora_get_field(fid);

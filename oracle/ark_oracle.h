@@ -64,6 +64,9 @@ void ora_scalar_batch_add(int field_id, size_t n, const u64* a, const u64* b, u6
 void ora_scalar_batch_sub(int field_id, size_t n, const u64* a, const u64* b, u64* out);
 void ora_scalar_batch_mul(int field_id, size_t n, const u64* a, const u64* b, u64* out);   /* scalar_result.rs:257-278 */
 void ora_scalar_batch_neg(int field_id, size_t n, const u64* a, u64* out);
+void ora_scalar_sum(int field_id, size_t n, const u64* a, u64 out[4]);          /* Iterator::sum over Scalars */
+void ora_scalar_product(int field_id, size_t n, const u64* a, u64 out[4]);      /* scalar_result.rs:325-338 */
+void ora_share_sum(int field_id, size_t n, const u64* shares, u64 out[8]);      /* share.rs:103-111 */
 void ora_scalar_batch_inverse(int field_id, size_t n, const u64* a, u64* out);    /* scalar.rs:93-100 */
 void ora_scalar_prefix_product(int field_id, size_t n, const u64* a, u64* out);   /* gadgets.rs:131-137 */
 

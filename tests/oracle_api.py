@@ -58,6 +58,13 @@ class Oracle:
     def scalar_mul(self, fid, a, b): return self.bin("ora_scalar_batch_mul", fid, len(a) // 4, a, b, 4)
     def scalar_neg(self, fid, a): return self.un("ora_scalar_batch_neg", fid, len(a) // 4, a, 4)
     def scalar_prefix_product(self, fid, a): return self.un("ora_scalar_prefix_product", fid, len(a) // 4, a, 4)
+    def scalar_sum(self, fid, a): return self._red("ora_scalar_sum", fid, len(a) // 4, a, 4)
+    def scalar_product(self, fid, a): return self._red("ora_scalar_product", fid, len(a) // 4, a, 4)
+    def share_sum(self, fid, a): return self._red("ora_share_sum", fid, len(a) // 8, a, 8)
+    def _red(self, name, fid, n, a, out_words):
+        out = np.zeros(out_words, dtype=np.uint64)
+        self._call(name, fid, n, np.ascontiguousarray(a, dtype=np.uint64), out)
+        return out
     def scalar_batch_inverse(self, fid, a): return self.un("ora_scalar_batch_inverse", fid, len(a) // 4, a, 4)
     def share_add(self, fid, a, b): return self.bin("ora_share_batch_add", fid, len(a) // 8, a, b, 8)
     def share_sub(self, fid, a, b): return self.bin("ora_share_batch_sub", fid, len(a) // 8, a, b, 8)

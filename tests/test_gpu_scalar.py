@@ -47,6 +47,25 @@ def test_scalar_ops(engines, oracle, fid, n):
 
 
 @pytest.mark.parametrize("fid", FIDS)
+@pytest.mark.parametrize("n", [0, 1, 255, 257, 1000, 300001])
+def test_scalar_and_share_reductions(engines, oracle, fid, n):
+    """arkmpc_scalar_sum / _product / arkmpc_share_sum vs the oracle's left-to-right folds (scalar_result.rs:325-338, share.rs:103-111):
+    empty input, one workgroup, two levels, more than RED_MAX_BLOCKS workgroups' worth of elements."""
+    e = engines[fid]
+    vals = mixed_values(fid, min(n, 2000), seed=17 * n + fid)
+    a = mont_array(fid, vals)
+    if n > 2000:                                              # large case: tile the small vector (python big-int setup stays cheap)
+        a = np.ascontiguousarray(np.tile(a.reshape(-1, 4), ((n + 1999) // 2000, 1))[:n].reshape(-1))
+    out = _z(1, 4); e.scalar_sum(n, a, out)
+    assert np.array_equal(out, oracle.scalar_sum(fid, a))
+    out = _z(1, 4); e.scalar_product(n, a, out)
+    assert np.array_equal(out, oracle.scalar_product(fid, a))
+    rec = np.ascontiguousarray(np.concatenate([a.reshape(-1, 4), a.reshape(-1, 4)[::-1]], axis=1).reshape(-1))
+    out = _z(1, 8); e.share_sum(n, rec, out)
+    assert np.array_equal(out, oracle.share_sum(fid, rec))
+
+
+@pytest.mark.parametrize("fid", FIDS)
 @pytest.mark.parametrize("n", [1, 300])
 @pytest.mark.parametrize("party", [0, 1])
 def test_share_ops(engines, oracle, fid, n, party):

@@ -26,6 +26,15 @@ def link_mode(request):
     os.environ.pop("ARKMPC_MOCK_LINK", None)
 
 
+@pytest.fixture(params=["split", "aos"], autouse=True)
+def share_layout(request):
+    """... and in both HBM layouts of the mirror's AuthenticatedScalarBatch: the engine-native split columns (the default: K1 reads no dead
+    MAC bytes, the opening payload is the share column itself) and arkworks' AoS records."""
+    os.environ["ARKMPC_SHARE_LAYOUT"] = request.param
+    yield request.param
+    os.environ.pop("ARKMPC_SHARE_LAYOUT", None)
+
+
 def run(tmp_path, scenario, fid, a, b, *flags):
     n = len(a)
     inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
@@ -80,6 +89,23 @@ def test_circuit(tmp_path):
     a, b = rand_values(fid, n, 21), mixed_values(fid, n, 22)
     res = run(tmp_path, "circuit", fid, a, b)
     want = [(-(x * x - y * y) * x + x - y) % p for x, y in zip(a, b)]
+    assert res[0] == (0, want) and res[1] == (0, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fid,n", [(0, 1), (0, 300), (2, 77)])
+def test_api_tail_pow_sum_constants(tmp_path, fid, n):
+    """pow (authenticated_scalar.rs:86-100; pow(0) is the shared ZERO wire in the reference, pow(1) a clone), batch_add_constant (:531-560),
+    Sum for AuthenticatedScalarResult (:563-575), ones_authenticated (fabric.rs:525-534), Sum / Product for ScalarResult
+    (scalar_result.rs:325-338) and ScalarResult::batch_add_constant / batch_sub_constant, in one circuit with exact-integer expectations."""
+    import functools
+    p = pyref.P[fid]
+    a, b = mixed_values(fid, n, 41), rand_values(fid, n, 42)
+    res = run(tmp_path, "tail", fid, a, b)
+    S = sum(pow(x, 5, p) + y for x, y in zip(a, b)) % p
+    P = functools.reduce(lambda u, v: u * v % p, b, 1)
+    T = sum(b) % p
+    want = [(pow(x, 5, p) + y + S + 0 + 1 + P + T - y - x) % p for x, y in zip(a, b)]
     assert res[0] == (0, want) and res[1] == (0, want)
 
 

@@ -120,3 +120,19 @@ def test_prefix_product_vs_bigint(oracle):
     for v in vals:
         run = run * v % p; want.append(run)
     assert got == want
+
+
+@pytest.mark.parametrize("fid", FIDS)
+def test_reductions_vs_bigint(oracle, fid):
+    """Sum / Product for ScalarResult and Sum for ScalarShare (scalar_result.rs:325-338, share.rs:103-111) against Python ints,
+    including the empty fold (0 / 1)."""
+    import functools
+    p = pyref.P[fid]
+    for n in (0, 1, 2, 257):
+        a = mixed_values(fid, n, seed=900 + n + fid)
+        am = mont_array(fid, a)
+        assert from_mont_array(fid, oracle.scalar_sum(fid, am)) == [sum(a) % p]
+        assert from_mont_array(fid, oracle.scalar_product(fid, am)) == [functools.reduce(lambda x, y: x * y % p, a, 1)]
+        b = mixed_values(fid, n, seed=901 + n + fid)[::-1]
+        rec = np.ascontiguousarray(np.concatenate([am.reshape(-1, 4), mont_array(fid, b).reshape(-1, 4)], axis=1).reshape(-1))
+        assert from_mont_array(fid, oracle.share_sum(fid, rec)) == [sum(a) % p, sum(b) % p]

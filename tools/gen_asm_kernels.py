@@ -379,7 +379,7 @@ class Emu:
 # ------------------------------------------------------------------------------------------------
 def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False, lds=False):
     global NT_BASES, LDS_MODE
-    NT_BASES = NT_SPLIT if nt else NT_AOS
+    NT_BASES = (NT_SPLIT - {"out_s", "out_m"} if nt == 2 else NT_SPLIT) if nt else NT_AOS     # nt = 2: hints on the loads only
     LDS_MODE = lds
     try:
         return _build_beaver_finish(p, first_vgpr, key_names, sched, lds)
@@ -589,7 +589,8 @@ def emit_header(path):
     out = []
     out.append("// GENERATED by tools/gen_asm_kernels.py -- do not edit.  Hand-scheduled gfx950 bodies; see the generator for")
     out.append("// the hazard rules (H1-H4), the register map and the single-lane emulator that validates each stream.")
-    out.append("// beaver_finish_asm<F, NT>: NT = 1 adds non-temporal hints on once-streamed data (split-column layout).")
+    out.append("// beaver_finish_asm<F, NT>: NT = 1 adds non-temporal hints on once-streamed data (split-column layout); NT = 2 on the loads only")
+    out.append("// (non-temporal 16-byte stores 32 B apart leave the L2 as partial lines: WRITE_SIZE +23..34 % on pure store kernels, probes/write_calib.hip).")
     out.append("#pragma once")
     stats = []
     for fid, (name, p) in enumerate(FIELDS):
@@ -597,8 +598,8 @@ def emit_header(path):
             continue
         selftest_finish(p, trials=16, seed=fid)               # emulator check (uses placeholder SGPR names for the key)
         out.append("template <> struct HasAsmFinish<%d> { static constexpr bool value = true; };" % fid)
-        for nt in (0, 1):
-            E, mp = build_beaver_finish(p, nt=bool(nt))        # same stream with the asm operand names %[k0]..%[k7]
+        for nt in (0, 1, 2):
+            E, mp = build_beaver_finish(p, nt=nt)              # same stream with the asm operand names %[k0]..%[k7]
             nvalu = sum(1 for i in E.order if i.op in ("mov", "mad", "mul_lo", "addco", "addc", "subco", "subb", "cnd", "and"))
             nmad = sum(1 for i in E.order if i.op == "mad")
             if nt == 0:
