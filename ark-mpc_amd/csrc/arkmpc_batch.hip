@@ -274,6 +274,13 @@ int arkmpc_edpoint_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const 
 // ---- events: device-side ordering between the streams of two contexts ---------------------------------------------------------
 }  // extern "C"
 struct arkmpc_event { hipEvent_t ev; int device; };
+// hipEventCreate / hipEventDestroy cost microseconds each and a latency-bound circuit records one event per message: retired events are
+// kept per device and recorded again.  Re-recording is safe once the consumers have ISSUED their waits (hipStreamWaitEvent binds to the
+// record that is current when it is called), which is what arkmpc_event_destroy's contract already requires.
+namespace {
+std::mutex g_ev_mu;
+std::vector<arkmpc_event*> g_ev_free[16];
+}
 extern "C" {
 int arkmpc_event_record(arkmpc_ctx* ctx, arkmpc_event** out) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
@@ -281,11 +288,20 @@ int arkmpc_event_record(arkmpc_ctx* ctx, arkmpc_event** out) {
     if (guard.rc) return guard.rc;
     if (!out) return ark_bad(ctx, "null out");
     *out = nullptr;
-    hipEvent_t ev;
-    ARK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(ev, ctx->stream);
-    if (e != hipSuccess) { (void)hipEventDestroy(ev); ark_set_err(ctx, std::string("hipEventRecord: ") + hipGetErrorString(e)); return ARKMPC_ERR_HIP; }
-    *out = new arkmpc_event{ev, ctx->device};
+    arkmpc_event* e = nullptr;
+    if (ctx->device < 16) {
+        std::lock_guard<std::mutex> lk(g_ev_mu);
+        auto& fl = g_ev_free[ctx->device];
+        if (!fl.empty()) { e = fl.back(); fl.pop_back(); }
+    }
+    if (!e) {
+        hipEvent_t ev;
+        ARK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e = new arkmpc_event{ev, ctx->device};
+    }
+    hipError_t err = hipEventRecord(e->ev, ctx->stream);
+    if (err != hipSuccess) { (void)hipEventDestroy(e->ev); delete e; ark_set_err(ctx, std::string("hipEventRecord: ") + hipGetErrorString(err)); return ARKMPC_ERR_HIP; }
+    *out = e;
     return ARKMPC_OK;
 }
 int arkmpc_event_wait(arkmpc_ctx* ctx, arkmpc_event* event) {
@@ -298,6 +314,10 @@ int arkmpc_event_wait(arkmpc_ctx* ctx, arkmpc_event* event) {
 }
 int arkmpc_event_destroy(arkmpc_event* event) {
     if (!event) return ARKMPC_ERR_BAD_ARG;
+    if (event->device >= 0 && event->device < 16) {
+        std::lock_guard<std::mutex> lk(g_ev_mu);
+        if (g_ev_free[event->device].size() < 4096) { g_ev_free[event->device].push_back(event); return ARKMPC_OK; }
+    }
     (void)hipEventDestroy(event->ev);          // HIP defers the release until the event has completed
     delete event;
     return ARKMPC_OK;

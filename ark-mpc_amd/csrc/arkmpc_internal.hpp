@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -38,6 +39,12 @@ struct arkmpc_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
     // small pinned buffer (64 KiB): window sums of the MSM for the host-side Horner fold
     unsigned char* h_small = nullptr;
+    // per-context block cache in front of the device pool (arkmpc_malloc / arkmpc_free): a block freed through this context was last
+    // used on THIS context's stream (the contract of arkmpc_free), so the same context may hand it out again with no event at all --
+    // whatever uses it next is ordered behind the earlier use by the stream itself.  Keyed by size class; spills to the device pool
+    // (with an event) above cache_cap.
+    std::unordered_map<size_t, std::vector<void*>> cache;
+    size_t cache_bytes = 0;
     // kernel timer: event pairs bound to the dispatch of the NEXT K1 / K3 launch (hipExtLaunchKernelGGL)
     static constexpr int kTimerSlots = 64;
     hipEvent_t tev[2 * kTimerSlots] = {};

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(TPB) k_share_extract(size_t n, const u64* a, u
 // K1: d_i = x_i.share - a_i.share ; e_i = y_i.share - b_i.share ; out = d || e  (:863-868, :141-145).
 // The MAC halves of d and e are dead in the reference (only `.share()` is sent), so they are not computed.
 template <int F, int NT>   // NT bit0: x,y non-temporal ; bit1: a,b non-temporal ; bit2: d||e stores non-temporal
-__global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col a, Col b, u64* out_d, u64* out_e) {
+__global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col a, Col b, u64* out_d, u64* out_e, u64* dup_d, u64* dup_e) {
     size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     Fe xs = (NT & 1) ? fe_load_nt(x.p + (size_t)x.stride * i) : fe_load(x.p + (size_t)x.stride * i);
@@ -250,6 +250,10 @@ __global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col
     } else {
         fe_store(out_d + 4 * i, fe_sub<F>(xs, as));
         fe_store(out_e + 4 * i, fe_sub<F>(ys, bs));
+    }
+    if (dup_d) {            // the same payload a second time: the copy that is handed to the link (uniform branch)
+        fe_store(dup_d + 4 * i, fe_sub<F>(xs, as));
+        fe_store(dup_e + 4 * i, fe_sub<F>(ys, bs));
     }
 }
 // K2: open_batch combine gate (:161-171)
@@ -418,19 +422,20 @@ static int k1_nt_mode() {
     return v;
 }
 template <int F>
-static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u64* out, u64* out_e = nullptr) {
+static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u64* out, u64* out_e = nullptr, u64* dup = nullptr) {
     if (!out_e) out_e = out + 4 * n;                     // d||e in one buffer unless the caller places e itself
+    u64* dup_e = dup ? dup + 4 * n : nullptr;
     dim3 g(blocks_for(n, TPB)), t(TPB);
     const bool split = x.stride == 4 && y.stride == 4 && a.stride == 4 && b.stride == 4;
     static const int aos_mode = getenv("ARKMPC_K1_NT_AOS") ? atoi(getenv("ARKMPC_K1_NT_AOS")) & 7 : 0;
     switch (split ? k1_nt_mode() : aos_mode) {
-        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out, out_e); break;
-        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out, out_e); break;
-        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out, out_e); break;
-        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out, out_e); break;
-        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out, out_e); break;
-        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out, out_e); break;
-        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out, out_e); break;
+        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
+        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
+        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
+        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
+        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
+        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
+        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
     }
 }
 
@@ -531,6 +536,10 @@ size_t pool_cap() {
     static const size_t cap = getenv("ARKMPC_POOL_MAX_MB") ? (size_t)atoll(getenv("ARKMPC_POOL_MAX_MB")) << 20 : (size_t)16 << 30;
     return cap;
 }
+size_t ctx_cache_cap() {      // bytes a context keeps in its own event-free cache before spilling to the device pool
+    static const size_t cap = getenv("ARKMPC_CTX_CACHE_MB") ? (size_t)atoll(getenv("ARKMPC_CTX_CACHE_MB")) << 20 : (size_t)2 << 30;
+    return cap;
+}
 size_t pool_class(size_t bytes) {
     if (bytes < 256) bytes = 256;
     if (bytes >= ((size_t)1 << 20)) return (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
@@ -552,11 +561,10 @@ void pool_reclaim(DevicePool& p, bool wait) {
 }
 void pool_release_all(DevicePool& p) {   // caller holds p.mu; blocks everything pending first
     pool_reclaim(p, true);
-    for (auto& kv : p.free_) for (void* q : kv.second) (void)hipFree(q);
+    for (auto& kv : p.free_) for (void* q : kv.second) { (void)hipFree(q); p.cached -= kv.first; }     // (blocks in context caches stay counted)
     p.free_.clear();
     for (hipEvent_t e : p.events_) (void)hipEventDestroy(e);
     p.events_.clear();
-    p.cached = 0;
 }
 }  // namespace
 
@@ -605,6 +613,10 @@ int arkmpc_ctx_destroy(arkmpc_ctx* ctx) {
     if (ctx->device < 16) {          // the last context of a device returns the cached blocks
         DevicePool& p = g_pool[ctx->device];
         std::lock_guard<std::mutex> lk(p.mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);         // the context's own cache joins the pool: its stream has drained, no event needed
+        for (auto& kv : ctx->cache) for (void* q : kv.second) p.free_[kv.first].push_back(q);
+        ctx->cache.clear(); ctx->cache_bytes = 0;
         if (--p.refs == 0) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); pool_release_all(p); }
     }
     {
@@ -684,6 +696,17 @@ int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
     DevicePool& p = g_pool[ctx->device];
     const size_t cls = pool_class(bytes);
     std::lock_guard<std::mutex> lk(p.mu);
+    {   // the context's own cache: no event, no query -- stream order is the guarantee
+        auto ci = ctx->cache.find(cls);
+        if (ci != ctx->cache.end() && !ci->second.empty()) {
+            *out_dptr = ci->second.back();
+            ci->second.pop_back();
+            ctx->cache_bytes -= cls;
+            p.cached -= cls;
+            p.live_[*out_dptr] = cls;
+            return ARKMPC_OK;
+        }
+    }
     auto it = p.free_.find(cls);
     if (it == p.free_.end() || it->second.empty()) { pool_reclaim(p, false); it = p.free_.find(cls); }
     if (it != p.free_.end() && !it->second.empty()) {
@@ -694,6 +717,9 @@ int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
         hipError_t e = hipMalloc(out_dptr, cls);
         if (e != hipSuccess && p.cached) {       // out of memory with blocks cached: give them back and retry
             (void)hipGetLastError();
+            (void)hipStreamSynchronize(ctx->stream);
+            for (auto& kv : ctx->cache) for (void* q : kv.second) { (void)hipFree(q); p.cached -= kv.first; }
+            ctx->cache.clear(); ctx->cache_bytes = 0;
             pool_release_all(p);
             e = hipMalloc(out_dptr, cls);
         }
@@ -712,6 +738,12 @@ int arkmpc_free(arkmpc_ctx* ctx, void* dptr) {
         if (it != p.live_.end()) {
             const size_t cls = it->second;
             p.live_.erase(it);
+            if (ctx->cache_bytes + cls <= ctx_cache_cap() && p.cached + cls <= pool_cap()) {     // keep it for this context: no event needed
+                ctx->cache[cls].push_back(dptr);
+                ctx->cache_bytes += cls;
+                p.cached += cls;
+                return ARKMPC_OK;
+            }
             if (p.cached + cls > pool_cap()) {           // over the cap: a real free (waits for the device)
                 ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 ARK_HIP(ctx, hipFree(dptr));
@@ -966,14 +998,16 @@ int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const 
 // ---------------------------------------------------------------------------------------------
 // C ABI: Beaver multiplication
 // ---------------------------------------------------------------------------------------------
-static bool stride_ok(size_t s) { return s >= 4 && (s % 2) == 0 && s <= 0xffffffffu; }
+// element stride of a column view in u64 units; 0 = broadcast: every element reads the one record at the base pointer (the constant
+// batches of a preprocessing source -- `vec![share; n]`, offline_prep.rs:137-158 -- without materialising n copies)
+static bool stride_ok(size_t s) { return s == 0 || (s >= 4 && (s % 2) == 0 && s <= 0xffffffffu); }
 
 static int share_public_v(arkmpc_ctx* ctx, int op, size_t n, int party, const uint64_t key[4], const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
                           const uint64_t* pub, uint64_t* out_share, uint64_t* out_mac, size_t out_stride) {
     ENTER(ctx);
     if (op != OP_MUL && !party_ok(party)) return ark_bad(ctx, "party_id must be 0 or 1");
     if (op != OP_MUL && !key) return ark_bad(ctx, "null mac_key");
-    if (!stride_ok(a_stride) || !stride_ok(out_stride)) return ark_bad(ctx, "bad stride");
+    if (!stride_ok(a_stride) || !stride_ok(out_stride) || !out_stride) return ark_bad(ctx, "bad stride");
     if (ctx->host_buffers) return ark_bad(ctx, "share-view entry points take device pointers only");
     if (n && (!a_share || !a_mac || !pub || !out_share || !out_mac)) return ark_bad(ctx, "null pointer");
     if (((uintptr_t)a_share | (uintptr_t)a_mac | (uintptr_t)pub | (uintptr_t)out_share | (uintptr_t)out_mac) & 15) return ark_bad(ctx, "device pointer not 16-byte aligned");
@@ -1087,7 +1121,7 @@ int arkmpc_beaver_finish_fused_v(arkmpc_ctx* ctx, size_t n, int party_id, const 
     ENTER(ctx);
     if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
     if (!mac_key) return ark_bad(ctx, "null mac_key");
-    if (!stride_ok(a_stride) || !stride_ok(b_stride) || !stride_ok(c_stride) || !stride_ok(out_stride)) return ark_bad(ctx, "bad stride");
+    if (!stride_ok(a_stride) || !stride_ok(b_stride) || !stride_ok(c_stride) || !stride_ok(out_stride) || !out_stride) return ark_bad(ctx, "bad stride");
     if (ctx->host_buffers) return ark_bad(ctx, "share-view entry points take device pointers only");
     if (n && (!my_de || !peer_de || !a_share || !a_mac || !b_share || !b_mac || !c_share || !c_mac || !out_share || !out_mac)) return ark_bad(ctx, "null pointer");
     if (((uintptr_t)my_de | (uintptr_t)peer_de | (uintptr_t)a_share | (uintptr_t)a_mac | (uintptr_t)b_share | (uintptr_t)b_mac |
@@ -1125,6 +1159,25 @@ int arkmpc_beaver_mask_to(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, si
     }
     return ARKMPC_OK;
 }
+// K1 that writes the payload twice: out_de stays with the party (its own K2+K3 reads it), out_de_msg is the message handed to the link.
+// network/mock.rs MOVES a payload to the peer; a device-resident link must not alias a buffer the sender still reads (the two parties'
+// streams are not ordered against each other's later reuse), so the alternative is a device-to-device copy after K1 -- one more launch
+// in the dependent chain of every round and 128 B per gate of extra traffic.
+int arkmpc_beaver_mask_dup(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share, size_t y_stride,
+                           const uint64_t* a_share, size_t a_stride, const uint64_t* b_share, size_t b_stride, uint64_t* out_de, uint64_t* out_de_msg) {
+    ENTER(ctx);
+    if (!stride_ok(x_stride) || !stride_ok(y_stride) || !stride_ok(a_stride) || !stride_ok(b_stride)) return ark_bad(ctx, "bad stride");
+    if (ctx->host_buffers) return ark_bad(ctx, "share-view entry points take device pointers only");
+    if (n && (!x_share || !y_share || !a_share || !b_share || !out_de || !out_de_msg)) return ark_bad(ctx, "null pointer");
+    if (((uintptr_t)x_share | (uintptr_t)y_share | (uintptr_t)a_share | (uintptr_t)b_share | (uintptr_t)out_de | (uintptr_t)out_de_msg) & 15)
+        return ark_bad(ctx, "device pointer not 16-byte aligned");
+    if (n) {
+        Col x{x_share, (u32)x_stride}, y{y_share, (u32)y_stride}, a{a_share, (u32)a_stride}, b{b_share, (u32)b_stride};
+        DISPATCH_FIELD(ctx, launch_mask<F>(ctx, n, x, y, a, b, out_de, nullptr, out_de_msg));
+        ARK_HIP(ctx, hipGetLastError());
+    }
+    return ARKMPC_OK;
+}
 int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4], const uint64_t* my_d, const uint64_t* my_e,
                                     const uint64_t* peer_d, const uint64_t* peer_e, const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
                                     const uint64_t* b_share, const uint64_t* b_mac, size_t b_stride, const uint64_t* c_share,
@@ -1132,7 +1185,7 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
     ENTER(ctx);
     if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
     if (!mac_key) return ark_bad(ctx, "null mac_key");
-    if (!stride_ok(a_stride) || !stride_ok(b_stride) || !stride_ok(c_stride) || !stride_ok(out_stride)) return ark_bad(ctx, "bad stride");
+    if (!stride_ok(a_stride) || !stride_ok(b_stride) || !stride_ok(c_stride) || !stride_ok(out_stride) || !out_stride) return ark_bad(ctx, "bad stride");
     if (ctx->host_buffers) return ark_bad(ctx, "range entry points take device pointers only");
     if (n && (!my_d || !my_e || !peer_d || !peer_e || !a_share || !a_mac || !b_share || !b_mac || !c_share || !c_mac || !out_share || !out_mac))
         return ark_bad(ctx, "null pointer");

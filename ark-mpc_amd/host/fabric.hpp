@@ -103,6 +103,8 @@ class DeviceBuf {
         check(e_->dev(), arkmpc_batch_create(e_->dev(), kind, layout, n, &b_), "batch_create");
         words_ = n * arkmpc_batch_elem_words(b_);
     }
+    // a second owner of the same storage (Clone of the handle: arkmpc_batch_retain)
+    DeviceBuf share() const { DeviceBuf d; if (b_) { arkmpc_batch_retain(b_); d.e_ = e_; d.b_ = b_; d.words_ = words_; } return d; }
     // take over a handle the C ABI returned (arkmpc_batch_from_host, arkmpc_batch_column, ...)
     static DeviceBuf adopt(std::shared_ptr<Engine> e, arkmpc_batch* b) {
         DeviceBuf d; d.e_ = std::move(e); d.b_ = b; d.words_ = arkmpc_batch_len(b) * arkmpc_batch_elem_words(b); return d;
@@ -126,9 +128,9 @@ class DeviceBuf {
     // returns to the pool ordered on the dropping context's stream)
     void rebind(std::shared_ptr<Engine> e) { e_ = std::move(e); }
     void upload(const void* host, size_t bytes) { if (bytes) check(e_->dev(), arkmpc_memcpy_h2d(e_->dev(), ptr(), host, bytes), "h2d"); }
-    void download(void* host, size_t bytes) const {
-        check(e_->dev(), arkmpc_sync(e_->dev()), "sync");
+    void download(void* host, size_t bytes) const {          // the copy runs on the context's stream, behind everything submitted so far, and blocks
         if (bytes) check(e_->dev(), arkmpc_memcpy_d2h(e_->dev(), host, ptr(), bytes), "d2h");
+        else check(e_->dev(), arkmpc_sync(e_->dev()), "sync");
     }
 
   private:
@@ -505,6 +507,14 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         NetworkOutbound m{next_id_++, {}, {}, std::move(copy), std::shared_ptr<arkmpc_event>(ev, [](arkmpc_event* e) { arkmpc_event_destroy(e); })};
         net_->send(std::move(m));
     }
+    // device hand-over of a buffer the sender GIVES UP (no copy): the message owns it from here on
+    void send_device_owned(std::shared_ptr<DeviceBuf> buf, size_t words) {
+        buf->set_words(words);
+        arkmpc_event* ev = nullptr;
+        check(ctx(), arkmpc_event_record(ctx(), &ev), "event_record");
+        NetworkOutbound m{next_id_++, {}, {}, std::move(buf), std::shared_ptr<arkmpc_event>(ev, [](arkmpc_event* e) { arkmpc_event_destroy(e); })};
+        net_->send(std::move(m));
+    }
     void await_device(const NetworkOutbound& m) {
         if (m.ready) check(ctx(), arkmpc_event_wait(ctx(), m.ready.get()), "event_wait");
     }
@@ -513,15 +523,16 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // error here, before any kernel sees the buffer (the reference's `.into()` casts panic on a malformed value,
     // fabric/result.rs:127-233).  kAnyCount: the caller checks.
     static constexpr size_t kAnyCount = ~(size_t)0;
-    ScalarBatch receive_values(size_t expect = kAnyCount) {
-        ScalarBatch b = receive_values_unchecked();
+    static constexpr uint64_t kNextId = ~(uint64_t)0;
+    ScalarBatch receive_values(size_t expect = kAnyCount, uint64_t id = kNextId) {
+        ScalarBatch b = receive_values_unchecked(id);
         if (expect != kAnyCount && b.n != expect)
             throw std::runtime_error("MpcNetworkError: peer sent " + std::to_string(b.n) + " scalars where " + std::to_string(expect) + " were expected");
         return b;
     }
-    ScalarBatch receive_values_unchecked() {
+    ScalarBatch receive_values_unchecked(uint64_t id = kNextId) {
+        if (id == kNextId) id = next_id_++;
         NetworkOutbound m = net_->receive();
-        const uint64_t id = next_id_++;
         if (link_ == LinkMode::Device) {
             if (!m.dev) throw std::runtime_error("MpcNetworkError: device link message without a buffer");
             await_device(m);
@@ -541,9 +552,39 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         return b;
     }
     // both parties send a batch of the same length (every exchange on this path is symmetric): the peer's must match
+    // Result ids: party 0 allocates send-then-receive, party 1 receive-then-send (fabric.rs:752-767), so the two sides stay in lock-step.
+    // In the reference both operations only enqueue; here receive blocks, so party 1 takes its receive id first, SENDS, and only then
+    // waits -- neither party's message is held back by the other's (one network latency per round, not two).
     ScalarBatch exchange_values(const ScalarBatch& mine) {
         if (party_ == PARTY0) { send_values(mine); return receive_values(mine.n); }
-        ScalarBatch peer = receive_values(mine.n); send_values(mine); return peer;
+        const uint64_t rid = next_id_++;
+        send_values(mine);
+        return receive_values(mine.n, rid);
+    }
+    // exchange_values for a device-link payload the caller gives up (see send_device_owned)
+    ScalarBatch exchange_device_owned(std::shared_ptr<DeviceBuf> mine, size_t words, size_t expect_n) {
+        if (party_ == PARTY0) { send_device_owned(std::move(mine), words); return receive_values(expect_n); }
+        const uint64_t rid = next_id_++;
+        send_device_owned(std::move(mine), words);
+        return receive_values(expect_n, rid);
+    }
+    // one public Scalar as a batch of one, written by a kernel argument (no host-to-device copy, no synchronisation)
+    ScalarBatch scalar_constant(const Scalar& v) {
+        ScalarBatch b; b.n = 1; b.buf = DeviceBuf(eng_, ARKMPC_KIND_SCALAR, 1);
+        check(ctx(), arkmpc_fill(ctx(), 1, 4, v.l, b.buf.ptr()), "fill");
+        return b;
+    }
+    // exchange of ONE scalar both sides hold on the host (a commitment, a blinder): over the host and device links it travels as the 32
+    // bytes it is; in wire mode as a ScalarBatch frame like everything else
+    Scalar exchange_scalar(const Scalar& mine) {
+        if (link_ == LinkMode::Wire) return exchange_values(scalar_constant(mine)).to_host()[0];
+        uint64_t sid, rid;
+        if (party_ == PARTY0) { sid = next_id_++; rid = next_id_++; } else { rid = next_id_++; sid = next_id_++; }
+        (void)rid;
+        net_->send(NetworkOutbound{sid, {mine}, {}, {}, {}});
+        NetworkOutbound m = net_->receive();
+        if (m.payload.size() != 1) throw std::runtime_error("MpcNetworkError: peer sent " + std::to_string(m.payload.size()) + " scalars where 1 was expected");
+        return m.payload[0];
     }
     // batch_share_plaintext (fabric.rs:602-620): the sender's values become public on both sides
     ScalarBatch batch_share_plaintext(const std::vector<Scalar>& mont, size_t n, PartyId sender) {
@@ -578,10 +619,10 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         net_->send(std::move(m));
     }
     // n = the point count the protocol step requires; a payload of any other size is a network error (never read past)
-    template <class PB> PB receive_points(size_t n) {
+    template <class PB> PB receive_points(size_t n, uint64_t id = kNextId) {
         using Cv = typename PB::Curve;
+        if (id == kNextId) id = next_id_++;
         NetworkOutbound m = net_->receive();
-        const uint64_t id = next_id_++;
         if (link_ == LinkMode::Device) {
             if (!m.dev || m.dev->words() != Cv::PW * n) throw std::runtime_error("MpcNetworkError: unexpected point payload size");
             await_device(m);
@@ -610,9 +651,13 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     }
     template <class PB> PB exchange_points(const PB& mine) {
         if (party_ == PARTY0) { send_points(mine); return receive_points<PB>(mine.n); }
-        PB r = receive_points<PB>(mine.n); send_points(mine); return r;
+        const uint64_t rid = next_id_++;              // as exchange_values: id order of the reference, message out before blocking
+        send_points(mine);
+        return receive_points<PB>(mine.n, rid);
     }
-    void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c);  // fabric.rs:894-915
+    // fabric.rs:894-915.  broadcast_ok: the caller consumes the triples through column views only (the scalar Beaver kernels), so a source
+    // whose batch is n copies of one value may hand out ONE record read with element stride 0 instead of n materialised copies
+    void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c, bool broadcast_ok = false);
     AuthenticatedScalarBatch random_shared_scalars(size_t n);                                    // fabric.rs:917-928
     AuthenticatedScalarBatch random_shared_bits(size_t n);                                       // fabric.rs:961-984
     void random_inverse_pairs(size_t n, AuthenticatedScalarBatch& l, AuthenticatedScalarBatch& r);  // fabric.rs:942-958
@@ -632,6 +677,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     std::unique_ptr<PreprocessingPhase> prep_;
     Scalar mac_key_;
     bool wire_ = false;
+    std::vector<AuthenticatedScalarBatch> const_triple_;     // the constant source's (a, b, c) records, shared by every broadcast triple batch
     int share_layout_ = ARKMPC_LAYOUT_SPLIT;
     LinkMode link_ = LinkMode::Host;
     uint64_t next_id_ = 6;   // N_CONSTANT_RESULTS (fabric.rs:55-70)
@@ -649,9 +695,10 @@ class AuthenticatedScalarBatch {
     static AuthenticatedScalarBatch alloc(const std::shared_ptr<MpcFabric>& f, size_t n) {
         AuthenticatedScalarBatch r; r.n = n; r.fabric = f; r.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR_SHARE, n, f->share_layout()); return r;
     }
+    bool bcast = false;                                  // n logical elements, ONE stored record read with stride 0 (constant preprocessing batches)
     uint64_t* s() const { return buf.ptr(); }            // share of element i at s() + st() * i
     uint64_t* m() const { return buf.mac_ptr(); }        // MAC   of element i at m() + st() * i
-    size_t st() const { return buf.stride(); }
+    size_t st() const { return bcast ? 0 : buf.stride(); }
     bool split() const { return buf.layout() == ARKMPC_LAYOUT_SPLIT; }
     // always arkworks records, whatever the device layout (arkmpc_batch_to_host)
     std::vector<ScalarShare> to_host() const {
@@ -737,11 +784,20 @@ class AuthenticatedScalarBatch {
         auto f = a.fabric;
         if (n == 0) return alloc(f, 0);                                                       // :853-855
         AuthenticatedScalarBatch ta, tb, tc;
-        f->next_triple_batch(n, ta, tb, tc);                                                  // :859
+        f->next_triple_batch(n, ta, tb, tc, true);                                            // :859 (constant sources: one record, stride 0)
         // masked_lhs = a - beaver_a, masked_rhs = b - beaver_b, all_masks = lhs || rhs; open_batch sends `.share()` (:863-868, :141-145)
         ScalarBatch my_de; my_de.n = 2 * n; my_de.buf = DeviceBuf(f->engine(), ARKMPC_KIND_SCALAR, 2 * n);
-        check(f->ctx(), arkmpc_beaver_mask_v(f->ctx(), n, a.s(), a.st(), b.s(), b.st(), ta.s(), ta.st(), tb.s(), tb.st(), my_de.buf.ptr()), "beaver_mask");
-        ScalarBatch peer_de = f->exchange_values(my_de);                                      // the one network round (length-checked: 2n)
+        ScalarBatch peer_de;
+        if (f->link_mode() == MpcFabric::LinkMode::Device) {
+            // device link: K1 writes the payload twice -- one copy stays for this party's K2+K3, the other IS the message (no copy launch
+            // in the round's dependent chain); ids and ordering as exchange_values
+            auto msg = std::make_shared<DeviceBuf>(f->engine(), ARKMPC_KIND_SCALAR, 2 * n);
+            check(f->ctx(), arkmpc_beaver_mask_dup(f->ctx(), n, a.s(), a.st(), b.s(), b.st(), ta.s(), ta.st(), tb.s(), tb.st(), my_de.buf.ptr(), msg->ptr()), "beaver_mask");
+            peer_de = f->exchange_device_owned(std::move(msg), 8 * n, 2 * n);
+        } else {
+            check(f->ctx(), arkmpc_beaver_mask_v(f->ctx(), n, a.s(), a.st(), b.s(), b.st(), ta.s(), ta.st(), tb.s(), tb.st(), my_de.buf.ptr()), "beaver_mask");
+            peer_de = f->exchange_values(my_de);                                              // the one network round (length-checked: 2n)
+        }
         auto r = alloc(f, n);                                                                 // combine (:161-171) + de + d[b] + e[a] + [c] (:871-878)
         check(f->ctx(), arkmpc_beaver_finish_fused_v(f->ctx(), n, (int)f->party_id(), f->mac_key().l, my_de.buf.ptr(), peer_de.buf.ptr(),
                                                      ta.s(), ta.m(), ta.st(), tb.s(), tb.m(), tb.st(), tc.s(), tc.m(), tc.st(), r.s(), r.m(), r.st()), "beaver_finish_fused");
@@ -811,11 +867,11 @@ class AuthenticatedScalarBatch {
         check(c, arkmpc_open_and_mac_check_v(c, n, f->mac_key().l, s(), m(), st(), peer.buf.ptr(), opened.buf.ptr(), chk.buf.ptr()), "open_and_mac_check");   // :161-171 + :299-311
         Scalar my_comm;
         check(c, arkmpc_commit_sha3(c, n, chk.buf.ptr(), blinder.l, my_comm.l), "commit_sha3");  // batch_commit (commitment.rs:63-89)
-        ScalarBatch peer_comm = f->exchange_values(f->allocate_scalars({my_comm}));               // round 2: commitments
+        const Scalar pc = f->exchange_scalar(my_comm);                                            // round 2: commitments
         ScalarBatch peer_chk = f->exchange_values(chk);                                           // round 3: MAC-check shares
-        ScalarBatch peer_blinder = f->exchange_values(f->allocate_scalars({blinder}));            // round 4: blinders
+        const Scalar pb = f->exchange_scalar(blinder);                                            // round 4: blinders
         // batch_verify_mac_check (:201-220): the peer's commitment opens correctly, and my_i + peer_i == 0 for all i
-        Scalar pb = peer_blinder.to_host()[0], pc = peer_comm.to_host()[0], recomputed;
+        Scalar recomputed;
         check(c, arkmpc_commit_sha3(c, n, peer_chk.buf.ptr(), pb.l, recomputed.l), "commit_sha3(verify)");
         int ok_sum = 0;
         check(c, arkmpc_mac_verify(c, n, chk.buf.ptr(), peer_chk.buf.ptr(), &ok_sum), "mac_verify");
@@ -1116,10 +1172,23 @@ inline AuthenticatedScalarBatch MpcFabric::fill_scalar_shares(const ScalarShare&
 }
 inline AuthenticatedScalarBatch MpcFabric::zeros_authenticated(size_t n) { return fill_scalar_shares(ScalarShare{Scalar{{0, 0, 0, 0}}, Scalar{{0, 0, 0, 0}}}, n); }
 inline AuthenticatedScalarBatch MpcFabric::ones_authenticated(size_t n) { return fill_scalar_shares(ScalarShare{eng_->from_u64(party_), mac_key_}, n); }
-inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c) {
+inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c, bool broadcast_ok) {
     ScalarShare ca, cb, cc;
     if (prep_->constant_triplet(ca, cb, cc)) {
         next_id_ += 3 * n;
+        if (broadcast_ok) {                       // `vec![share; n]` (offline_prep.rs:137-158) as one record + stride 0, written once per fabric
+            if (const_triple_.empty() || const_triple_[0].buf.layout() != share_layout_) {
+                const_triple_.clear();
+                const_triple_.push_back(fill_scalar_shares(ca, 1)); const_triple_.push_back(fill_scalar_shares(cb, 1)); const_triple_.push_back(fill_scalar_shares(cc, 1));
+                for (auto& t : const_triple_) t.fabric.reset();           // no cycle fabric -> batch -> fabric
+            }
+            AuthenticatedScalarBatch* out[3] = {&a, &b, &c};
+            for (int k = 0; k < 3; ++k) {
+                AuthenticatedScalarBatch r; r.n = n; r.bcast = true; r.fabric = shared_from_this(); r.buf = const_triple_[k].buf.share();
+                *out[k] = std::move(r);
+            }
+            return;
+        }
         a = fill_scalar_shares(ca, n); b = fill_scalar_shares(cb, n); c = fill_scalar_shares(cc, n);
         return;
     }

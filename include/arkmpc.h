@@ -226,6 +226,12 @@ int arkmpc_beaver_finish_fused_v(arkmpc_ctx* ctx, size_t n, int party_id, const 
 int arkmpc_beaver_mask_to(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share,
                           size_t y_stride, const uint64_t* a_share, size_t a_stride, const uint64_t* b_share, size_t b_stride,
                           uint64_t* out_d, uint64_t* out_e);
+/* K1 writing its payload twice (both 2n Scalars, d then e): out_de stays with the party for its own K2+K3, out_de_msg is the message a
+ * device-resident link hands to the peer (network/mock.rs moves payloads; the sender must not alias a buffer it still reads).  Replaces
+ * K1 + a device-to-device copy: one launch less in every round's dependent chain. */
+int arkmpc_beaver_mask_dup(arkmpc_ctx* ctx, size_t n, const uint64_t* x_share, size_t x_stride, const uint64_t* y_share,
+                           size_t y_stride, const uint64_t* a_share, size_t a_stride, const uint64_t* b_share, size_t b_stride,
+                           uint64_t* out_de, uint64_t* out_de_msg);
 int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t mac_key[4],
                                     const uint64_t* my_d, const uint64_t* my_e, const uint64_t* peer_d, const uint64_t* peer_e,
                                     const uint64_t* a_share, const uint64_t* a_mac, size_t a_stride,
