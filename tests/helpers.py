@@ -136,5 +136,10 @@ class EngineAdapter:
     def scalarshare_mul_point(self, ss, pts): n = len(ss) // 8; o = self._o(n, 24); self.eng(0).scalarshare_mul_point(n, ss, pts, o); return o
     def g1_msm(self, pts, sc): n = len(pts) // 12; o = self._o(1, 12); self.eng(0).g1_msm(n, pts, sc, o); return o
     def g1_msm_authenticated(self, pts, ss): n = len(pts) // 12; o = self._o(1, 24); self.eng(0).g1_msm_authenticated(n, pts, ss, o); return o
+    # Curve25519 (context field = Curve25519 Fr): 16-word extended points
+    def ed_batch_scalar_mul(self, pts, sc): n = len(pts) // 16; o = self._o(n, 16); self.eng(2).ed_scalar_mul(n, pts, sc, o); return o
+    def ed_batch_add(self, a, b): n = len(a) // 16; o = self._o(n, 16); self.eng(2).ed_add(n, a, b, o); return o
+    def ed_batch_neg(self, a): n = len(a) // 16; o = self._o(n, 16); self.eng(2).ed_neg(n, a, o); return o
+    def ed_to_bytes(self, pts): n = len(pts) // 16; o = np.zeros(32 * n, dtype=np.uint8); self.eng(2).ed_to_bytes(n, pts, o); return o
     def g1_from_bytes(self, data):
         n = len(data) // 32; o = self._o(n, 12); ok = np.zeros(n, dtype=np.uint8); self.eng(0).g1_from_bytes(n, data, o, ok); return o, ok
