@@ -568,6 +568,24 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         send_device_owned(std::move(mine), words);
         return receive_values(expect_n, rid);
     }
+    // a payload that is already a host vector (the group fabric gathers its ranges to the host itself): host link semantics in every mode
+    std::vector<Scalar> exchange_host_values(std::vector<Scalar>&& mine) {
+        const size_t expect = mine.size();
+        uint64_t sid, rid;
+        if (party_ == PARTY0) { sid = next_id_++; rid = next_id_++; } else { rid = next_id_++; sid = next_id_++; }
+        (void)rid;
+        net_->send(NetworkOutbound{sid, std::move(mine), {}, {}, {}});
+        NetworkOutbound m = net_->receive();
+        if (m.payload.size() != expect)
+            throw std::runtime_error("MpcNetworkError: peer sent " + std::to_string(m.payload.size()) + " scalars where " + std::to_string(expect) + " were expected");
+        return std::move(m.payload);
+    }
+    // the next n triples as host vectors (PreprocessingPhase::next_triplet_batch, offline_prep.rs:65-81), ids advanced as next_triple_batch
+    void next_triple_host(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) {
+        prep_->next_triplet_batch(n, a, b, c);
+        if (a.size() != n || b.size() != n || c.size() != n) throw std::runtime_error("preprocessing exhausted");
+        next_id_ += 3 * n;
+    }
     // one public Scalar as a batch of one, written by a kernel argument (no host-to-device copy, no synchronisation)
     ScalarBatch scalar_constant(const Scalar& v) {
         ScalarBatch b; b.n = 1; b.buf = DeviceBuf(eng_, ARKMPC_KIND_SCALAR, 1);
@@ -1247,6 +1265,132 @@ inline AuthenticatedScalarBatch MpcFabric::batch_share_scalar(const std::vector<
     AuthenticatedScalarBatch shares = allocate_scalar_shares(mask_shares);
     return AuthenticatedScalarBatch::batch_add_public(shares, masked);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// One party over SEVERAL GPUs: the multi-device group of the C ABI (arkmpc_group_*) under the same fabric.  A party of the reference
+// is one process (fabric.rs:402-466), so this is the shape an 8-GPU deployment has: the fabric (party id, MAC key share, preprocessing,
+// network, result ids) is the one above; batches are range-sharded over the group's members -- member g owns elements
+// [g*n/G, (g+1)*n/G) -- and the scalar hot path (batch_mul, open_authenticated_batch) runs as the group entry points.  Payloads cross
+// the link as host vectors: every member DMAs its range to / from host memory over its own PCIe link (arkmpc_group_gather_d2h /
+// _scatter_h2d), which is where a NIC would pick them up.
+// ---------------------------------------------------------------------------------------------------------------
+class GroupFabric;
+struct GroupOpenResult {            // AuthenticatedScalarOpenResult for a sharded batch: the opened values gathered to the host
+    MpcError err = MpcError::None;
+    std::vector<Scalar> value;
+};
+// a sharded vector: `segs` segments of `ew` words per element on every member (see include/arkmpc.h); freed with the group
+class ShardedBuf {
+  public:
+    ShardedBuf() = default;
+    ShardedBuf(arkmpc_group* g, size_t n, size_t segs, size_t ew) : g_(g), n_(n), segs_(segs), ew_(ew), p_((size_t)arkmpc_group_size(g), nullptr) {
+        if (arkmpc_group_malloc(g, n, segs, ew, p_.data()) != ARKMPC_OK) throw std::runtime_error(std::string("arkmpc_group_malloc: ") + arkmpc_group_last_error(g));
+    }
+    ~ShardedBuf() { if (g_) arkmpc_group_free(g_, p_.data()); }
+    ShardedBuf(ShardedBuf&& o) noexcept { *this = std::move(o); }
+    ShardedBuf& operator=(ShardedBuf&& o) noexcept {
+        if (this != &o) { if (g_) arkmpc_group_free(g_, p_.data()); g_ = o.g_; n_ = o.n_; segs_ = o.segs_; ew_ = o.ew_; p_ = std::move(o.p_); o.g_ = nullptr; }
+        return *this;
+    }
+    ShardedBuf(const ShardedBuf&) = delete;
+    uint64_t* const* ptrs() const { return p_.data(); }
+    const uint64_t* const* cptrs() const { return const_cast<const uint64_t* const*>(p_.data()); }
+    size_t n() const { return n_; }
+
+  private:
+    arkmpc_group* g_ = nullptr;
+    size_t n_ = 0, segs_ = 0, ew_ = 0;
+    std::vector<uint64_t*> p_;
+};
+struct ShardedShares {              // Vec<AuthenticatedScalarResult<C>> range-sharded over the group, in the fabric's share layout
+    size_t n = 0;
+    ShardedBuf buf;
+    std::shared_ptr<GroupFabric> fabric;
+};
+class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
+  public:
+    GroupFabric(std::shared_ptr<MpcFabric> fabric, const std::vector<int>& device_ids) : f_(std::move(fabric)) {
+        if (arkmpc_group_create(f_->engine()->field_id(), (int)device_ids.size(), device_ids.data(), &g_) != ARKMPC_OK)
+            throw std::runtime_error("arkmpc_group_create failed: the engine needs GPUs, there is no CPU fallback");
+    }
+    ~GroupFabric() { if (g_) arkmpc_group_destroy(g_); }
+    GroupFabric(const GroupFabric&) = delete;
+    arkmpc_group* group() const { return g_; }
+    int layout() const { return f_->share_layout(); }
+    std::shared_ptr<MpcFabric> fabric() const { return f_; }
+    void gcheck(int rc, const char* what) const { if (rc != ARKMPC_OK) throw std::runtime_error(std::string(what) + ": " + arkmpc_group_last_error(g_)); }
+    ShardedShares alloc(size_t n) {
+        ShardedShares r; r.n = n; r.fabric = shared_from_this();
+        r.buf = layout() == ARKMPC_LAYOUT_SPLIT ? ShardedBuf(g_, n, 2, 4) : ShardedBuf(g_, n, 1, 8);
+        return r;
+    }
+    ShardedShares shares_from_host(const std::vector<ScalarShare>& v) {
+        ShardedShares r = alloc(v.size());
+        gcheck(arkmpc_group_shares_from_host(g_, layout(), v.size(), v.empty() ? nullptr : &v[0].share.l[0], r.buf.ptrs()), "group_shares_from_host");
+        return r;
+    }
+    std::vector<ScalarShare> to_host(const ShardedShares& a) {
+        std::vector<ScalarShare> v(a.n);
+        gcheck(arkmpc_group_shares_to_host(g_, layout(), a.n, a.buf.cptrs(), a.n ? &v[0].share.l[0] : nullptr), "group_shares_to_host");
+        return v;
+    }
+    // the d||e / share-value / MAC-check exchanges: range DMAs to the host, the message, range DMAs back (ids as MpcFabric::exchange_values)
+    ShardedBuf exchange(const ShardedBuf& mine, size_t n, size_t segs) {
+        std::vector<Scalar> pay(n * segs);
+        gcheck(arkmpc_group_gather_d2h(g_, n, segs, 4, mine.cptrs(), n ? &pay[0].l[0] : nullptr), "group_gather_d2h");
+        std::vector<Scalar> peer = f_->exchange_host_values(std::move(pay));
+        ShardedBuf r(g_, n, segs, 4);
+        gcheck(arkmpc_group_scatter_h2d(g_, n, segs, 4, n ? &peer[0].l[0] : nullptr, r.ptrs()), "group_scatter_h2d");
+        return r;
+    }
+    // Beaver multiplication over the group (authenticated_scalar.rs:848-879)
+    ShardedShares batch_mul(const ShardedShares& a, const ShardedShares& b) {
+        if (a.n != b.n) throw std::invalid_argument("Cannot operate on batches of different sizes");
+        const size_t n = a.n;
+        if (n == 0) return alloc(0);
+        std::vector<ScalarShare> ha, hb, hc;
+        f_->next_triple_host(n, ha, hb, hc);
+        ShardedShares ta = shares_from_host(ha), tb = shares_from_host(hb), tc = shares_from_host(hc);
+        ShardedBuf my_de(g_, n, 2, 4);
+        gcheck(arkmpc_group_beaver_mask(g_, layout(), n, a.buf.cptrs(), b.buf.cptrs(), ta.buf.cptrs(), tb.buf.cptrs(), my_de.ptrs()), "group_beaver_mask");
+        ShardedBuf peer_de = exchange(my_de, n, 2);
+        ShardedShares r = alloc(n);
+        gcheck(arkmpc_group_beaver_finish_fused(g_, layout(), n, (int)f_->party_id(), f_->mac_key().l, my_de.cptrs(), peer_de.cptrs(), ta.buf.cptrs(),
+                                                tb.buf.cptrs(), tc.buf.cptrs(), r.buf.ptrs()), "group_beaver_finish_fused");
+        return r;                                             // the temporaries' frees are stream-ordered per member (arkmpc_free): no synchronisation
+    }
+    // open_authenticated_batch over the group (:278-354): opening, MAC-check shares, commit, three exchanges, verification
+    GroupOpenResult open_authenticated_batch(const ShardedShares& x, const Scalar& blinder) {
+        GroupOpenResult res;
+        const size_t n = x.n;
+        if (n == 0) return res;
+        ShardedBuf mine(g_, n, 1, 4);
+        gcheck(arkmpc_group_share_extract(g_, layout(), n, x.buf.cptrs(), mine.ptrs()), "group_share_extract");
+        ShardedBuf peer = exchange(mine, n, 1);                                                    // round 1
+        ShardedBuf opened(g_, n, 1, 4), chk(g_, n, 1, 4);
+        gcheck(arkmpc_group_open_and_mac_check(g_, layout(), n, f_->mac_key().l, x.buf.cptrs(), peer.cptrs(), opened.ptrs(), chk.ptrs()), "group_open_and_mac_check");
+        Scalar my_comm, recomputed;
+        gcheck(arkmpc_group_commit_sha3(g_, n, chk.cptrs(), blinder.l, my_comm.l), "group_commit_sha3");
+        const Scalar pc = f_->exchange_scalar(my_comm);                                            // round 2
+        ShardedBuf peer_chk = exchange(chk, n, 1);                                                 // round 3
+        const Scalar pb = f_->exchange_scalar(blinder);                                            // round 4
+        gcheck(arkmpc_group_commit_sha3(g_, n, peer_chk.cptrs(), pb.l, recomputed.l), "group_commit_sha3(verify)");
+        int ok = 0;
+        gcheck(arkmpc_group_mac_verify(g_, n, chk.cptrs(), peer_chk.cptrs(), &ok), "group_mac_verify");
+        res.err = (ok == 1 && std::memcmp(recomputed.l, pc.l, 32) == 0) ? MpcError::None : MpcError::AuthenticationError;
+        res.value.resize(n);
+        gcheck(arkmpc_group_gather_d2h(g_, n, 1, 4, opened.cptrs(), &res.value[0].l[0]), "group_gather_d2h");
+        return res;
+    }
+    // input sharing (fabric.rs:578-600) on the single-device fabric, then sharded: the sharing step is one round and tiny next to the gates
+    ShardedShares batch_share_scalar(const std::vector<Scalar>& vals_mont, size_t n, PartyId sender) {
+        return shares_from_host(f_->batch_share_scalar(vals_mont, n, sender).to_host());
+    }
+
+  private:
+    std::shared_ptr<MpcFabric> f_;
+    arkmpc_group* g_ = nullptr;
+};
 
 // gadgets.rs:105-148 prefix_product: blind in a telescoping manner with inverse pairs, open, scan in public, unblind
 inline AuthenticatedScalarBatch prefix_product(const AuthenticatedScalarBatch& values, const Scalar& blinder, MpcError* err = nullptr) {

@@ -170,6 +170,27 @@ int main(int argc, char** argv) {
                 ScalarBatch PT = scalar_batch_addsub(fabric->engine(), scalar_batch_addsub(fabric->engine(), Pn, Tn, false), pb, true);       // P + T - b_i
                 auto r1 = AuthenticatedScalarBatch::batch_add(AuthenticatedScalarBatch::batch_add(q, S), AuthenticatedScalarBatch::batch_add(z, one));
                 res = AuthenticatedScalarBatch::batch_sub(AuthenticatedScalarBatch::batch_add_public(r1, PT), AuthenticatedScalarBatch::pow(a, 1));
+            } else if (scenario == "group_mul") {
+                // one party over several GPUs: the same circuit as "batch_mul" + the authenticated opening, range-sharded over the members of
+                // an arkmpc_group (ARKMPC_GROUP_DEVICES = comma-separated device ids, repeats allowed; default 0,0,0)
+                std::vector<int> devs;
+                const char* gd = std::getenv("ARKMPC_GROUP_DEVICES");
+                for (std::string t = gd ? gd : "0,0,0"; !t.empty();) { const size_t c = t.find(','); devs.push_back(std::atoi(t.substr(0, c).c_str())); t = c == std::string::npos ? "" : t.substr(c + 1); }
+                auto gf = std::make_shared<GroupFabric>(fabric, devs);
+                auto a = gf->batch_share_scalar(a_m, n, PARTY0);
+                auto b = gf->batch_share_scalar(b_m, n, PARTY1);
+                auto prod = gf->batch_mul(a, b);
+                auto sq = gf->batch_mul(prod, prod);                                   // a second, dependent gate on sharded operands
+                if (fabric->party_id() == PARTY0 && n && (bad_mac || bad_share)) {
+                    std::vector<ScalarShare> h = gf->to_host(sq);
+                    (bad_mac ? h[n - 1].mac : h[n - 1].share) = eng.from_u64(42);       // the LAST element: the last member's range
+                    sq = gf->shares_from_host(h);
+                }
+                GroupOpenResult o = gf->open_authenticated_batch(sq, blinder);
+                PartyOut out;
+                out.err = (o.err == MpcError::None) ? 0 : 2;
+                if (n) out.opened = eng.to_canonical(o.value);
+                return out;
             } else if (scenario == "short_peer") {
                 // a peer that sends one element fewer than the protocol step requires: must surface as a network error on the
                 // honest side before any kernel reads the short buffer (never an out-of-bounds read)

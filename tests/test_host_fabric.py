@@ -110,6 +110,27 @@ def test_api_tail_pow_sum_constants(tmp_path, fid, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices,n", [("0,0,0", 1000), ("0,0,0,0,0,0,0,0", 5), ("0", 257)])
+def test_group_fabric_one_party_over_several_gpus(tmp_path, devices, n):
+    """host/fabric.hpp GroupFabric: each party drives an arkmpc_group (members sharing GPU 0 here); two dependent Beaver gates and the
+    authenticated opening on range-sharded batches give (x*y)^2 on both sides, and a corrupted LAST share / MAC (the last member's range)
+    is an AuthenticationError on both."""
+    fid = 0
+    p = pyref.P[fid]
+    a, b = mixed_values(fid, n, 51), rand_values(fid, n, 52)
+    os.environ["ARKMPC_GROUP_DEVICES"] = devices
+    try:
+        res = run(tmp_path, "group_mul", fid, a, b)
+        want = [pow(x * y, 2, p) for x, y in zip(a, b)]
+        assert res[0] == (0, want) and res[1] == (0, want)
+        for flag in ("--bad-mac", "--bad-share"):
+            res = run(tmp_path, "group_mul", fid, a, b, flag)
+            assert res[0][0] == 2 and res[1][0] == 2
+    finally:
+        os.environ.pop("ARKMPC_GROUP_DEVICES", None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flag", ["--bad-mac", "--bad-share"])
 def test_open_authenticated_detects_corruption(tmp_path, flag):
     """integration/src/authenticated_scalar.rs:49-75: a modified MAC or share must surface as AuthenticationError on
