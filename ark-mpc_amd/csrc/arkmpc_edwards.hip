@@ -661,7 +661,16 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_mac_check_kp(size_t n, const u64*
     if (guard__.rc) return guard__.rc;                                                          \
     if ((ctx)->field_id != ARKMPC_CURVE25519_FR) { ark_set_err((ctx), "Curve25519 point ops need a CURVE25519_FR context"); return ARKMPC_ERR_UNSUPPORTED; }
 
+#include "arkmpc_ed_msm.inc"
+
 extern "C" {
+
+int arkmpc_ed_msm(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out_point) {
+    return ed_msm_impl(ctx, n, points, scalars, 4, 1, out_point);
+}
+int arkmpc_ed_msm_authenticated(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalar_shares, uint64_t* out_share) {
+    return ed_msm_impl(ctx, n, points, scalar_shares, 8, 2, out_share);
+}
 
 static int ed_addsub(arkmpc_ctx* ctx, bool sub, size_t m, const uint64_t* a, const uint64_t* b, uint64_t* out) {
     ENTER_ED(ctx);

@@ -312,6 +312,8 @@ class Engine:
     def ed_mac_check_shares(self, n, key, opened, shares, out): self.call("ed_mac_check_shares", ("size", n), ("key", key), opened, shares, out)
     def ed_mac_verify(self, n, mine, peer, out_ok): self.call("ed_mac_verify", ("size", n), mine, peer, out_ok)
     def commit_ed_points_sha3(self, n, pts, blinders, out): self.call("commit_ed_points_sha3", ("size", n), pts, blinders, out)
+    def ed_msm(self, n, pts, scalars, out): self.call("ed_msm", ("size", n), pts, scalars, out)
+    def ed_msm_authenticated(self, n, pts, scalar_shares, out): self.call("ed_msm_authenticated", ("size", n), pts, scalar_shares, out)
     def ed_sum(self, n, pts, out): self.call("ed_sum", ("size", n), pts, out)
     def edshare_sum(self, n, shares, out): self.call("edshare_sum", ("size", n), shares, out)
 

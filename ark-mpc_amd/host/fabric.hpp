@@ -400,23 +400,9 @@ struct Curve25519 {                   // ark_curve25519::EdwardsProjective (READ
     static int share_sum(arkmpc_ctx* c, size_t n, const uint64_t* a, uint64_t* o) { return arkmpc_edshare_sum(c, n, a, o); }
     static int beaver_finish(arkmpc_ctx* c, size_t n, int party, const uint64_t* k, const uint64_t* d, const uint64_t* eG, const uint64_t* ta, const uint64_t* tb,
                              const uint64_t* tc, uint64_t* o) { return arkmpc_edpoint_beaver_finish(c, n, party, k, d, eG, ta, tb, tc, o); }
-    // no bucket-method MSM on this curve: CurvePoint::msm as n scalar-muls + one sum (the definition, curve.rs:549-560)
-    static int msm(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) {
-        void* t = nullptr;
-        int rc = arkmpc_malloc(c, (n ? n : 1) * PW * 8, &t);
-        if (!rc && n) rc = arkmpc_ed_scalar_mul(c, n, p, s, (uint64_t*)t);
-        if (!rc) rc = arkmpc_ed_sum(c, n, (const uint64_t*)t, o);
-        if (t) arkmpc_free(c, t);
-        return rc;
-    }
-    static int msm_authenticated(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* ss, uint64_t* o) {
-        void* t = nullptr;
-        int rc = arkmpc_malloc(c, (n ? n : 1) * 2 * PW * 8, &t);
-        if (!rc && n) rc = arkmpc_scalarshare_mul_ed_point(c, n, ss, p, (uint64_t*)t);
-        if (!rc) rc = arkmpc_edshare_sum(c, n, (const uint64_t*)t, o);
-        if (t) arkmpc_free(c, t);
-        return rc;
-    }
+    // CurvePoint::msm / msm_authenticated (curve.rs:549-560, :618-642): the bucket method on the complete Edwards addition
+    static int msm(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* s, uint64_t* o) { return arkmpc_ed_msm(c, n, p, s, o); }
+    static int msm_authenticated(arkmpc_ctx* c, size_t n, const uint64_t* p, const uint64_t* ss, uint64_t* o) { return arkmpc_ed_msm_authenticated(c, n, p, ss, o); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------

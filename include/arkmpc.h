@@ -374,6 +374,11 @@ int arkmpc_ed_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key
 int arkmpc_ed_mac_verify(arkmpc_ctx* ctx, size_t n, const uint64_t* mine, const uint64_t* peer, uint8_t* out_ok);
 int arkmpc_commit_ed_points_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* blinders,
                                  uint64_t* out_commitments);
+/* CurvePoint::msm / msm_authenticated on Curve25519 (curve.rs:549-560, :618-642 -- generic over C): the bucket method on the complete
+ * twisted-Edwards addition (no exceptional lanes, no affine conversion pass); semantics of arkmpc_g1_msm / arkmpc_g1_msm_authenticated
+ * on 16-word points, out = ONE point / ONE PointShare (32 x u64); n = 0 gives the identity */
+int arkmpc_ed_msm(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out_point);
+int arkmpc_ed_msm_authenticated(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalar_shares, uint64_t* out_share);
 int arkmpc_ed_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* points, uint64_t* out_point);
 int arkmpc_edshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share);
 

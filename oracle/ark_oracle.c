@@ -859,6 +859,17 @@ void ora_ed_sum(size_t n, const u64* pts, size_t stride, u64 out[16]) {
     for (size_t i = 0; i < n; ++i) { u64 t[16]; ora_ed_add(acc, pts + stride * i, t); memcpy(acc, t, 128); }
     memcpy(out, acc, 128);
 }
+/* CurvePoint::msm on Curve25519 (curve.rs:549-560, generic over C): the definition, sum_i s_i * P_i */
+void ora_ed_msm(size_t n, const u64* pts, const u64* scalars, size_t scalar_stride, u64 out[16]) {
+    u64 acc[16], t[16], u[16]; ora_ed_identity(acc);
+    for (size_t i = 0; i < n; ++i) { ora_ed_scalar_mul(pts + 16 * i, scalars + scalar_stride * i, t); ora_ed_add(acc, t, u); memcpy(acc, u, 128); }
+    memcpy(out, acc, 128);
+}
+/* CurvePointResult::msm_authenticated (curve.rs:618-642): PointShare(msm(shares, points), msm(macs, points)) */
+void ora_ed_msm_authenticated(size_t n, const u64* pts, const u64* scalar_shares, u64 out[32]) {
+    ora_ed_msm(n, pts, scalar_shares, 8, out);
+    ora_ed_msm(n, pts, scalar_shares + 4, 8, out + 16);
+}
 /* authenticated_curve.rs:127-131: my + peer == identity; returns 1 when it is.  Compared on affine coordinates (0, 1). */
 int ora_ed_is_identity_sum(const u64 a[16], const u64 b[16]) {
     u64 s[16], xy[8], one[4];

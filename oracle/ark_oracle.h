@@ -166,6 +166,8 @@ void ora_pointshare_batch_sub_public(size_t n, int party_id, const u64 mac_key[4
 void ora_point_mac_check_shares(size_t n, const u64 mac_key[4], const u64* opened, const u64* shares, u64* out);
 void ora_ed_mac_check_shares(size_t n, const u64 mac_key[4], const u64* opened, const u64* shares, u64* out);
 void ora_ed_sum(size_t n, const u64* pts, size_t stride_u64, u64 out[16]);
+void ora_ed_msm(size_t n, const u64* pts, const u64* scalars, size_t scalar_stride_u64, u64 out[16]);   /* curve.rs:549-560 on Curve25519 */
+void ora_ed_msm_authenticated(size_t n, const u64* pts, const u64* scalar_shares, u64 out[32]);         /* curve.rs:618-642 */
 int ora_ed_is_identity_sum(const u64 a[16], const u64 b[16]);
 
 /* ---- range-parallel forms (same per-element functions, static range split over pthreads; full-size parity tests) ---- */

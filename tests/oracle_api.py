@@ -227,6 +227,10 @@ class Oracle:
     def ed_sum(self, pts, stride=16, off=0):
         n = len(pts) // stride; out = np.zeros(16, dtype=np.uint64)
         self.lib.ora_ed_sum(ctypes.c_size_t(n), ctypes.c_void_p(pts.ctypes.data + 8 * off), ctypes.c_size_t(stride), self._p(out)); return out
+    def ed_msm(self, pts, scalars, stride=4):
+        n = len(pts) // 16; out = np.zeros(16, dtype=np.uint64); self._call("ora_ed_msm", n, pts, scalars, stride, out); return out
+    def ed_msm_authenticated(self, pts, scalar_shares):
+        n = len(pts) // 16; out = np.zeros(32, dtype=np.uint64); self._call("ora_ed_msm_authenticated", n, pts, scalar_shares, out); return out
     def ed_is_identity_sum(self, a, b):
         self.lib.ora_ed_is_identity_sum.restype = ctypes.c_int
         return bool(self.lib.ora_ed_is_identity_sum(self._p(np.ascontiguousarray(a)), self._p(np.ascontiguousarray(b))))

@@ -267,3 +267,74 @@ def test_edpoint_beaver_finish_equals_the_references_four_terms(eng, oracle, par
     out = np.zeros(32 * n, dtype=np.uint64)
     eng.point_beaver_finish(n, party, key, d, eG, ta, tb, tc, out, ed=True)
     assert aff_equal(eng, oracle, out, want)
+
+
+# ---- variable-base MSM on Curve25519 (arkmpc_ed_msm / arkmpc_ed_msm_authenticated): CurvePoint::msm is generic over C (curve.rs:549-560)
+def _ed_msm(eng, P, S):
+    n = len(P) // 16
+    out = np.zeros(16, dtype=np.uint64)
+    eng.ed_msm(n, P if n else np.zeros(16, dtype=np.uint64), S if n else np.zeros(4, dtype=np.uint64), out)
+    return out
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 33, 200])
+def test_ed_msm_small_vs_oracle(eng, oracle, n):
+    """the bucket method vs the definition (sum of scalar multiples), edge scalars 0, 1, l - 1 and the identity among the bases"""
+    pts, P = rand_points(max(n, 1), 1900 + n)
+    P = np.ascontiguousarray(P[:16 * n])
+    ks = ([0, 1, pyref.EL - 1, 2, (1 << 252)] + rand_values(2, max(n, 5), 1901 + n))[:n]
+    S = mont_array(2, ks)
+    want = oracle.ed_msm(P, S) if n else np.array(pyref.ed_extended_mont((0, 1)), dtype=np.uint64)
+    assert aff_equal(eng, oracle, _ed_msm(eng, P, S), want)
+
+
+def test_ed_msm_repeated_and_cancelling_members(eng, oracle):
+    """a base repeated with equal scalars (doubling inside a bucket), a base and its negative (cancellation inside a bucket), another
+    representative of the same point: the addition law is complete, so these are ordinary lanes -- no flags, no fallback"""
+    n = 16
+    pts, P = rand_points(n, 1950)
+    ks = rand_values(2, n, 1951)
+    P[16 * 3:16 * 4] = P[16 * 2:16 * 3]; ks[3] = ks[2]
+    P[16 * 5:16 * 6] = oracle.ed_batch_neg(P[16 * 4:16 * 5].copy()); ks[5] = ks[4]
+    P[16 * 7:16 * 8] = ext([pts[6]], [12345]); ks[7] = ks[6]
+    ks[8] = 0
+    S = mont_array(2, ks)
+    assert aff_equal(eng, oracle, _ed_msm(eng, P, S), oracle.ed_msm(P, S))
+    Q = np.concatenate([P[:32], oracle.ed_batch_neg(P[:32].copy())])               # everything cancels
+    S2 = mont_array(2, ks[:2] + ks[:2])
+    assert aff_equal(eng, oracle, _ed_msm(eng, Q, S2), np.array(pyref.ed_extended_mont((0, 1)), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("n", [1000, 70000])
+def test_ed_msm_closed_form_and_authenticated(eng, oracle, n):
+    """size-independent check: bases k_i * B => msm = (sum s_i k_i mod l) * B, evaluated in Python integers (RFC 8032 base point);
+    the authenticated form gives that per column (share column, MAC column)"""
+    l = pyref.EL
+    ks, s0, s1 = rand_values(2, n, 2001), rand_values(2, n, 2002), rand_values(2, n, 2003)
+    ks[0], s0[0], s1[1] = 0, 5, 0                                                   # an identity base, a zero scalar
+    P = np.zeros(16 * n, dtype=np.uint64)
+    eng.ed_generator_mul(n, mont_array(2, ks), P)
+    want0 = pyref.ed_mul(pyref.ED_B, sum(a * b for a, b in zip(ks, s0)) % l)
+    want1 = pyref.ed_mul(pyref.ED_B, sum(a * b for a, b in zip(ks, s1)) % l)
+    got = _ed_msm(eng, P, mont_array(2, s0))
+    xy = np.zeros(8, dtype=np.uint64); eng.ed_to_affine(1, got, xy)
+    assert [pyref.from_mont(4, v) for v in limbs_to_ints(xy)] == list(want0)
+    ss = np.ascontiguousarray(np.concatenate([mont_array(2, s0).reshape(-1, 4), mont_array(2, s1).reshape(-1, 4)], axis=1).reshape(-1))
+    out = np.zeros(32, dtype=np.uint64)
+    eng.ed_msm_authenticated(n, P, ss, out)
+    xy2 = np.zeros(16, dtype=np.uint64); eng.ed_to_affine(2, out, xy2)
+    assert [pyref.from_mont(4, v) for v in limbs_to_ints(xy2)] == list(want0) + list(want1)
+
+
+def test_ed_msm_skewed_scalars(eng, oracle):
+    """all scalars equal / 0-1 scalars: one bucket per window holds every point (long runs cut into tasks and re-joined by the tree)"""
+    n = 5000
+    l = pyref.EL
+    ks = rand_values(2, n, 2101)
+    P = np.zeros(16 * n, dtype=np.uint64)
+    eng.ed_generator_mul(n, mont_array(2, ks), P)
+    for sc in ([7] * n, [i & 1 for i in range(n)], [l - 1] * n):
+        want = pyref.ed_mul(pyref.ED_B, sum(a * b for a, b in zip(ks, sc)) % l)
+        got = _ed_msm(eng, P, mont_array(2, sc))
+        xy = np.zeros(8, dtype=np.uint64); eng.ed_to_affine(1, got, xy)
+        assert [pyref.from_mont(4, v) for v in limbs_to_ints(xy)] == list(want)
