@@ -339,6 +339,32 @@ __global__ void __launch_bounds__(TPB) k_beaver_finish_asm_aos(u32 n, u32 mask, 
     }
 }
 
+// Split-column K2+K3 with the result staged through LDS: the hand-scheduled body leaves each thread's share and MAC in two 8 KiB LDS
+// columns and the workgroup writes them out lane-contiguously -- every non-temporal store instruction covers whole lines.  (The body's own
+// stores are 16 bytes per lane, 32 bytes apart; as non-temporal stores they reach HBM as partial lines: +10 % write traffic measured.)
+template <int F>
+__global__ void __launch_bounds__(TPB) k_beaver_finish_asm_so(u32 n, u32 mask, Fe key, const u64* my_d, const u64* my_e, const u64* peer_d,
+                                                              const u64* peer_e, const u64* a_s, const u64* a_m, const u64* b_s, const u64* b_m,
+                                                              const u64* c_s, const u64* c_m, u64* out_s, u64* out_m) {
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    __shared__ v4u lds[2 * TPB * 2];                         // 16 KiB: 256 shares (32 B each), then 256 MACs
+    const u32 first = blockIdx.x * TPB, i = first + threadIdx.x;
+    const u32 cnt = (n - first < TPB) ? n - first : TPB;
+    const u32 lds_base = (u32)(size_t)(__attribute__((address_space(3))) char*)lds;
+    if (i < n) beaver_finish_asm_so<F>(i * 32u, i * 32u, lds_base + threadIdx.x * 32u, my_d, my_e, peer_d, peer_e, a_s, a_m, b_s, b_m, c_s, c_m, key, mask);
+    __syncthreads();
+    v4u* os = reinterpret_cast<v4u*>(out_s) + 2 * (size_t)first;
+    v4u* om = reinterpret_cast<v4u*>(out_m) + 2 * (size_t)first;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 idx = threadIdx.x + k * TPB;
+        if (idx < 2 * cnt) {
+            __builtin_nontemporal_store(lds[idx], os + idx);
+            __builtin_nontemporal_store(lds[2 * TPB + idx], om + idx);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // batch open + MAC check (authenticated_scalar.rs:278-354)
 // ---------------------------------------------------------------------------------------------
@@ -463,8 +489,11 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                 const size_t cnt = (n - lo < CH) ? (n - lo) : CH;
                 const size_t cs = (size_t)a_s.stride * lo, os = (size_t)o_s.stride * lo;
                 // split-column layout (stride 4): once-streamed data carries non-temporal hints; AoS: none (halves share lines)
-                // ARKMPC_K3_NT: 0 = no hints, 1 = hints on once-streamed loads AND on the result stores, 2 (default) = on the loads only
-                static const int k3_nt = getenv("ARKMPC_K3_NT") ? atoi(getenv("ARKMPC_K3_NT")) : 2;     // A/B switch for the cache-policy measurement
+                // ARKMPC_K3_NT (A/B switch, split columns; measured at 2^20 gates, tools/ab_k3_nt.sh): 3 (default) = non-temporal hints on the
+                // once-streamed loads, result staged through LDS and written with whole-line non-temporal stores: 58.4 us; 1 = the same hints with the
+                // body's own 16-byte stores: 61.1 us (partial-line write amplification); 2 = hints on the loads only: 66 us (plain stores keep the
+                // results in the cache K3's re-reads want); 0 = no hints: 74 us
+                static const int k3_nt = getenv("ARKMPC_K3_NT") ? atoi(getenv("ARKMPC_K3_NT")) : 3;
                 static const bool aos_lds = !(getenv("ARKMPC_K3_AOS_LDS") && getenv("ARKMPC_K3_AOS_LDS")[0] == '0');
                 const bool aos_records = a_s.stride == 8 && o_s.stride == 8 && a_m.p == a_s.p + 4 && b_m.p == b_s.p + 4 && c_m.p == c_s.p + 4 &&
                                          o_m.p == o_s.p + 4;
@@ -478,7 +507,10 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
     launch_k(ctx, k_beaver_finish_asm<F, NT>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo,   \
              peer_e + 4 * lo, a_s.p + cs, a_m.p + cs, b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os, a_s.stride * 8u,          \
              o_s.stride * 8u)
-                if (nt == 1) ARK_K3_LAUNCH(1);
+                if (nt == 3)            // result staged through LDS, whole-line stores (split columns only)
+                    launch_k(ctx, k_beaver_finish_asm_so<F>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo,
+                             peer_e + 4 * lo, a_s.p + cs, a_m.p + cs, b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os);
+                else if (nt == 1) ARK_K3_LAUNCH(1);
                 else if (nt == 2) ARK_K3_LAUNCH(2);
                 else ARK_K3_LAUNCH(0);
 #undef ARK_K3_LAUNCH

@@ -118,6 +118,11 @@ NT_BASES = set()
 # loads -- every 64-byte line consumed by ONE instruction, which is what makes the hint usable for AoS data -- and the body
 # reads its own record from there; the result record goes back through the a-region.  Record layout: share at +0, MAC at +32.
 LDS_MODE = False
+# split-layout variant with the RESULT staged through LDS (global loads as usual): a thread leaves its share at lds_off and its MAC at
+# lds_off + 8192 (lds_off = 32 * thread), and the workgroup streams both 8 KiB columns out with lane-contiguous non-temporal stores --
+# whole lines per instruction.  Non-temporal 16-byte stores 32 B apart (what the body issues otherwise) leave the L2 as partial lines:
+# +10 % write traffic on K3, +23..34 % on pure store kernels (probes/write_calib.hip).
+LDS_OUT_MODE = False
 LDS_STREAM = {"a": 0, "b": 16384, "c": 32768, "out": 0}
 def lds_offset(base, half):
     stream, part = base.split("_")
@@ -131,6 +136,9 @@ def i_load(regs, off, base, half):
     return Ins("global_load_dwordx4 %s, %%[%s], %%[%s]%s%s" % (quad(regs), off, base, " offset:16" if half else "", " nt" if base in NT_BASES else ""), "load", (regs, base, half),
                rd=["MEMORDER"], wr=list(regs) + ["MEMORDER"])
 def i_store(regs, off, base, half):
+    if LDS_OUT_MODE:
+        return Ins("ds_write_b128 %%[lds_off], %s offset:%d" % (quad(regs), (8192 if base.endswith("_m") else 0) + 16 * half), "store", (regs, base, half),
+                   rd=list(regs) + ["MEMORDER"], wr=["MEMORDER"])
     if LDS_MODE:
         return Ins("ds_write_b128 %%[lds_off], %s offset:%d" % (quad(regs), lds_offset(base, half)), "store", (regs, base, half),
                    rd=list(regs) + ["MEMORDER"], wr=["MEMORDER"])
@@ -377,17 +385,19 @@ class Emu:
 # ------------------------------------------------------------------------------------------------
 # K2+K3 body
 # ------------------------------------------------------------------------------------------------
-def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False, lds=False):
-    global NT_BASES, LDS_MODE
+def build_beaver_finish(p, first_vgpr=8, key_names=None, sched=True, nt=False, lds=False, ldsout=False):
+    global NT_BASES, LDS_MODE, LDS_OUT_MODE
     NT_BASES = (NT_SPLIT - {"out_s", "out_m"} if nt == 2 else NT_SPLIT) if nt else NT_AOS     # nt = 2: hints on the loads only
     LDS_MODE = lds
+    LDS_OUT_MODE = ldsout
     try:
-        return _build_beaver_finish(p, first_vgpr, key_names, sched, lds)
+        return _build_beaver_finish(p, first_vgpr, key_names, sched, lds, ldsout)
     finally:
         LDS_MODE = False
+        LDS_OUT_MODE = False
 
 
-def _build_beaver_finish(p, first_vgpr, key_names, sched, lds):
+def _build_beaver_finish(p, first_vgpr, key_names, sched, lds, ldsout=False):
     """Emit the fused combine + finish body for modulus p.  Returns (Emitter, regmap)."""
     key = key_names or ["%[k" + str(i) + "]" for i in range(8)]
     rg = Regs(first_vgpr)
@@ -461,7 +471,7 @@ def _build_beaver_finish(p, first_vgpr, key_names, sched, lds):
         for h in (0, 1):
             seg.append(i_store(regs[4 * h:4 * h + 4], "off_out", nm, h))
     run(seg)
-    if lds:
+    if lds or ldsout:
         E.emit(i_wait_lds(0))                                         # the caller's barrier must see the result record in LDS
     regmap = dict(P=P, dm=dm, dp=dp, em=em, ep=ep, bs=bs, as_=as_, bm=bm, am=am, rs=rs, rm=rm, first=first_vgpr, nv=nv)
     return E, regmap
@@ -618,6 +628,26 @@ def emit_header(path):
             out.append("          " + ", ".join('[k%d] "s"(key.v[%d])' % (i, i) for i in range(8)))
             out.append("        : " + ", ".join(clob) + ");")
             out.append("}")
+    # split layout, result staged through LDS (whole-line stores by the workgroup)
+    for fid, (name, p) in enumerate(FIELDS):
+        if name in COORD_ONLY:
+            continue
+        E, mp = build_beaver_finish(p, nt=1, ldsout=True)
+        nvalu = sum(1 for i in E.order if i.op in ("mov", "mad", "mul_lo", "addco", "addc", "subco", "subb", "cnd", "and"))
+        clob = ['"memory"', '"vcc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mp["first"], mp["nv"])]
+        out.append("// %s (split layout, result left in LDS: share at lds_off, MAC at lds_off + 8192): %d VALU, %d H1 wait states" % (name, nvalu, E.nops))
+        out.append("template <> __device__ __forceinline__ void beaver_finish_asm_so<%d>(u32 off_de, u32 off_col, u32 lds_off, const u64* my_d, const u64* my_e," % fid)
+        out.append("        const u64* peer_d, const u64* peer_e, const u64* a_s, const u64* a_m, const u64* b_s, const u64* b_m, const u64* c_s, const u64* c_m,")
+        out.append("        const Fe& key, u32 mask) {")
+        out.append("    asm volatile(")
+        out.append(c_string(E.lines))
+        out.append("        :")
+        out.append('        : [off_de] "v"(off_de), [off_col] "v"(off_col), [lds_off] "v"(lds_off), [my_d] "s"(my_d), [my_e] "s"(my_e),')
+        out.append('          [peer_d] "s"(peer_d), [peer_e] "s"(peer_e), [a_s] "s"(a_s), [a_m] "s"(a_m), [b_s] "s"(b_s), [b_m] "s"(b_m),')
+        out.append('          [c_s] "s"(c_s), [c_m] "s"(c_m), [mask] "s"(mask),')
+        out.append("          " + ", ".join('[k%d] "s"(key.v[%d])' % (i, i) for i in range(8)))
+        out.append("        : " + ", ".join(clob) + ");")
+        out.append("}")
     # LDS-staged AoS variant of the K2+K3 body
     for fid, (name, p) in enumerate(FIELDS):
         if name in COORD_ONLY:

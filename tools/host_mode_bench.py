@@ -23,3 +23,27 @@ t = (time.perf_counter() - t0) / reps
 moved = n * (4 * 64 + 64 + 2 * 64 + 3 * 64 + 64)     # H2D x,y,a,b + D2H d||e + H2D d||e x2 + a,b,c + D2H out
 print(json.dumps({"mode": "host buffers (pageable), one party, 2^%d gates" % int(np.log2(n)), "ms": t * 1e3, "party_gates_per_s": n / t,
                   "pcie_GBps": moved / t / 1e9}))
+# what the box's PCIe link gives with plain copies of the same volume (the ceiling for the mode above): pageable and pinned, one direction
+# and both at once
+import torch
+m = 256 << 20
+dev = torch.empty(m, dtype=torch.uint8, device="cuda"); dev2 = torch.empty(m, dtype=torch.uint8, device="cuda")
+rows = {}
+for kind in ("pageable", "pinned"):
+    h = torch.empty(m, dtype=torch.uint8); h2 = torch.empty(m, dtype=torch.uint8)
+    if kind == "pinned": h = h.pin_memory(); h2 = h2.pin_memory()
+    h.fill_(1); h2.fill_(2)
+    def h2d(): dev.copy_(h, non_blocking=True)
+    def d2h(): h2.copy_(dev2, non_blocking=True)
+    s2 = torch.cuda.Stream()
+    def both():
+        dev.copy_(h, non_blocking=True)
+        with torch.cuda.stream(s2): h2.copy_(dev2, non_blocking=True)
+    for name, fn in (("h2d", h2d), ("d2h", d2h), ("both_directions", both)):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4): fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 4
+        rows["%s_%s_GBps" % (kind, name)] = (m if name != "both_directions" else 2 * m) / dt / 1e9
+print(json.dumps({"pcie_calibration_256MiB": rows}))
