@@ -24,7 +24,15 @@ rocprofv3 -L 2>/dev/null | grep -i -E "WRREQ|WRITE_SIZE|WRITE_REQ" | head -40 > 
 $REPO/probes/write_calib 21 20 > $OUT/write_calib_plain.jsonl 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/calib_write -o calib -- $REPO/probes/write_calib 21 20 > $OUT/write_calib_under_pmc.jsonl 2> $OUT/calib_write.log
 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace -f csv -d $OUT/calib_wrreq -o calib -- $REPO/probes/write_calib 21 20 > /dev/null 2> $OUT/calib_wrreq.log
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_ec -o ec -- env REPS=3 LOG2N=18 MSM_LOG2N=10 python $REPO/tools/ec_bench.py > $OUT/ec_bench_pmc.json 2> $OUT/pmc_ec.log
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_k3 -o k3 -- $B $A > /dev/null 2> $OUT/pmc_k3.log
 cd $REPO
+REPS=5 LOG2N=18 python tools/ec_bench.py > $OUT/ec_bench.json 2>/dev/null
+python tools/ed_bench.py 2>/dev/null > $OUT/ed_bench.jsonl
+SKIP_NAIVE=1 LOG2N=10,14,18,20,22 python tools/msm_bench.py 2>/dev/null > $OUT/msm_bench.jsonl
+python tools/host_mode_bench.py 2>/dev/null > $OUT/host_mode.jsonl
+bash tools/host_latency.sh > $OUT/host_latency.jsonl 2>&1
+python tools/kernel_suite.py 2>/dev/null | grep -v "^\[" > $OUT/kernel_suite.txt
 for d in "0,0" "0,0,0,0" "0,0,0,0,0,0,0,0"; do
   N=$(echo $d | tr ',' '\n' | wc -l)
   python bench.py --single-process --gpus $N --devices $d --log2n 20 --steps 50 --warmup 5 >> $OUT/bench_single_process.jsonl 2>> $OUT/bench_single_process.log

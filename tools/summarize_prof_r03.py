@@ -117,9 +117,10 @@ for tag in ("k_beaver_finish_asm", "k_beaver_mask"):
         continue
     cyc, ns = gui[ks[0]], tavg[ks[0]]
     un = [v for kk, v in avg.items() if tag in kk]
-    ce[tag] = {"GRBM_GUI_ACTIVE_cycles_per_launch": cyc, "kernel_wall_us_in_pmc_pass": ns / 1e3, "MHz_in_pmc_pass": cyc / ns * 1e3,
+    ce[tag] = {"GRBM_GUI_ACTIVE_cycles_per_launch_sum_of_8_XCDs": cyc, "kernel_wall_us_in_pmc_pass": ns / 1e3, "busy_MHz_per_XCD_in_pmc_pass": cyc / 8 / ns * 1e3,
                "kernel_wall_us_kernel_trace_only": (un[0] / 1e3) if un else None}
-    print("  %-24s %10.0f cycles  %8.2f us (PMC pass)  -> %7.1f MHz ; kernel-trace-only pass %s us" % (tag, cyc, ns / 1e3, cyc / ns * 1e3, ("%.2f" % (un[0] / 1e3)) if un else "?"))
+    print("  %-24s %10.0f cycles (8 XCDs)  %8.2f us (PMC pass)  -> %7.1f busy-MHz per XCD ; kernel-trace-only pass %s us" % (tag, cyc, ns / 1e3, cyc / 8 / ns * 1e3,
+          ("%.2f" % (un[0] / 1e3)) if un else "?"))
 if bench_line:
     ev = bench_line["roofline"]["avg_launch_ms"] * 1e3
     ce["hip_event_us_unprofiled_run"] = ev
@@ -127,9 +128,10 @@ if bench_line:
         tr = ce["k_beaver_finish_asm"]["kernel_wall_us_kernel_trace_only"]
         ce["rocprof_over_hip_event"] = tr / ev
         print("  K2+K3: un-profiled HIP events %.2f us, rocprofv3 kernel trace %.2f us: ratio %.3f" % (ev, tr, tr / ev))
-ce["note"] = ("GRBM_GUI_ACTIVE counts GPU-busy cycles at the shader clock; divided by the kernel's wall time in the same pass it is the clock the kernel ran at "
-              "under the profiler.  MI355X_MICROARCH.md notes profiled passes clock a few per cent lower; the bench line's `frac` uses un-profiled dispatch-bound HIP events, "
-              "`frac_rocprof` the kernel-trace average")
+ce["note"] = ("GRBM_GUI_ACTIVE counts GPU-busy cycles at the shader clock, summed over the 8 XCDs, and includes the dispatch ramp around a kernel: for 37-60 us kernels "
+              "busy cycles / kernel wall time overshoots the 2.4 GHz engine clock (it is an upper bound), for the 6.6 ms k_g1_smul_loop it reads 2.16 GHz (profiles/r03/summary.txt). "
+              "What the profiler costs is read directly: the same kernel's average under rocprofv3 --kernel-trace over its un-profiled dispatch-bound HIP-event duration "
+              "(rocprof_over_hip_event, 1.03); the bench line's `frac` uses the HIP events, `frac_rocprof` the kernel-trace average")
 json.dump(ce, open(os.path.join(out, "clock_effect.json"), "w"), indent=1)
 print("== single-process group (members sharing device 0)")
 sp = os.path.join(out, "bench_single_process.jsonl")
@@ -141,3 +143,29 @@ if os.path.exists(sp):
                   json.dumps({k: round(v["GBps"], 1) for k, v in d.get("gather", {}).items() if isinstance(v, dict)})))
         except Exception as ex:
             print("  unparsable line: %r" % ex)
+
+print("== VALU occupancy of the hand-scheduled kernels (per launch; SQ_INSTS_VALU wave-instructions, GRBM_GUI_ACTIVE summed over the 8 XCDs)")
+print("   cycle model from profiles/ubench_r01.log: v_mad_u64_u32 31.2e12 lane-ops/s chip-wide = 5.04 cycles per wave64 instruction on one of the 1024 SIMDs at 2.4 GHz, other VALU 1.8x faster = 2.8 cycles")
+import json as _json
+try:
+    st = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ark-mpc_amd", "csrc", "ec_asm_stats.json")))
+except Exception:
+    st = {}
+for sub, tags in (("pmc_ec", ("k_g1_smul_loop", "k_g1_smul_table")), ("pmc_k3", ("k_beaver_finish_asm", "k_beaver_mask"))):
+    cs = {n: counter(sub, n) for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_INST_ANY")}
+    for tag in tags:
+        ks = [k for k in cs["SQ_WAVES"] if tag in k]
+        if not ks:
+            continue
+        k = ks[0]
+        w, valu, gui = cs["SQ_WAVES"][k], cs["SQ_INSTS_VALU"][k], cs["GRBM_GUI_ACTIVE"][k]
+        per_wave = valu / max(w, 1)
+        mult = {"k_g1_smul_loop": st.get("mult_instrs_loop"), "k_g1_smul_table": st.get("mult_instrs_table"), "k_beaver_finish_asm": 576 * 64, "k_beaver_mask": 0}.get(tag)
+        line = "  %-24s waves %6d  VALU/wave %9.0f  GUI_ACTIVE/XCD %11.0f  SQ_ACTIVE_INST_VALU %s  SQ_BUSY_CYCLES %s" % (
+            tag, w, per_wave, gui / 8, cs["SQ_ACTIVE_INST_VALU"].get(k), cs["SQ_BUSY_CYCLES"].get(k))
+        if mult is not None:
+            mult_per_wave = mult if tag.startswith("k_g1") else (576 if tag == "k_beaver_finish_asm" else 0)      # a wave instruction serves its 64 lanes: per-lane count = per-wave count
+            need = w * (mult_per_wave * 5.04 + (per_wave - mult_per_wave) * 2.8)
+            avail = 1024 * gui / 8
+            line += "  | multiplier instrs/wave %d  modelled VALU cycles / available SIMD cycles = %.2f" % (mult_per_wave, need / max(avail, 1))
+        print(line)
