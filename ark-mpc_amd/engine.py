@@ -214,6 +214,20 @@ class Engine:
         self.call("beaver_finish_fused_v", ("size", n), ("int", party), ("key", key), my_de, peer_de, a_s, a_m, ("size", ast),
                   b_s, b_m, ("size", bst), c_s, c_m, ("size", cst), o_s, o_m, ("size", ost))
 
+    def beaver_mask_to(self, n, xs, xst, ys, yst, as_, ast, bs, bst, out_d, out_e):
+        self.call("beaver_mask_to", ("size", n), xs, ("size", xst), ys, ("size", yst), as_, ("size", ast), bs, ("size", bst), out_d, out_e)
+    def beaver_mask_dup(self, n, xs, xst, ys, yst, as_, ast, bs, bst, out_de, out_de_msg):
+        self.call("beaver_mask_dup", ("size", n), xs, ("size", xst), ys, ("size", yst), as_, ("size", ast), bs, ("size", bst), out_de, out_de_msg)
+    def beaver_finish_fused_from(self, n, party, key, my_d, my_e, peer_d, peer_e, a_s, a_m, ast, b_s, b_m, bst, c_s, c_m, cst, o_s, o_m, ost):
+        self.call("beaver_finish_fused_from", ("size", n), ("int", party), ("key", key), my_d, my_e, peer_d, peer_e, a_s, a_m, ("size", ast),
+                  b_s, b_m, ("size", bst), c_s, c_m, ("size", cst), o_s, o_m, ("size", ost))
+    def share_add_public_v(self, n, party, key, a_s, a_m, ast, pub, o_s, o_m, ost):
+        self.call("share_add_public_v", ("size", n), ("int", party), ("key", key), a_s, a_m, ("size", ast), pub, o_s, o_m, ("size", ost))
+    def share_sub_public_v(self, n, party, key, a_s, a_m, ast, pub, o_s, o_m, ost):
+        self.call("share_sub_public_v", ("size", n), ("int", party), ("key", key), a_s, a_m, ("size", ast), pub, o_s, o_m, ("size", ost))
+    def share_mul_public_v(self, n, a_s, a_m, ast, pub, o_s, o_m, ost):
+        self.call("share_mul_public_v", ("size", n), a_s, a_m, ("size", ast), pub, o_s, o_m, ("size", ost))
+
     # ---- batch open + MAC check
     def mac_check_shares(self, n, key, opened, shares, out): self.call("mac_check_shares", ("size", n), ("key", key), opened, shares, out)
     def open_and_mac_check(self, n, key, shares, peer, out_opened, out_chk):

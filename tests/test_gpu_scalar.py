@@ -519,3 +519,80 @@ def test_error_text_is_safe_under_concurrent_failures(pkg):
     assert not errs
     assert seen <= {"", "element kind not defined for this context", "timer slot out of range"}, seen
     eng.close()
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_range_forms_dup_broadcast_and_column_ops(pkg, oracle, fid):
+    """Round-3 pointer-level entry points vs the oracle: arkmpc_beaver_mask_to / _finish_fused_from on a RANGE of a larger batch (d and e addressed
+    separately, written into the full d||e buffer), arkmpc_beaver_mask_dup (payload written twice), element stride 0 (a constant triple as ONE
+    record), and the column forms of add_public / sub_public / mul_public on split columns AND on an AoS view (stride 8)."""
+    import torch
+    n, lo, cnt = 1000, 137, 611
+    e = pkg.Engine(fid, device=0, host_buffers=False, stream=torch.cuda.current_stream().cuda_stream)
+    x, y, key, keys, sh = _two_party_inputs(fid, n, seed=777 + fid)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    cols = lambda a: (dev(a.reshape(-1, 8)[:, :4].reshape(-1)), dev(a.reshape(-1, 8)[:, 4:].reshape(-1)))
+    party = 1
+    S = {k: cols(sh[k][party]) for k in "xyabc"}
+    want_de = oracle.beaver_mask(fid, sh["x"][party], sh["y"][party], sh["a"][party], sh["b"][party])
+    off = 4 * 8 * lo                                                    # byte offset of element lo in a 32-byte column
+    # range form of K1: gates [lo, lo + cnt) written into their place of the FULL d||e buffer
+    full = torch.zeros(8 * n, dtype=torch.int64, device="cuda")
+    p = lambda t, extra=0: t.data_ptr() + extra
+    e.beaver_mask_to(cnt, p(S["x"][0], off), 4, p(S["y"][0], off), 4, p(S["a"][0], off), 4, p(S["b"][0], off), 4, p(full, off), p(full, 32 * n + off))
+    torch.cuda.synchronize()
+    got = host(full).reshape(2, n, 4)
+    w = want_de.reshape(2, n, 4)
+    assert np.array_equal(got[:, lo:lo + cnt], w[:, lo:lo + cnt]) and not got[:, :lo].any() and not got[:, lo + cnt:].any()
+    # dup: the same payload twice
+    d1 = torch.zeros(8 * n, dtype=torch.int64, device="cuda"); d2 = torch.zeros_like(d1)
+    e.beaver_mask_dup(n, S["x"][0], 4, S["y"][0], 4, S["a"][0], 4, S["b"][0], 4, d1, d2)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(d1), want_de) and np.array_equal(host(d2), want_de)
+    # range form of K2+K3 reading the two parties' d / e slices in place
+    peer_de = oracle.beaver_mask(fid, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0])
+    dpeer = dev(peer_de)
+    o_s = torch.zeros(4 * n, dtype=torch.int64, device="cuda"); o_m = torch.zeros_like(o_s)
+    e.beaver_finish_fused_from(cnt, party, keys[party], p(d1, off), p(d1, 32 * n + off), p(dpeer, off), p(dpeer, 32 * n + off),
+                               p(S["a"][0], off), p(S["a"][1], off), 4, p(S["b"][0], off), p(S["b"][1], off), 4, p(S["c"][0], off), p(S["c"][1], off), 4,
+                               p(o_s, off), p(o_m, off), 4)
+    torch.cuda.synchronize()
+    opened = oracle.open_combine(fid, want_de, peer_de)
+    want = oracle.beaver_finish(fid, party, keys[party], opened[:4 * n].copy(), opened[4 * n:].copy(), sh["a"][party], sh["b"][party], sh["c"][party]).reshape(-1, 8)
+    gs, gm = host(o_s).reshape(-1, 4), host(o_m).reshape(-1, 4)
+    assert np.array_equal(gs[lo:lo + cnt], want[lo:lo + cnt, :4]) and np.array_equal(gm[lo:lo + cnt], want[lo:lo + cnt, 4:])
+    assert not gs[:lo].any() and not gm[lo + cnt:].any()
+    # element stride 0: the triple is ONE record broadcast to every gate (vec![share; n] of the dummy source)
+    ta, tb, tc = (np.tile(sh[k][party][:8], n) for k in "abc")
+    A1, B1, C1 = (cols(sh[k][party][:8]) for k in "abc")
+    dz = torch.zeros(8 * n, dtype=torch.int64, device="cuda")
+    e.beaver_mask_v(n, S["x"][0], 4, S["y"][0], 4, A1[0], 0, B1[0], 0, dz)
+    want_dz = oracle.beaver_mask(fid, sh["x"][party], sh["y"][party], ta, tb)
+    oz_s = torch.zeros(4 * n, dtype=torch.int64, device="cuda"); oz_m = torch.zeros_like(oz_s)
+    e.beaver_finish_fused_v(n, party, keys[party], dz, dpeer, A1[0], A1[1], 0, B1[0], B1[1], 0, C1[0], C1[1], 0, oz_s, oz_m, 4)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(dz), want_dz)
+    op2 = oracle.open_combine(fid, want_dz, peer_de)
+    wz = oracle.beaver_finish(fid, party, keys[party], op2[:4 * n].copy(), op2[4 * n:].copy(), ta, tb, tc).reshape(-1, 8)
+    assert np.array_equal(host(oz_s).reshape(-1, 4), wz[:, :4]) and np.array_equal(host(oz_m).reshape(-1, 4), wz[:, 4:])
+    with pytest.raises(pkg.ArkMpcError):                                  # an OUTPUT cannot be broadcast
+        e.beaver_finish_fused_v(n, party, keys[party], dz, dpeer, A1[0], A1[1], 0, B1[0], B1[1], 0, C1[0], C1[1], 0, oz_s, oz_m, 0)
+    # column forms of the public-operand ops: split columns and an AoS view of the same records
+    pub = mont_array(fid, mixed_values(fid, n, 5))
+    dpub = dev(pub)
+    aos = dev(sh["a"][party])
+    for name, ora in (("add", lambda: oracle.share_add_public(fid, party, keys[party], sh["a"][party], pub)),
+                      ("sub", lambda: oracle.share_add_public(fid, party, keys[party], sh["a"][party], pub, sub=True)),
+                      ("mul", lambda: oracle.share_mul_public(fid, sh["a"][party], pub))):
+        wv = ora().reshape(-1, 8)
+        for view in ("split", "aos"):
+            rs = torch.zeros(4 * n, dtype=torch.int64, device="cuda"); rm = torch.zeros_like(rs)
+            a_s, a_m, ast = (S["a"][0], S["a"][1], 4) if view == "split" else (aos, aos.data_ptr() + 32, 8)
+            if name == "mul":
+                e.share_mul_public_v(n, a_s, a_m, ast, dpub, rs, rm, 4)
+            else:
+                getattr(e, "share_%s_public_v" % name)(n, party, keys[party], a_s, a_m, ast, dpub, rs, rm, 4)
+            torch.cuda.synchronize()
+            assert np.array_equal(host(rs).reshape(-1, 4), wv[:, :4]) and np.array_equal(host(rm).reshape(-1, 4), wv[:, 4:]), (name, view)
+    e.close()
