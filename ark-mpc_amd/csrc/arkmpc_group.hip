@@ -74,7 +74,10 @@ int push(arkmpc_group* g, int from, int to, void* dst, const void* src, size_t b
     if (!bytes) return ARKMPC_OK;
     hipStream_t st = g->ctx[from]->stream;
     GHIP(g, hipSetDevice(g->dev[from]));
-    if (g->dev[from] == g->dev[to]) GHIP(g, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    // ARKMPC_GROUP_FORCE_PEER=1 (test hook): take the peer-copy API even between members that share a device, so that the call the
+    // multi-GPU path makes is at least executed on a one-GPU box
+    static const bool force_peer = getenv("ARKMPC_GROUP_FORCE_PEER") && getenv("ARKMPC_GROUP_FORCE_PEER")[0] == '1';
+    if (g->dev[from] == g->dev[to] && !force_peer) GHIP(g, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
     else GHIP(g, hipMemcpyPeerAsync(dst, g->dev[to], src, g->dev[from], bytes, st));
     return ARKMPC_OK;
 }

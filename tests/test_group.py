@@ -50,6 +50,16 @@ def test_group_oversubscribed_equals_single_context(tmp_path, n, G):
 
 
 @pytest.mark.gpu
+def test_group_peer_copy_api_on_one_device(tmp_path):
+    """ARKMPC_GROUP_FORCE_PEER=1: the gathers go through hipMemcpyPeerAsync (the call the multi-GPU path makes) even though the members share
+    device 0 -- same results."""
+    import os
+    env = dict(os.environ, ARKMPC_GROUP_FORCE_PEER="1")
+    r = subprocess.run([_build_c_smoke(tmp_path, "group_oversub"), "20011", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "group ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_group_config3_and_config5_shapes_8_members(tmp_path):
     """8 members (the 8 GPUs of BASELINE configs 3 and 5, here sharing one), 2^21 gates / shares: bit-equal to ONE context."""
     r = subprocess.run([_build_c_smoke(tmp_path, "group_oversub"), str(1 << 21), "8"], capture_output=True, text=True)
