@@ -663,7 +663,30 @@ __global__ void __launch_bounds__(TPB_ED) k_ed_mac_check_kp(size_t n, const u64*
 
 #include "arkmpc_ed_msm.inc"
 
+// test hook (not part of include/arkmpc.h): the unsaturated arithmetic of the MSM kernels on caller-supplied 256-bit integers, so that its limb
+// bounds are exercised at the edges (0, 1, q - 1, q, 2^255 - 20, 2^256 - 1 ...) and not only on the coordinates random points happen to have.
+// out: 5 results of 8 words per element, canonical residues mod 2^255 - 19: a b | a + b | a - b | (a - b)(a + b) [loose limbs into the product] | a^-1
+__global__ void __launch_bounds__(128) k_f9_selftest(size_t n, const u64* a, const u64* b, u64* out) {
+    const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) return;
+    const F9 x = f9_from_words(fe_load(a + 4 * i)), y = f9_from_words(fe_load(b + 4 * i));
+    fe_store(out + 20 * i, f9_to_words(f9_mul(x, y)));
+    fe_store(out + 20 * i + 4, f9_to_words(f9_add(x, y)));
+    fe_store(out + 20 * i + 8, f9_to_words(f9_sub(x, f9_norm(y))));
+    fe_store(out + 20 * i + 12, f9_to_words(f9_mul(f9_sub(x, f9_norm(y)), f9_add(x, y))));
+    fe_store(out + 20 * i + 16, f9_to_words(f9_inv(x)));
+}
+
 extern "C" {
+
+int arkmpc_test_f9(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    ENTER_ED(ctx);
+    Stage st(ctx);
+    int ia = st.declare_in(a, n * 32), ib = st.declare_in(b, n * 32), io = st.declare_out(out, n * 160);
+    if (st.commit()) return st.rc;
+    if (n) hipLaunchKernelGGL(k_f9_selftest, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+    return st.finish();
+}
 
 int arkmpc_ed_msm(arkmpc_ctx* ctx, size_t n, const uint64_t* points, const uint64_t* scalars, uint64_t* out_point) {
     return ed_msm_impl(ctx, n, points, scalars, 4, 1, out_point);

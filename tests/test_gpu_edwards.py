@@ -338,3 +338,28 @@ def test_ed_msm_skewed_scalars(eng, oracle):
         got = _ed_msm(eng, P, mont_array(2, sc))
         xy = np.zeros(8, dtype=np.uint64); eng.ed_to_affine(1, got, xy)
         assert [pyref.from_mont(4, v) for v in limbs_to_ints(xy)] == list(want)
+
+
+def test_unsaturated_field_arithmetic_at_the_edges(pkg):
+    """arkmpc_test_f9 (a test hook of the library, not in the header): the 29-bit-limb plain arithmetic of the Curve25519 MSM kernels on 256-bit
+    integers chosen at the edges of its bounds -- against Python integers mod 2^255 - 19."""
+    import ctypes
+    import random
+    q = (1 << 255) - 19
+    edge = [0, 1, 2, 19, q - 1, q, q + 1, (1 << 255) - 20, (1 << 255) - 1, 1 << 255, (1 << 256) - 1, (1 << 256) - 38, (1 << 252), (1 << 29) - 1, ((1 << 232) - 1),
+            int("1" * 29 + "0" * 29 + "1" * 29 + "0" * 29 + "1" * 29 + "0" * 29 + "1" * 29 + "0" * 29 + "1" * 24, 2) % (1 << 256), sum(((1 << 29) - 1) << (29 * i) for i in range(8)) | (0xffffff << 232)]
+    rng = random.Random(5)
+    A = [x for x in edge for _ in edge] + [rng.randrange(1 << 256) for _ in range(400)]
+    B = [y for _ in edge for y in edge] + [rng.randrange(1 << 256) for _ in range(400)]
+    n = len(A)
+    from helpers import ints_to_limbs, limbs_to_ints
+    e = pkg.Engine("curve25519_fr", device=0, host_buffers=True)
+    a, b = ints_to_limbs(A), ints_to_limbs(B)
+    out = np.zeros(20 * n, dtype=np.uint64)
+    rc = e.lib.arkmpc_test_f9(e.h, ctypes.c_size_t(n), ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(out.ctypes.data))
+    assert rc == 0
+    got = np.array(limbs_to_ints(out), dtype=object).reshape(n, 5)
+    for i, (x, y) in enumerate(zip(A, B)):
+        want = [x * y % q, (x + y) % q, (x - y) % q, (x - y) * (x + y) % q, pow(x, q - 2, q)]
+        assert list(got[i]) == want, (hex(x), hex(y))
+    e.close()
