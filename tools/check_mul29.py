@@ -13,4 +13,6 @@ for line in sys.stdin:
         assert got % q == want and got < 2 * q, (hex(got), hex(want))
         print("mul29 ok: x*x/2^261 mod q matches Python (result in [0, 2q))")
     else:
+        if d.get("ok") is False:
+            raise SystemExit("hand-scheduled block differs from the compiled one")
         print(line.strip())
