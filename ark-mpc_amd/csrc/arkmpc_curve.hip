@@ -13,6 +13,7 @@
 #include "arkmpc_internal.hpp"
 #include "fp_asm.hpp"
 #include <cstdlib>
+#include <cstring>
 
 // Fq multiplication used by the point formulas: the hand-scheduled block fe_mul_fast (298 instructions, 2 wait states;
 // tools/gen_asm_kernels.py) unless -DARKMPC_EC_CPP selects the plain C++ core.  Measured on config 4: 12.2 ms vs 13.8 ms.
@@ -591,6 +592,7 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* p
 // Measured (config 4, 2^19 scalar-muls): see DESIGN.md section 3.
 // ---------------------------------------------------------------------------------------------
 #include "ec_asm_kernels.inc"
+#include "ec29_asm_kernels.inc"      // the same loop / table on nine 29-bit limbs (tools/gen_ec29_asm.py): the default; ARKMPC_EC_LIMBS=32 selects the kernels above
 #define TPB_LOOP 256
 // fixed-base chain on the hand-scheduled mixed-addition body (see the generator-table section above)
 __global__ void __launch_bounds__(TPB_LOOP) k_gen_mul_chain_asm(u32 n, const u32* vals, const u32* lens, const u64* table, u64* out, u32* exc) {
@@ -696,6 +698,17 @@ __global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_table(u32 ncol, const u64*
     if (i >= ncol) return;
     g1_smul_table_asm(i, p_stride * 8u * (i / p_div), ncol, points, jtab, tab, zc);
 }
+// 29-bit-limb forms: same arguments, same tab / zc / res formats (packed 32-bit words); jtab is private to the table kernel (27-word entries)
+__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_table29(u32 ncol, const u64* points, u32 p_stride, u32 p_div, u64* jtab, u64* tab, u64* zc) {
+    const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
+    if (i >= ncol) return;
+    g1_smul_table29_asm(i, p_stride * 8u * (i / p_div), ncol, points, jtab, tab, zc);
+}
+__global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_loop29(u32 n, u32 tdiv, const u64* tab, const u32* dig, u64* res, u32* exc) {
+    const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
+    if (i >= n) return;
+    g1_smul_loop29_asm(i, n, i / tdiv, n / tdiv, tab, dig, res, exc);
+}
 // tdiv lanes share one table column (ScalarShare x point: the share lane and the MAC lane multiply the same point)
 __global__ void __launch_bounds__(TPB_LOOP) k_g1_smul_loop(u32 n, u32 tdiv, const u64* tab, const u32* dig, u64* res, u32* exc) {
     const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
@@ -717,10 +730,10 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_smul_finish(u32 n, const u64* poi
     r.z = FQ_MUL(r.z, fe_load(ws.zc + 4 * (size_t)(i / tdiv)));
     g1_store(out + 12 * (size_t)i, r);
 }
-#define G1_ASM_WS_BYTES (16 * 96 + G1_ASM_TABLE * 64 + G1_ASM_STEPS * 4 + 96 + 32 + 8)
+#define G1_ASM_WS_BYTES (16 * G1_ASM29_JT_STRIDE + G1_ASM_TABLE * 64 + G1_ASM_STEPS * 4 + 96 + 32 + 8)
 static inline G1AsmWs g1_asm_carve(char* base, size_t n) {
     G1AsmWs w;
-    w.jtab = (u64*)base; base += n * 16 * 96;
+    w.jtab = (u64*)base; base += n * 16 * G1_ASM29_JT_STRIDE;     // 112 B per entry for the 29-bit table kernel, 96 used otherwise
     w.tab = (u64*)base; base += n * G1_ASM_TABLE * 64;
     w.res = (u64*)base; base += n * 96;
     w.zc = (u64*)base; base += n * 32;
@@ -979,6 +992,7 @@ static void g1_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_s
                            char* wsbase) {
     const size_t achunk = m < G1_ASM_CHUNK ? m : G1_ASM_CHUNK;
     static const bool asm_prep = !(getenv("ARKMPC_EC_ASM_PREP") && getenv("ARKMPC_EC_ASM_PREP")[0] == '0');
+    static const bool limbs29 = !(getenv("ARKMPC_EC_LIMBS") && !strcmp(getenv("ARKMPC_EC_LIMBS"), "32"));
     for (size_t lo = 0; lo < m; lo += achunk) {                // chunk boundaries are even: the point / scalar divisors (1 or 2) stay aligned
         const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
         const u64* pp = points ? points + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
@@ -991,11 +1005,13 @@ static void g1_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_s
             // p_div lanes multiply the same point: one table column serves them all (the table is a sixth of a scalar-mul's work)
             if (p_div > 1 && cnt % p_div == 0) tdiv = p_div;
             const u32 ncol = (u32)(cnt / tdiv);
-            hipLaunchKernelGGL(k_g1_smul_table, dim3(blocks_for(ncol, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.jtab, ws.tab, ws.zc);
+            if (limbs29) hipLaunchKernelGGL(k_g1_smul_table29, dim3(blocks_for(ncol, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.jtab, ws.tab, ws.zc);
+            else hipLaunchKernelGGL(k_g1_smul_table, dim3(blocks_for(ncol, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.jtab, ws.tab, ws.zc);
         } else {
             hipLaunchKernelGGL(k_g1_smul_prep, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
         }
-        hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res, ws.exc1);
+        if (limbs29 && pp && asm_prep) hipLaunchKernelGGL(k_g1_smul_loop29, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res, ws.exc1);
+        else hipLaunchKernelGGL(k_g1_smul_loop, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res, ws.exc1);
         // test hook: ARKMPC_EC_ASM_NOFIX=1 leaves flagged lanes as the loop produced them (garbage), which is how the tests prove that the
         // crafted inputs really reach the exceptional path
         static const u32 recompute = (getenv("ARKMPC_EC_ASM_NOFIX") && getenv("ARKMPC_EC_ASM_NOFIX")[0] == '1') ? 0u : 1u;

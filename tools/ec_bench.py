@@ -24,11 +24,12 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / reps * 1e-3
 asm = os.environ.get('ARKMPC_EC_ASM', '1') != '0'
-st = json.load(open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec_asm_stats.json")))
+limbs = 32 if os.environ.get("ARKMPC_EC_LIMBS") == "32" else 29
+st = json.load(open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec_asm_stats.json" if limbs == 32 else "ec29_asm_stats.json")))
 per = st["mult_instrs_loop"] + st["mult_instrs_table"]
 FQ_R01 = 27 * (5 * 7 + 2 * 16 + 1) + 8 * 7 + 7 * 16          # round 1's work definition: general multiplications per scalar-mul
 res = {"workload": "2^%d PointShare x Scalar = %d scalar-muls" % (int(np.log2(n)), 2 * n), "ms": t * 1e3, "scalar_muls_per_s": 2 * n / t,
-       "path": "hand-scheduled pipeline (digits, table, window loop, finish)" if asm else "compiled window loop (round 1)",
+       "path": "hand-scheduled pipeline (digits, table, window loop, finish), %d-bit limbs" % limbs if asm else "compiled window loop (round 1)",
        "r01_accounting_frac_of_mad_only_peak": 2 * n * FQ_R01 * 136 / t / 31.2e12}
 if asm:
     res.update({"mult_instrs_per_scalar_mul": per, "frac_of_int_alu_peak": 2 * n * per / t / 31.2e12})
