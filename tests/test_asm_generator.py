@@ -119,6 +119,61 @@ def test_committed_ec_header_is_current(tmp_path):
     assert st["mult_instrs_per_montmul"] == 136 and st["mult_instrs_per_montsqr"] == 108 and st["doublings"] == 130 and st["mixed_additions"] == 55
 
 
+# ---- round 3: the same two streams on nine 29-bit limbs (tools/gen_ec29_asm.py -> csrc/ec29_asm_kernels.inc) -----------------------
+import gen_ec29_asm as ec29  # noqa: E402
+
+
+def test_ec29_bodies_match_the_affine_group_law_and_keep_their_bounds():
+    """Double and mixed addition on unsaturated limbs, scheduled as emitted, against the affine group law; outputs must satisfy the
+    accumulator invariant the generator carried (limbs, value); the exceptional inputs must leave Z = 0 (mod q) and Z must stay 0
+    through a following double / add (the loop's single end-of-run test relies on that)."""
+    Ed, Ea = ec29.selftest(trials=48, seed=20260929)
+    assert len(Ed.order) < 1600 and len(Ea.order) < 2400
+
+
+def test_ec29_every_multiplication_at_its_operand_bounds():
+    assert ec29.selftest_extremes() >= 15
+
+
+def test_ec29_limb_operations_against_integers():
+    import random
+    rng = random.Random(3)
+    Q, M29 = ec29.Q, ec29.M29
+    rm = ec29.RegMap()
+    for t in range(40):
+        la = [rng.randrange(M29 + 9) for _ in range(8)] + [rng.randrange(1 << 26)]
+        lb = [rng.randrange(4 * M29) for _ in range(8)] + [rng.randrange(1 << 25)]
+        if t == 0:
+            la = [M29 + 8] * 8 + [(1 << 26) - 1]; lb = [4 * M29] * 8 + [(1 << 25) - 1]
+        a = ec29.FV(rm.X1, M29 + 8, (1 << 26) - 1, ec29.val29([M29 + 8] * 8 + [(1 << 26) - 1]))
+        b = ec29.FV(rm.X2, 4 * M29, (1 << 25) - 1, ec29.val29([4 * M29] * 8 + [(1 << 25) - 1]))
+        B = ec29.Bld(rm)
+        d = B.sub(a, b, rm.T0)
+        dn = B.norm(d, rm.T1)
+        ng = B.neg(b, rm.T2)
+        sa = B.shl_add(a, 1, a, rm.SY)
+        E = ec29.Emitter(); E.schedule(B.seq)
+        em = ec29.emu_for(); em.set9(rm.X1, la); em.set9(rm.X2, lb)
+        em.run(E.order)
+        va, vb = ec29.val29(la), ec29.val29(lb)
+        got_d = [em.v[r] for r in rm.T0]
+        assert (ec29.val29(got_d) - (va - vb)) % Q == 0 and ec29.val29(got_d) <= d.vmax and max(got_d[:8]) <= d.lmax and got_d[8] <= d.tmax
+        got_n = [em.v[r] for r in rm.T1]
+        assert ec29.val29(got_n) == ec29.val29(got_d) and max(got_n[:8]) <= dn.lmax <= M29 + 8
+        assert (em.get9(rm.T2) + vb) % Q == 0 and em.get9(rm.T2) <= ng.vmax
+        assert em.get9(rm.SY) == 3 * va
+
+
+def test_committed_ec29_header_is_current(tmp_path):
+    out = tmp_path / "ec29_asm_kernels.inc"
+    ec29.emit_header(str(out))
+    committed = open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec29_asm_kernels.inc")).read()
+    assert out.read_text() == committed, "regenerate with: python tools/gen_ec29_asm.py"
+    import json
+    st = json.load(open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec29_asm_stats.json")))
+    assert st["mult_instrs_per_mul"] == 171 and st["mult_instrs_per_sqr"] == 135 and st["doublings"] == 130 and st["mixed_additions"] == 55
+
+
 # ---- round 2: the Curve25519 window loop (tools/gen_ed_asm.py -> csrc/ed_asm_kernels.inc) ------------------------------------
 import gen_ed_asm as ed  # noqa: E402
 

@@ -246,8 +246,10 @@ def _exceptional_cases():
     return flagged, plain
 
 
-def test_crafted_inputs_really_hit_the_exceptional_path(tmp_path):
-    """With the recomputation switched off (ARKMPC_EC_ASM_NOFIX=1, a test hook) every crafted lane must come out WRONG and every
+@pytest.mark.parametrize("limbs", ["29", "32"])
+def test_crafted_inputs_really_hit_the_exceptional_path(tmp_path, limbs):
+    """Both forms of the window loop (nine 29-bit limbs: the default, flag = final Z is 0 mod q; eight 32-bit limbs, ARKMPC_EC_LIMBS=32: flag = H is 0
+    in an addition) must flag exactly the same lanes.  With the recomputation switched off (ARKMPC_EC_ASM_NOFIX=1, a test hook) every crafted lane must come out WRONG and every
     ordinary lane right: the inputs do reach H = 0 inside the loop, and nothing else does."""
     import os
     import subprocess
@@ -268,11 +270,49 @@ def test_crafted_inputs_really_hit_the_exceptional_path(tmp_path):
         gx, gi = hip.g1_batch_to_affine(got); wx, wi = ora.g1_batch_to_affine(want)
         print([int(np.array_equal(gx[8 * i:8 * i + 8], wx[8 * i:8 * i + 8]) and gi[i] == wi[i]) for i in range(len(cases))])
     """ % (root, root))
-    env = dict(os.environ, ARKMPC_EC_ASM_NOFIX="1")
+    env = dict(os.environ, ARKMPC_EC_ASM_NOFIX="1", ARKMPC_EC_LIMBS=limbs)
     r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     flagged, plain = _exceptional_cases()
     assert eval(r.stdout.strip().splitlines()[-1]) == [0] * len(flagged) + [1] * len(plain)
+
+
+def test_both_limb_forms_of_the_pipeline_agree_with_the_oracle():
+    """The 32-bit-limb kernels stay selectable (ARKMPC_EC_LIMBS=32); a mixed batch -- crafted exceptional lanes, the identity, zero scalars,
+    random lanes -- and a PointShare x Scalar batch (two lanes per table column) must equal the oracle in that form too, and the canonical affine
+    outputs of the two forms must be the same bytes."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import importlib, sys, os, hashlib
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, pyref, oracle_api
+        from helpers import mont_array, rand_values, EngineAdapter
+        import test_gpu_curve as T
+        hip = EngineAdapter(importlib.import_module("ark-mpc_amd")); ora = oracle_api.load()
+        flagged, plain = T._exceptional_cases()
+        rnd_pts, _ = T.random_points(150, 99, with_identity=False)
+        pts = [c[0] for c in flagged + plain] + rnd_pts; ks = [c[1] for c in flagged + plain] + rand_values(0, 150, 100)
+        P = T.jac(pts, [11 + 3 * i for i in range(len(pts))]); S = mont_array(0, ks)
+        got = hip.g1_batch_scalar_mul(P, S)
+        ok1 = T.affine_equal(hip, ora, got, ora.g1_batch_scalar_mul(P, S))
+        n = len(pts) // 2
+        sc = mont_array(0, rand_values(0, n, 101))
+        got2 = hip.pointshare_mul_public(P[:24 * n], sc); want2 = ora.pointshare_mul_public(P[:24 * n], sc)
+        ok2 = T.affine_equal(hip, ora, got2, want2)
+        xy, inf = hip.g1_batch_to_affine(got); xy2, inf2 = hip.g1_batch_to_affine(got2)
+        print(int(ok1), int(ok2), hashlib.sha256(xy.tobytes() + inf.tobytes() + xy2.tobytes() + inf2.tobytes()).hexdigest())
+    """ % (root, root))
+    outs = {}
+    for limbs in ("29", "32"):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, ARKMPC_EC_LIMBS=limbs), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[limbs] = r.stdout.strip().splitlines()[-1].split()
+        assert outs[limbs][:2] == ["1", "1"], (limbs, outs[limbs])
+    assert outs["29"][2] == outs["32"][2]
 
 
 def test_asm_loop_exceptional_lanes_are_recomputed_exactly(hip, oracle):

@@ -43,7 +43,7 @@ M29 = (1 << 29) - 1
 RP = 1 << 261                       # Montgomery radix of this representation
 R32 = 1 << 256                      # radix of the engine's 32-bit representation (memory formats)
 N_STEPS, N_TABLE = EC.N_STEPS, EC.N_TABLE
-JT_STRIDE = 112                     # bytes per Jacobian scratch entry (27 words + pad)
+JT_STRIDE = 128                     # bytes per scratch entry of the table kernel: eight 16-byte chunks (27 words used)
 
 # ---- SGPR map (all clobbered by the asm statements) -------------------------------------------------------------------------
 S_JUNK, S_INV, S_MASK = "s[16:17]", "s18", "s19"
@@ -197,6 +197,7 @@ class Bld:
     def __init__(self, rm):
         self.rm, self.seq = rm, []
         self.n_mul = self.n_sqr = 0
+        self.sigs = []                                      # operand bounds of every multiplication built (selftest_extremes)
 
     # -- multiplier ---------------------------------------------------------------------------------------------------------
     def mul(self, prods, out):
@@ -218,6 +219,7 @@ class Bld:
                 plist.append((a.r, b.r, False))
             col += 9 * a.big * b.big
             vprod += a.vmax * b.vmax
+        self.sigs.append(tuple((a.lmax, a.tmax, b.lmax, b.tmax, a is b) for a, b in prods))
         assert col < (1 << 64), "multiplier column can overflow: normalise an operand (%.2f bits)" % (col.bit_length())
         first = True
         for k in range(2 * NL - 1):
@@ -298,8 +300,9 @@ def fv_z(r):
 
 # ---- the two bodies ----------------------------------------------------------------------------------------------------------
 def seq_double(rm, B=None):
-    """dbl-2009-l with a = 0, in place on (X1, Y1, Z1); scratch X2, Y2, SX, SY, T0..T2, W.  D = X (4B) and 8C = 2 (2B)^2 keep the powers
-    of two in limb shifts; 7 multiplier blocks (4 squarings), 3 subtractions, 3 carry passes."""
+    """dbl-2009-l with a = 0, in place on (X1, Y1, Z1); scratch X2, Y2, SX, T0..T2, W.  D = X (4B) keeps the powers of two in limb
+    shifts and Y3 = E (D - X3) + (K - 4B)(2B) is ONE reduction of two products; 6 multiplier blocks (3 squarings), 3 subtractions / negations,
+    4 carry passes."""
     B = B or Bld(rm)
     X, Y, Z = fv_acc(rm.X1), fv_acc(rm.Y1), fv_z(rm.Z1)
     A = B.mul([(X, X)], rm.T0)
@@ -309,25 +312,25 @@ def seq_double(rm, B=None):
     B4 = B.shl(Bq, 2, rm.T2)
     D = B.mul([(X, B4)], rm.X2)
     E = B.norm(B.shl_add(A, 1, A, rm.SX))                   # E = 3 A
+    NB4 = B.norm(B.neg(B4, rm.T2))                          # K - 4 B
     B2 = B.shl(Bq, 1, rm.T1)
-    C4 = B.mul([(B2, B2)], rm.T1)
-    C8 = B.shl(C4, 1, rm.T1)
-    F = B.mul([(E, E)], rm.SY)
-    D2 = B.shl(D, 1, rm.T2)
+    F = B.mul([(E, E)], rm.Y2)
+    D2 = B.shl(D, 1, rm.T0)
     X3 = B.norm(B.sub(F, D2, rm.X1))
-    DX = B.sub(D, X3, rm.X2)
-    Yt = B.mul([(E, DX)], rm.Y1)
-    Y3 = B.norm(B.sub(Yt, C8, rm.Y1))
+    DX = B.norm(B.sub(D, X3, rm.X2))
+    Y3 = B.mul([(E, DX), (NB4, B2)], rm.Y1)                 # E (D - X3) - 8 B^2: one reduction for both products
     check_acc(X3, "double X3"); check_acc(Y3, "double Y3")
     assert Z3.vmax <= fv_z(rm.Z1).vmax
     return B
 
 
-def seq_madd(rm, B=None, y2=None):
+def seq_madd(rm, B=None, y2=None, h2_out=None):
     """madd-2007-bl: (X1, Y1, Z1) += affine (X2, Y2), in place; scratch T0..T2, W.  Z3 = Z1 (2H), I = (2H)^2, and
     Y3 = r (V - X3) + (K - 2 Y1) J is ONE reduction of two products.  10 multiplier blocks (3 squarings), 5 subtractions / negations,
-    5 carry passes.  y2: bounds of the second operand's y (the loop negates it conditionally)."""
+    5 carry passes.  y2: bounds of the second operand's y (the loop negates it conditionally).  h2_out: registers that keep 2H = Z3 / Z1
+    (the table kernel rescales its entries with these factors)."""
     B = B or Bld(rm)
+    B.h2 = None
     X1, Y1, Z1 = fv_acc(rm.X1), fv_acc(rm.Y1), fv_z(rm.Z1)
     X2 = fv_mulout(rm.X2, (2 * Q) * (2 * Q))                # table entries are multiplier outputs (below 2q, limbs below 2^29)
     Y2 = y2 or fv_mulout(rm.Y2, (2 * Q) * (2 * Q))
@@ -336,8 +339,9 @@ def seq_madd(rm, B=None, y2=None):
     YZ = B.mul([(Y2, Z1)], rm.Y2)
     S2 = B.mul([(YZ, ZZ)], rm.Y2)
     H = B.norm(B.sub(U2, X1, rm.X2))
-    H2 = B.shl(H, 1, rm.T0)
+    H2 = B.shl(H, 1, h2_out or rm.T0)
     Z3 = B.mul([(Z1, H2)], rm.Z1)
+    B.h2 = H2
     I = B.mul([(H2, H2)], rm.T0)
     r = B.shl(B.norm(B.sub(S2, Y1, rm.Y2)), 1, rm.Y2)
     V = B.mul([(X1, I)], rm.X1)
@@ -387,19 +391,28 @@ def seq_pack(l, words):
 
 # ---- registers -------------------------------------------------------------------------------------------------------------------
 class RegMap:
-    def __init__(self, first=8):
+    """The loop needs the saved accumulator (SX, SY, SZ) and ends at v147: three waves per SIMD.  The table kernel has no saved accumulator
+    and no digit record, and fits 128 VGPRs: FOUR waves per SIMD -- at 2^18 columns that is the whole launch resident at once instead of
+    three quarters of it followed by a tail at one wave per SIMD."""
+
+    def __init__(self, first=8, table_kernel=False):
         rg = G.Regs(first)
-        blk = rg.vec(27, 4)
+        blk = rg.vec(27, 2)
         self.X1, self.Y1, self.Z1 = blk[0:9], blk[9:18], blk[18:27]          # accumulator; contiguous: one jtab entry
-        blk = rg.vec(27, 4)
+        blk = rg.vec(27, 2)
         self.X2, self.Y2, self.SX = blk[0:9], blk[9:18], blk[18:27]          # table entry / operand; contiguous for the table kernel
-        blk = rg.vec(18, 4)
-        self.SY, self.SZ = blk[0:9], blk[9:18]
-        self.T0, self.T1, self.T2 = rg.vec(9, 4), rg.vec(9, 4), rg.vec(9, 4)
+        if not table_kernel:
+            blk = rg.vec(18, 2)
+            self.SY, self.SZ = blk[0:9], blk[9:18]
+        self.T0, self.T1, self.T2 = rg.vec(9, 2), rg.vec(9, 2), rg.vec(9, 2)
         self.W = rg.vec(9, 2)                                                # doubled operand of a squaring / carries of norm
         self.m = rg.vec(9)
         self.acc = rg.pair()
-        self.rec, self.off, self.tid4, self.tid64, self.tid96, self.tmp, self.flag, self.off2, self.tid32, self.tidjt = (rg.one() for _ in range(10))
+        self.off, self.tid64, self.tmp = (rg.one() for _ in range(3))
+        if table_kernel:
+            self.off2, self.tid32, self.tidjt = (rg.one() for _ in range(3))
+        else:
+            self.rec, self.tid4, self.tid96, self.flag = (rg.one() for _ in range(4))
         self.first, self.end = first, rg.next
 
 
@@ -539,6 +552,37 @@ def selftest(trials=40, seed=11):
     return Ed, Ea
 
 
+def selftest_extremes():
+    """Every multiplication the two bodies contain, re-built on its own with ALL limbs of both operands at the bounds the generator
+    carried to that point: the emulator asserts that no column overflows 64 bits and the result is checked against Python integers."""
+    rm = RegMap()
+    sigs = set(seq_double(rm).sigs) | set(seq_madd(rm).sigs)
+    Bn = Bld(rm)
+    yn = Bn.neg(fv_mulout(rm.Y2, 4 * Q * Q), rm.T2)
+    sigs |= set(seq_madd(rm, y2=FV(rm.Y2, yn.lmax, yn.tmax, yn.vmax)).sigs)
+    Rinv = pow(RP, -1, Q)
+    for sig in sorted(sigs):
+        B = Bld(rm)
+        em = emu_for()
+        ops, want = [], 0
+        pool = [rm.X1, rm.X2, rm.Y2, rm.SX]
+        for k, (al, at, bl, bt, sq) in enumerate(sig):
+            ra, rb = pool[2 * k], pool[2 * k + 1]
+            la, lb = [al] * 8 + [at], [bl] * 8 + [bt]
+            a = FV(ra, al, at, val29(la)); em.set9(ra, la)
+            if sq:
+                ops.append((a, a)); want += val29(la) ** 2
+            else:
+                b = FV(rb, bl, bt, val29(lb)); em.set9(rb, lb)
+                ops.append((a, b)); want += val29(la) * val29(lb)
+        B.mul(ops, rm.Y1)
+        E = Emitter(); E.schedule(B.seq)
+        em.run(E.order)
+        got = [em.v[r] for r in rm.Y1]
+        assert max(got[:8]) <= M29 and val29(got) % Q == want * Rinv % Q and val29(got) <= want // RP + Q, sig
+    return len(sigs)
+
+
 # ---- the window loop -----------------------------------------------------------------------------------------------------------------
 def emit_loop():
     """Operands as g1_smul_loop_asm (tools/gen_ec_asm.py): %[tid] %[ptid] (VGPR), %[n] %[np] (SGPR), %[tab] %[dig] %[res] %[exc] (SGPR pairs)."""
@@ -655,24 +699,54 @@ def emit_loop():
 
 # ---- the table kernel -----------------------------------------------------------------------------------------------------------------
 def emit_table():
-    """Operands as g1_smul_table_asm: %[tid] %[poff] (VGPR), %[n] (SGPR), %[pts] %[jtab] %[tab] %[zc] (SGPR pairs).  jtab entries here are
-    27 words (X | Y | Z, nine limbs each) at a 112-byte stride."""
-    rm = RegMap()
+    """Operands as g1_smul_table_asm: %[tid] %[poff] (VGPR), %[n] (SGPR), %[pts] %[jtab] %[tab] %[zc] (SGPR pairs).
+
+    The 16 multiples T_e = (e + 1) P are built on the curve where P is affine (one doubling, 14 mixed additions), each with its own z_e; every
+    step multiplies Z by a factor g_e (2Y for the doubling, 2H for an addition), so z_e = g_1 ... g_e and the LAST z is a common multiple of all:
+    T_e rescaled to Z* = z_15 is (X_e c^2, Y_e c^3) with c = g_{e+1} ... g_15 -- ONE backward pass with a running product, no prefix
+    products and no inversion.  Scratch (jtab) entry e = (X_e, Y_e, g_e), 27 words in eight 16-byte chunks, chunk-major: chunk k of entry e
+    of lane t sits at ((8 e + k) n + t) 16, so every load / store instruction of a wave covers one contiguous kilobyte."""
+    rm = RegMap(table_kernel=True)
+    assert rm.end <= 128, "the table kernel must stay at four waves per SIMD"
     L = []
     A = L.append
     ld, st = mem_ops(A)
     lbl = lambda s_: "%s_%%=" % s_
-    S_E = S_STEP
-    ACC = rm.X1 + rm.Y1 + rm.Z1
-    ENT = rm.X2 + rm.Y2 + rm.SX
-    mults = [0]
+    S_E, S_N16 = S_STEP, S_N4
+    XY1, XY2 = rm.X1 + rm.Y1, rm.X2 + rm.Y2
+    tid16 = rm.tid32                                                         # lane * 16; the zc offset (lane * 32) is rebuilt at the end
 
     def sched(seq):
         E = Emitter()
         E.schedule(seq)
         L.extend(E.lines)
-        mults[0] += 0
         return E
+
+    def chunks(regs):
+        return [regs[i:i + 4] for i in range(0, len(regs), 4)]
+
+    def jt_off(dst, sidx):                                                   # dst = sidx * (8 n 16) + lane * 16
+        A("s_mul_i32 %s, %s, %s" % (S_TMP, sidx, S_NJT))
+        A("v_add_u32_e32 %s, %s, %s" % (dst, S_TMP, tid16))
+
+    def jt_io(kind, off, groups, first_chunk=0):
+        """groups: register runs, each starting a new chunk; `off` is advanced chunk by chunk (and left past the last one)"""
+        if first_chunk:
+            A("s_mul_i32 %s, %s, %d" % (S_TMP, S_N16, first_chunk))
+            A("v_add_u32_e32 %s, %s, %s" % (off, S_TMP, off))
+        n = 0
+        for g in groups:
+            for c in chunks(g):
+                if n:
+                    A("v_add_u32_e32 %s, %s, %s" % (off, S_N16, off))
+                sfx = {1: "dword", 2: "dwordx2", 3: "dwordx3", 4: "dwordx4"}[len(c)]
+                if kind == "st":
+                    A("global_store_%s %s, %s, %%[jtab]" % (sfx, off, vrange(c)))
+                else:
+                    A("global_load_%s %s, %s, %%[jtab]" % (sfx, vrange(c), off))
+                n += 1
+        if kind == "st":
+            A("s_nop 0")
 
     def entry_off(dst, sidx, stride_s, tid_v):
         A("s_mul_i32 %s, %s, %s" % (S_TMP, sidx, stride_s))
@@ -684,104 +758,79 @@ def emit_table():
 
     one = RP % Q
     prologue(A, rm)
-    A("v_lshlrev_b32_e32 %s, 5, %%[tid]" % rm.tid32)
+    A("v_lshlrev_b32_e32 %s, 4, %%[tid]" % tid16)
     A("v_lshlrev_b32_e32 %s, 6, %%[tid]" % rm.tid64)
-    A("v_mul_u32_u24_e32 %s, %d, %%[tid]" % (rm.tidjt, JT_STRIDE))
     A("s_lshl_b32 %s, %%[n], 6" % S_N64)
-    A("s_mul_i32 %s, %%[n], %d" % (S_NJT, JT_STRIDE))
-    # ---- T1 = P as the affine point (X, Y) of the curve scaled by its own Z, converted to 29-bit limbs / R' = 2^261 (x 2^266 / 2^261 = x 2^5)
+    A("s_lshl_b32 %s, %%[n], 4" % S_N16)
+    A("s_lshl_b32 %s, %%[n], 7" % S_NJT)
+    # ---- T_0 = P as the affine point (X, Y) of the curve scaled by its own Z, converted to 29-bit limbs / R' = 2^261 (x 2^266 / 2^261 = x 2^5)
     ld(rm.T1[:8], "%[poff]", "pts", 0); ld(rm.T2[:8], "%[poff]", "pts", 32)
     c266 = const_to(A, (1 << 266) % Q)
     mov_const(rm.Z1, one)
     A("s_waitcnt vmcnt(0)")
     Bc = Bld(rm)
     Bc.seq += seq_unpack(rm.T1[:8], rm.X1) + seq_unpack(rm.T2[:8], rm.Y1)
-    lazy_in = FV(rm.X1, M29, (1 << 24) - 1, (1 << 256) - 1)                      # any 256-bit input
-    Bc.mul([(lazy_in, c266)], rm.X1)
+    Bc.mul([(FV(rm.X1, M29, (1 << 24) - 1, (1 << 256) - 1), c266)], rm.X1)     # any 256-bit input
     Bc.mul([(FV(rm.Y1, M29, (1 << 24) - 1, (1 << 256) - 1), c266)], rm.Y1)
     sched(Bc.seq)
-    st(ACC, rm.tidjt, "jtab", 0)
-    Ed = sched(seq_double(rm).seq)
+    A("v_mov_b32_e32 %s, %s" % (rm.off, tid16))
+    jt_io("st", rm.off, [XY1])
+    Ed = sched(seq_double(rm).seq)                                           # T_1 = 2 P; g_1 = Z3 = 2 Y
     A("s_mov_b32 %s, 1" % S_E)
-    entry_off(rm.off, S_E, S_NJT, rm.tidjt)
-    st(ACC, rm.off, "jtab", 0)
-    A("s_waitcnt vmcnt(0)")
-    ld(rm.SY + rm.SZ, rm.tidjt, "jtab", 0)                                    # (x, y) of P for the additions
-    A("s_waitcnt vmcnt(0)")
-    # ---- T[e+1] = T[e] + P, e = 2 .. 15 (entry index = multiple - 1)
+    jt_off(rm.off, S_E)
+    jt_io("st", rm.off, [XY1, rm.Z1])
+    # ---- T_e = T_{e-1} + P, e = 2 .. 15; (x, y) of P come back from entry 0 every time (L2-resident); g_e = 2 H
     A("s_mov_b32 %s, 2" % S_E)
     A(lbl("T_build") + ":")
-    for d, s_ in zip(rm.X2 + rm.Y2, rm.SY + rm.SZ):
-        A("v_mov_b32_e32 %s, %s" % (d, s_))
-    Ea = sched(seq_madd(rm).seq)
-    entry_off(rm.off, S_E, S_NJT, rm.tidjt)
-    st(ACC, rm.off, "jtab", 0)
+    A("s_waitcnt vmcnt(0)")
+    A("v_mov_b32_e32 %s, %s" % (rm.off, tid16))
+    jt_io("ld", rm.off, [XY2])
+    A("s_waitcnt vmcnt(0)")
+    Ba = seq_madd(rm, h2_out=rm.SX)
+    Ea = sched(Ba.seq)
+    g_bounds = Ba.h2
+    jt_off(rm.off, S_E)
+    jt_io("st", rm.off, [XY1, rm.SX])
     A("s_add_u32 %s, %s, 1" % (S_E, S_E))
     A("s_cmp_lt_u32 %s, 16" % S_E)
     A("s_cbranch_scc1 " + lbl("T_build"))
     A("s_waitcnt vmcnt(0)")
-    # ---- prefix products of the z's: p_e = z_0 ... z_e (z_0 = 1), nine limbs parked at the start of tab[e]; "p_-1" = 1 in tab[17]
-    mov_const(rm.X1, one)
-    A("s_mov_b32 %s, 17" % S_IDX)
-    entry_off(rm.off, S_IDX, S_N64, rm.tid64)
-    st(rm.X1, rm.off, "tab", 0)
-    st(rm.X1, rm.tid64, "tab", 0)                                              # p_0 = 1
-    A("s_mov_b32 %s, 1" % S_E)
-    A(lbl("T_prefix") + ":")
-    entry_off(rm.off, S_E, S_NJT, rm.tidjt)
-    ld(rm.T0, rm.off, "jtab", 72)
-    A("s_waitcnt vmcnt(0)")
-    zf = fv_z(rm.T0)
-    pf = fv_mulout(rm.X1, 4 * Q * Q)
-    Bp = Bld(rm); Bp.mul([(pf, zf)], rm.X1); sched(Bp.seq)
-    entry_off(rm.off, S_E, S_N64, rm.tid64)
-    st(rm.X1, rm.off, "tab", 0)
-    A("s_add_u32 %s, %s, 1" % (S_E, S_E))
-    A("s_cmp_lt_u32 %s, 16" % S_E)
-    A("s_cbranch_scc1 " + lbl("T_prefix"))
-    for d, s_ in zip(rm.Z1, rm.X1):                                            # Zc = p_15
-        A("v_mov_b32_e32 %s, %s" % (d, s_))
-    A("s_waitcnt vmcnt(0)")
-    # ---- backward: c_e = p_{e-1} * (z_{e+1} ... z_15) = Zc / z_e ; x' = X c^2, y' = Y c^3 ; packed stores
-    mov_const(rm.Y1, one)                                                      # suffix product
+    # ---- backward: c = g_{e+1} ... g_15 (c = 1 for e = 15); x' = X c^2, y' = Y c^3; packed stores; then c *= g_e
+    mov_const(rm.T0, one)
     A("s_mov_b32 %s, 15" % S_E)
     A(lbl("T_back") + ":")
-    A("s_sub_u32 %s, %s, 1" % (S_IDX, S_E))
-    A("s_cmp_eq_u32 %s, 0" % S_E)
-    A("s_cselect_b32 %s, 17, %s" % (S_IDX, S_IDX))
-    entry_off(rm.off, S_IDX, S_N64, rm.tid64)
-    ld(rm.T0, rm.off, "tab", 0)
-    entry_off(rm.off2, S_E, S_NJT, rm.tidjt)
-    ld(ENT, rm.off2, "jtab", 0)
+    jt_off(rm.off, S_E)
+    jt_io("ld", rm.off, [XY2, rm.SX])
     A("s_waitcnt vmcnt(0)")
     Bk = Bld(rm)
     m2 = lambda r: fv_mulout(r, 4 * Q * Q)
-    c = Bk.mul([(m2(rm.T0), m2(rm.Y1))], rm.T0)                               # c
+    c = m2(rm.T0)
     c2 = Bk.mul([(c, c)], rm.T1)                                               # c^2
     Bk.mul([(fv_acc(rm.X2), c2)], rm.X2)                                       # x'
     c3 = Bk.mul([(c2, c)], rm.T1)                                              # c^3
     Bk.mul([(fv_acc(rm.Y2), c3)], rm.Y2)                                       # y'
-    Bk.mul([(m2(rm.Y1), fv_z(rm.SX))], rm.Y1)                                  # suffix *= z_e
+    gz = fv_z(rm.SX)
+    g = FV(rm.SX, max(g_bounds.lmax, gz.lmax), max(g_bounds.tmax, gz.tmax), max(g_bounds.vmax, gz.vmax))     # 2 H of an addition, or Z3 of the doubling (entry 1)
+    Bk.mul([(c, g)], rm.T0)                                                    # c *= g_e  (entry 0's g is never stored: the product is not used)
     Bk.seq += seq_pack(rm.X2, rm.T1[:8]) + seq_pack(rm.Y2, rm.T2[:8])
     sched(Bk.seq)
     entry_off(rm.off, S_E, S_N64, rm.tid64)
     st(rm.T1[:8], rm.off, "tab", 0); st(rm.T2[:8], rm.off, "tab", 32)
-    A("s_waitcnt vmcnt(0)")
     A("s_cmp_eq_u32 %s, 0" % S_E)
     A("s_cbranch_scc1 " + lbl("T_back_done"))
     A("s_sub_u32 %s, %s, 1" % (S_E, S_E))
     A("s_branch " + lbl("T_back"))
     A(lbl("T_back_done") + ":")
-    # ---- total Z of the table on the ORIGINAL curve: Zt = Zc * Z_P; blinding point and correction on the table's curve
+    # ---- total Z of the table on the ORIGINAL curve: Zt = Z* Z_P; blinding point and correction on the table's curve
     ld(rm.T2[:8], "%[poff]", "pts", 64)
     A("s_waitcnt vmcnt(0)")
-    const_to(A, (1 << 266) % Q)
+    c266 = const_to(A, (1 << 266) % Q)
     Bz = Bld(rm)
     Bz.seq += seq_unpack(rm.T2[:8], rm.SX)
     zp = Bz.mul([(FV(rm.SX, M29, (1 << 24) - 1, (1 << 256) - 1), c266)], rm.SX)
-    zt = Bz.mul([(m2(rm.Z1), zp)], rm.Z1)                                      # Zt
+    zt = Bz.mul([(fv_z(rm.Z1), zp)], rm.Z1)                                    # Zt
     zt2 = Bz.mul([(zt, zt)], rm.T0)                                            # Zt^2
-    zt3 = Bz.mul([(zt2, zt)], rm.SY)                                           # Zt^3
+    zt3 = Bz.mul([(zt2, zt)], rm.Y1)                                           # Zt^3
     sched(Bz.seq)
     t_ = int.from_bytes(hashlib.sha3_256(b"arkmpc g1 window-loop blinding point R0").digest(), "big") % RORD
     R0 = EC.g1_mul(EC.GEN, t_)
@@ -799,14 +848,14 @@ def emit_table():
         A("s_mov_b32 %s, %d" % (S_IDX, idx))
         entry_off(rm.off, S_IDX, S_N64, rm.tid64)
         st(rm.T1[:8], rm.off, "tab", 0); st(rm.T2[:8], rm.off, "tab", 32)
-        A("s_waitcnt vmcnt(0)")
     # Zt back to R = 2^256, packed (lazy range: the finish kernel multiplies it into the result's Z)
     c256 = const_to(A, R32 % Q)
     Bo = Bld(rm)
     Bo.mul([(zt, c256)], rm.Z1)
-    Bo.seq += seq_pack(rm.Z1, rm.T1[:8])
+    Bo.seq += seq_pack(rm.Z1, rm.X2[:8])
     sched(Bo.seq)
-    st(rm.T1[:8], rm.tid32, "zc", 0)
+    A("v_lshlrev_b32_e32 %s, 1, %s" % (rm.off, tid16))
+    st(rm.X2[:8], rm.off, "zc", 0)
     A("s_waitcnt vmcnt(0)")
     return L, rm, dict(double=len(Ed.order), madd=len(Ea.order), vgpr_end=rm.end)
 
@@ -826,7 +875,7 @@ def emit_header(path):
     cm = count_mults()
     n_dbl = 5 * (N_STEPS // 2 - 1)
     loop_m = n_dbl * cm["double"] + N_STEPS * cm["madd"] + (N_STEPS // 2) * cm["mul"] + 3 * cm["mul"]
-    table_m = 2 * cm["mul"] + cm["double"] + 14 * cm["madd"] + 15 * cm["mul"] + 16 * (5 * cm["mul"] + cm["sqr"]) + (3 * cm["mul"] + cm["sqr"]) + 4 * cm["mul"] + cm["mul"]
+    table_m = 2 * cm["mul"] + cm["double"] + 14 * cm["madd"] + 16 * (4 * cm["mul"] + cm["sqr"]) + (3 * cm["mul"] + cm["sqr"]) + 4 * cm["mul"] + cm["mul"]
     out = []
     out.append("// GENERATED by tools/gen_ec29_asm.py -- do not edit.  The BN254 G1 window loop and its table kernel on NINE 29-bit limbs (Montgomery radix 2^261):")
     out.append("// product-scanning multiplier with one 64-bit column accumulator, carry-free limb additions, bounds carried by the generator.")
@@ -872,6 +921,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.selftest:
         Ed, Ea = selftest(trials=200)
+        print("multiplications at their operand bounds: %d distinct, ok" % selftest_extremes())
         print("double ok: %d instructions; madd ok: %d instructions" % (len(Ed.order), len(Ea.order)))
         sys.exit(0)
     st, nlines = emit_header(a.o)

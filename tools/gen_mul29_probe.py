@@ -29,6 +29,13 @@ def i_and(d, a, b): return Ins("v_and_b32_e32 %s, %s, %s" % (d, src(a), b), "and
 def i_shr64(d, s_, sh): return Ins("v_lshrrev_b64 %s, %d, %s" % (pr(d), sh, pr(s_)), "shr64", (d, s_, sh), rd=list(s_), wr=list(d))
 def i_add64(d, a, b): return Ins("v_lshl_add_u64 %s, %s, 0, %s" % (pr(d), pr(a), pr(b)), "add64", (d, a, b), rd=list(a) + list(b), wr=list(d))
 def i_mov(d, s_): return Ins("v_mov_b32_e32 %s, %s" % (d, src(s_)), "mov", (d, s_), rd=regs_of(s_), wr=[d])
+def i_alignbit(d, hi, lo, sh): return Ins("v_alignbit_b32 %s, %s, %s, %d" % (d, hi, lo, sh), "alignbit", (d, hi, lo, sh), rd=regs_of(hi, lo), wr=[d])
+def i_lshr(d, a, sh): return Ins("v_lshrrev_b32_e32 %s, %d, %s" % (d, sh, a), "lshr", (d, a, sh), rd=regs_of(a), wr=[d])
+SPLIT_SHIFT = [False]        # the column carry as v_alignbit_b32 + v_lshrrev_b32 instead of one v_lshrrev_b64
+def carry_shift(acc):
+    if SPLIT_SHIFT[0]:
+        return [i_alignbit(acc[0], acc[1], acc[0], 29), i_lshr(acc[1], acc[1], 29)]
+    return [i_shr64(acc, acc, 29)]
 
 
 class Emu29(Emu):
@@ -38,6 +45,11 @@ class Emu29(Emu):
                 d, s_, sh = ins.args
                 v = (self.rd(s_[0]) | (self.rd(s_[1]) << 32)) >> sh
                 self.v[d[0]], self.v[d[1]] = v & M32, v >> 32
+            elif ins.op == "alignbit":
+                d, hi, lo, sh = ins.args
+                self.v[d] = (((self.rd(hi) << 32) | self.rd(lo)) >> sh) & M32
+            elif ins.op == "lshr":
+                self.v[ins.args[0]] = self.rd(ins.args[1]) >> ins.args[2]
             elif ins.op == "add64":
                 d, a, b = ins.args
                 v = ((self.rd(a[0]) | (self.rd(a[1]) << 32)) + (self.rd(b[0]) | (self.rd(b[1]) << 32))) & ((1 << 64) - 1)
@@ -67,13 +79,11 @@ def mul29_seq(a, b, o, acc0, acc1, m, two_acc=True):
             seq.append(i_mul_lo(m[k], acc0[0], S_INV))
             seq.append(i_and(m[k], S_MASK, m[k]))
             seq.append(i_mad(acc0, m[k], S_Q[0], acc0))
-            seq.append(i_shr64(acc0, acc0, 29))
+            seq += carry_shift(acc0)
         else:
             seq.append(i_and(o[k - 9], S_MASK, acc0[0]))
-            if k < 16:
-                seq.append(i_shr64(acc0, acc0, 29))
-            else:
-                seq.append(i_shr64(acc0, acc0, 29))
+            seq += carry_shift(acc0)
+            if k == 16:
                 seq.append(i_mov(o[8], acc0[0]))
         carry = acc0
     return seq
@@ -127,10 +137,11 @@ def selftest(trials=300, two_acc=True):
 def main():
     out = []
     out.append("// GENERATED by tools/gen_mul29_probe.py -- do not edit.  Hand-scheduled 29-bit-limb Montgomery multiplication (BN254 Fq, R = 2^261) for probes/mulrate29.hip.")
-    for name, two in (("mul29_asm", True), ("mul29_asm_1acc", False)):
+    for name, two in (("mul29_asm", True), ("mul29_asm_1acc", False), ("mul29_asm_1acc_split", False)):
+        SPLIT_SHIFT[0] = name.endswith("_split")
         E, mp = selftest(two_acc=two)
         nmad = sum(1 for i in E.order if i.op == "mad")
-        nother = sum(1 for i in E.order if i.op in ("mul_lo", "and", "shr64", "add64", "mov"))
+        nother = sum(1 for i in E.order if i.op in ("mul_lo", "and", "shr64", "add64", "mov", "alignbit", "lshr"))
         clob = ['"vcc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in mp["used"]]
         out.append("// %s: %d v_mad_u64_u32 + %d other VALU" % (name, nmad, nother))
         out.append("__device__ __forceinline__ F29 %s(const F29& a, const F29& b) {" % name)

@@ -1,5 +1,10 @@
-set -x
+# A/B of the two limb forms of the BN254 scalar-mul pipeline: curve tests, config-4 timing, per-kernel durations under the kernel trace
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_curve.py -m gpu -x -q 2>&1 | tail -15
-ARKMPC_EC_LIMBS=32 python tools/ec_bench.py 2>&1 | tail -1 | tee gpurun_out/ec_bench_32.json
-python tools/ec_bench.py 2>&1 | tail -1 | tee gpurun_out/ec_bench_29.json
+timeout 1200 python -m pytest tests/test_gpu_curve.py -m gpu -x -q 2>&1 | tail -3
+for L in 32 29; do ARKMPC_EC_LIMBS=$L python tools/ec_bench.py 2>&1 | tail -1 | tee gpurun_out/ec_bench_$L.json; done
+R=$PWD; cd /tmp && export TMPDIR=/tmp
+for L in 32 29; do
+  ARKMPC_EC_LIMBS=$L rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_$L -o p -- python $R/tools/ec_bench.py > $R/gpurun_out/ec_prof_$L.log 2>&1
+  f=$(find /tmp/prof_$L -name '*kernel_stats.csv' | head -1)
+  head -4 "$f" | cut -c1-160 | tee $R/gpurun_out/ec_kernel_stats_$L.csv
+done
