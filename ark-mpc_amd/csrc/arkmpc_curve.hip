@@ -482,6 +482,13 @@ __device__ __forceinline__ void g1_to_affine(const G1& a, Fe& x, Fe& y, bool& in
 // scalar-mul loop (g1_msm_acc_asm, the bucket fold of the MSM: the digit list of a lane IS a bucket run); a chain that meets
 // H = 0 only flags its lane and k_gen_mul_chain redoes it with the complete compiled addition.
 // ---------------------------------------------------------------------------------------------
+#include "ec_asm_kernels.inc"
+#include "ec29_asm_kernels.inc"      // the same loop / table on nine 29-bit limbs (tools/gen_ec29_asm.py): the default; ARKMPC_EC_LIMBS=32 selects the kernels above
+// nine 29-bit limbs (default) or eight 32-bit limbs (ARKMPC_EC_LIMBS=32) in the hand-scheduled kernels: window loop, table, MSM bucket fold, generator chain
+static bool g1_limbs29() {
+    static const bool on = !(getenv("ARKMPC_EC_LIMBS") && !strcmp(getenv("ARKMPC_EC_LIMBS"), "32"));
+    return on;
+}
 #define GEN_C 12
 #define GEN_WINDOWS 22                      // ceil(254 / 12); the top window holds 2 scalar bits + carry
 #define GEN_ENTRIES (1u << (GEN_C - 1))     // |digit| = 1 .. 2048
@@ -493,7 +500,13 @@ __global__ void __launch_bounds__(64) k_gen_table_bases(u64* bases) {           
         for (int k = 0; k < GEN_C; ++k) b = g1_double(b);
     }
 }
-__global__ void __launch_bounds__(TPB_EC) k_gen_table_fill(const u64* bases, u64* table) {     // thread (w, d): d * B_w, normalised
+__device__ __forceinline__ Fe fq_words(const u32 (&c)[8]) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = c[i];
+    return r;
+}
+__global__ void __launch_bounds__(TPB_EC) k_gen_table_fill(const u64* bases, u64* table, u64* table29) {     // thread (w, d): d * B_w, normalised
     const u32 t = blockIdx.x * TPB_EC + threadIdx.x;
     if (t >= GEN_WINDOWS * GEN_ENTRIES) return;
     const u32 w = t / GEN_ENTRIES, d = t % GEN_ENTRIES + 1;
@@ -507,6 +520,9 @@ __global__ void __launch_bounds__(TPB_EC) k_gen_table_fill(const u64* bases, u64
     g1_to_affine(acc, x, y, inf);                        // never the identity: d * 2^(12w) < r
     fe_store(table + 8 * (size_t)t, x);
     fe_store(table + 8 * (size_t)t + 4, y);
+    // the same entries for the 29-bit-limb chain (g1_msm_acc29_asm): Montgomery radix 2^261
+    fe_store(table29 + 8 * (size_t)t, FQ_CANON(FQ_MUL(x, fq_words(G1_ASM29_TO29))));
+    fe_store(table29 + 8 * (size_t)t + 4, FQ_CANON(FQ_MUL(y, fq_words(G1_ASM29_TO29))));
 }
 // signed 12-bit digits of the canonical scalar as a compacted member list: vals[GEN_WINDOWS * i + j] = table index | sign << 31 for the
 // j-th NON-ZERO digit, lens[i] = how many there are
@@ -591,8 +607,6 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_scalar_mul(size_t n, const u64* p
 //           crafted collisions with R0) are recomputed by the compiled window path, so every input gets the exact group-law result.
 // Measured (config 4, 2^19 scalar-muls): see DESIGN.md section 3.
 // ---------------------------------------------------------------------------------------------
-#include "ec_asm_kernels.inc"
-#include "ec29_asm_kernels.inc"      // the same loop / table on nine 29-bit limbs (tools/gen_ec29_asm.py): the default; ARKMPC_EC_LIMBS=32 selects the kernels above
 #define TPB_LOOP 256
 // fixed-base chain on the hand-scheduled mixed-addition body (see the generator-table section above)
 __global__ void __launch_bounds__(TPB_LOOP) k_gen_mul_chain_asm(u32 n, const u32* vals, const u32* lens, const u64* table, u64* out, u32* exc) {
@@ -605,6 +619,17 @@ __global__ void __launch_bounds__(TPB_LOOP) k_gen_mul_chain_asm(u32 n, const u32
     if (!valid) return;
     if (len == 0) { g1_store(out + 12 * (size_t)i, g1_identity()); exc[i] = 0; return; }     // zero scalar
     g1_msm_acc_asm(i * (GEN_WINDOWS * 4u), len, maxlen, vals, table, out + 12 * (size_t)i, i * 4u, exc);
+}
+__global__ void __launch_bounds__(TPB_LOOP) k_gen_mul_chain_asm29(u32 n, const u32* vals, const u32* lens, const u64* table29, u64* out, u32* exc) {
+    const u32 i = blockIdx.x * TPB_LOOP + threadIdx.x;
+    const bool valid = i < n;
+    const u32 len = valid ? lens[i] : 0u;
+    u32 m = len;
+    for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)m, o); m = other > m ? other : m; }
+    const u32 maxlen = __builtin_amdgcn_readfirstlane(m);
+    if (!valid) return;
+    if (len == 0) { g1_store(out + 12 * (size_t)i, g1_identity()); exc[i] = 0; return; }     // zero scalar
+    g1_msm_acc29_asm(i * (GEN_WINDOWS * 4u), len, maxlen, vals, table29, out + 12 * (size_t)i, i * 4u, exc);
 }
 struct G1AsmWs {
     u64* jtab;      // [16][n] Jacobian multiples (scratch of prep; window table of the fallback in finish)
@@ -958,7 +983,8 @@ static const size_t EC_CHUNK = (size_t)1 << 20;     // scalar-muls per launch: b
 
 // generator table, one per device, built on first use (a few milliseconds) and kept for the life of the process
 static std::mutex g_gen_mu;
-static u64* g_gen_table[16] = {nullptr};
+static u64* g_gen_table[16] = {nullptr};      // [0, N): entries in the engine's Montgomery form; [N, 2N): the same entries with radix 2^261 (29-bit-limb chain)
+static const size_t GEN_TABLE_WORDS = (size_t)GEN_WINDOWS * GEN_ENTRIES * 8;
 static int gen_table(arkmpc_ctx* ctx, const u64** out) {
     const int dev = ctx->device;
     if (dev < 0 || dev >= 16) return ark_bad(ctx, "device index");
@@ -966,9 +992,9 @@ static int gen_table(arkmpc_ctx* ctx, const u64** out) {
     if (!g_gen_table[dev]) {
         u64 *bases = nullptr, *table = nullptr;
         ARK_HIP(ctx, hipMalloc((void**)&bases, GEN_WINDOWS * 96));
-        ARK_HIP(ctx, hipMalloc((void**)&table, (size_t)GEN_WINDOWS * GEN_ENTRIES * 64));       // 2.75 MiB
+        ARK_HIP(ctx, hipMalloc((void**)&table, 2 * GEN_TABLE_WORDS * 8));                       // 2 x 2.75 MiB
         hipLaunchKernelGGL(k_gen_table_bases, dim3(1), dim3(64), 0, ctx->stream, bases);
-        hipLaunchKernelGGL(k_gen_table_fill, dim3(blocks_for(GEN_WINDOWS * GEN_ENTRIES, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, bases, table);
+        hipLaunchKernelGGL(k_gen_table_fill, dim3(blocks_for(GEN_WINDOWS * GEN_ENTRIES, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, bases, table, table + GEN_TABLE_WORDS);
         ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ARK_HIP(ctx, hipFree(bases));
         g_gen_table[dev] = table;
@@ -992,7 +1018,7 @@ static void g1_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_s
                            char* wsbase) {
     const size_t achunk = m < G1_ASM_CHUNK ? m : G1_ASM_CHUNK;
     static const bool asm_prep = !(getenv("ARKMPC_EC_ASM_PREP") && getenv("ARKMPC_EC_ASM_PREP")[0] == '0');
-    static const bool limbs29 = !(getenv("ARKMPC_EC_LIMBS") && !strcmp(getenv("ARKMPC_EC_LIMBS"), "32"));
+    static const bool limbs29 = g1_limbs29();
     for (size_t lo = 0; lo < m; lo += achunk) {                // chunk boundaries are even: the point / scalar divisors (1 or 2) stay aligned
         const size_t cnt = (m - lo < achunk) ? (m - lo) : achunk;
         const u64* pp = points ? points + (size_t)p_stride * (lo / p_div) : (const u64*)nullptr;
@@ -1085,7 +1111,8 @@ static int smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_t n
             u64* o = st.out<u64>(io) + 12 * lo;
             hipLaunchKernelGGL(k_gen_digits, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, cnt, sp, s_stride, s_div, vals, lens);
             if (asm_loop) {
-                hipLaunchKernelGGL(k_gen_mul_chain_asm, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, vals, lens, table, o, exc);
+                if (g1_limbs29()) hipLaunchKernelGGL(k_gen_mul_chain_asm29, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, vals, lens, table + GEN_TABLE_WORDS, o, exc);
+                else hipLaunchKernelGGL(k_gen_mul_chain_asm, dim3(blocks_for(cnt, TPB_LOOP)), dim3(TPB_LOOP), 0, ctx->stream, (u32)cnt, vals, lens, table, o, exc);
                 if (fix) hipLaunchKernelGGL(k_gen_mul_chain, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, vals, lens, table, o, (const u32*)exc);
             } else {
                 hipLaunchKernelGGL(k_gen_mul_chain, dim3(blocks_for(cnt, TPB_EC)), dim3(TPB_EC), 0, ctx->stream, cnt, vals, lens, table, o, (const u32*)nullptr);

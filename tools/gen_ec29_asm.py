@@ -395,7 +395,7 @@ class RegMap:
     and no digit record, and fits 128 VGPRs: FOUR waves per SIMD -- at 2^18 columns that is the whole launch resident at once instead of
     three quarters of it followed by a tail at one wave per SIMD."""
 
-    def __init__(self, first=8, table_kernel=False):
+    def __init__(self, first=8, table_kernel=False, msm=False):
         rg = G.Regs(first)
         blk = rg.vec(27, 2)
         self.X1, self.Y1, self.Z1 = blk[0:9], blk[9:18], blk[18:27]          # accumulator; contiguous: one jtab entry
@@ -413,6 +413,9 @@ class RegMap:
             self.off2, self.tid32, self.tidjt = (rg.one() for _ in range(3))
         else:
             self.rec, self.tid4, self.tid96, self.flag = (rg.one() for _ in range(4))
+        if msm:
+            self.LD1, self.LD2 = rg.vec(8, 2), rg.vec(8, 2)                  # landing registers of the prefetched member (the addition uses T1 / T2)
+            self.rec2, self.last = rg.one(), rg.one()
         self.first, self.end = first, rg.next
 
 
@@ -860,6 +863,110 @@ def emit_table():
     return L, rm, dict(double=len(Ed.order), madd=len(Ea.order), vgpr_end=rm.end)
 
 
+def emit_msm_acc():
+    """Bucket accumulation of the variable-base MSM and the fixed-base chain (as g1_msm_acc_asm of tools/gen_ec_asm.py) on the 29-bit mixed
+    addition.  Members are 64-byte affine records whose coordinates are ALREADY in this representation's Montgomery form (x 2^261 mod q as a
+    256-bit integer: the producers multiply by 2^5 once); the sum leaves in the engine's format (R = 2^256, lazy words).  The next member's
+    coordinates are requested BEFORE the addition of the current one (they land in registers the addition does not touch).  A chain that
+    meets H = 0 ends with Z = 0 (mod q): one test in the epilogue raises the lane's flag.
+    Operands: %[lo4] %[len] (VGPR), %[maxlen] (SGPR), %[vals] %[aff] %[exc] (SGPR pairs), %[dst] (VGPR pair), %[t4] (VGPR)."""
+    rm = RegMap(msm=True)
+    L = []
+    A = L.append
+    ld, st = mem_ops(A)
+    lbl = lambda s: "%s_%%=" % s
+
+    def sched(seq, pre=None):
+        E = Emitter()
+        if pre: E.lastw.update(pre)
+        E.schedule(seq)
+        L.extend(E.lines)
+        return E
+
+    def load_xy():
+        A("v_lshlrev_b32_e32 %s, 6, %s" % (rm.off, rm.rec))                 # 64 bytes per member; the shift drops the sign bit (index < 2^25)
+        ld(rm.LD1, rm.off, "aff", 0); ld(rm.LD2, rm.off, "aff", 32)
+
+    prologue(A, rm)
+    A("v_add_u32_e32 %s, -1, %%[len]" % rm.last)
+    A("global_load_dword %s, %%[lo4], %%[vals]" % rm.rec)
+    A("v_min_u32_e32 %s, 1, %s" % (rm.tmp, rm.last))
+    A("v_lshl_add_u32 %s, %s, 2, %%[lo4]" % (rm.tmp, rm.tmp))
+    A("global_load_dword %s, %s, %%[vals]" % (rm.rec2, rm.tmp))
+    A("s_waitcnt vmcnt(1)")
+    load_xy()
+    A("v_cmp_gt_i32_e64 %s, 0, %s" % (S_NEG, rm.rec))
+    for j, l in enumerate(limbs29(RP % Q)):
+        A("v_mov_b32_e32 %s, 0x%08x" % (rm.Z1[j], l))
+    A("s_waitcnt vmcnt(0)")
+    # accumulator = +- first member: unpack, negate y where the sign bit says so, one carry pass (the accumulator invariant wants normalised limbs)
+    B0 = Bld(rm)
+    B0.seq += seq_unpack(rm.LD1, rm.X1) + seq_unpack(rm.LD2, rm.Y1)
+    y_in = fv_mulout(rm.Y1, 4 * Q * Q)
+    y_neg = B0.neg(y_in, rm.T2)
+    B0.seq += [i_cnd(rm.Y1[j], rm.Y1[j], rm.T2[j], S_NEG) for j in range(NL)]
+    y0 = B0.norm(FV(rm.Y1, max(y_in.lmax, y_neg.lmax), max(y_in.tmax, y_neg.tmax), max(y_in.vmax, y_neg.vmax)))
+    check_acc(y0, "first member")
+    sched(B0.seq, pre={S_NEG: -1})
+    A("v_mov_b32_e32 %s, %s" % (rm.rec, rm.rec2))
+    load_xy()
+    A("s_mov_b32 %s, 1" % S_STEP)
+    A("s_cmp_ge_u32 %s, %%[maxlen]" % S_STEP)
+    A("s_cbranch_scc1 " + lbl("L_done"))
+    EC.align_head(A)
+    A(lbl("L_step") + ":")
+    A("s_add_u32 %s, %s, 1" % (S_TMP, S_STEP))
+    A("v_min_u32_e32 %s, %s, %s" % (rm.tmp, S_TMP, rm.last))
+    A("v_lshl_add_u32 %s, %s, 2, %%[lo4]" % (rm.tmp, rm.tmp))
+    A("global_load_dword %s, %s, %%[vals]" % (rm.rec2, rm.tmp))
+    A("v_cmp_gt_u32_e64 %s, %%[len], %s" % (S_NZ, S_STEP))                  # this lane still has a member at this step
+    A("v_cmp_gt_i32_e64 %s, 0, %s" % (S_NEG, rm.rec))
+    for d, s_ in zip(rm.SX + rm.SY + rm.SZ, rm.X1 + rm.Y1 + rm.Z1):
+        A("v_mov_b32_e32 %s, %s" % (d, s_))
+    A("s_waitcnt vmcnt(1)")
+    Bn = Bld(rm)
+    Bn.seq += seq_unpack(rm.LD1, rm.X2) + seq_unpack(rm.LD2, rm.Y2)
+    y_in = fv_mulout(rm.Y2, 4 * Q * Q)
+    y_neg = Bn.neg(y_in, rm.T2)
+    Bn.seq += [i_cnd(rm.Y2[j], rm.Y2[j], rm.T2[j], S_NEG) for j in range(NL)]
+    sched(Bn.seq, pre={S_NEG: -1})
+    y2 = FV(rm.Y2, max(y_in.lmax, y_neg.lmax), max(y_in.tmax, y_neg.tmax), max(y_in.vmax, y_neg.vmax))
+    # the member after this one: its coordinates fly during the addition
+    A("s_waitcnt vmcnt(0)")
+    A("v_mov_b32_e32 %s, %s" % (rm.rec, rm.rec2))
+    load_xy()
+    Ba = seq_madd(rm, y2=y2)
+    Ea = sched(Ba.seq)
+    A("s_nop 1")
+    for d, s_ in zip(rm.X1 + rm.Y1 + rm.Z1, rm.SX + rm.SY + rm.SZ):
+        A("v_cndmask_b32_e64 %s, %s, %s, %s" % (d, s_, d, S_NZ))
+    A("s_add_u32 %s, %s, 1" % (S_STEP, S_STEP))
+    A("s_cmp_lt_u32 %s, %%[maxlen]" % S_STEP)
+    A("s_cbranch_scc1 " + lbl("L_step"))
+    A(lbl("L_done") + ":")
+    A("s_waitcnt vmcnt(0)")                                                   # the last prefetch (clamped to the last member) is not used
+    c256 = const_to(A, R32 % Q)
+    Bo = Bld(rm)
+    Bo.mul([(fv_acc(rm.X1), c256)], rm.X1)
+    Bo.mul([(fv_acc(rm.Y1), c256)], rm.Y1)
+    Bo.mul([(fv_z(rm.Z1), c256)], rm.Z1)
+    Bo.seq += seq_pack(rm.X1, rm.T0[:8]) + seq_pack(rm.Y1, rm.T1[:8]) + seq_pack(rm.Z1, rm.T2[:8])
+    u = rm.X2
+    Bo.seq += [i_or(u[0], rm.T2[0], rm.T2[1])] + [i_or(u[0], u[0], rm.T2[j]) for j in range(2, 8)] + [i_cmpz(S_M1, u[0])]
+    Bo.seq += [i_xor(u[j], (Q >> (32 * j)) & M32, rm.T2[j]) for j in range(8)]
+    Bo.seq += [i_or(u[0], u[0], u[j]) for j in range(1, 8)] + [i_cmpz(S_M2, u[0])]
+    sched(Bo.seq)
+    A("s_nop 1")
+    A("s_or_b64 %s, %s, %s" % (S_EXC, S_M1, S_M2))
+    for k, regs in enumerate((rm.T0[:4], rm.T0[4:8], rm.T1[:4], rm.T1[4:8], rm.T2[:4], rm.T2[4:8])):
+        A("global_store_dwordx4 %%[dst], %s, off offset:%d" % (vrange(regs), 16 * k))
+    A("s_nop 0")
+    A("v_cndmask_b32_e64 %s, 0, 1, %s" % (rm.flag, S_EXC))
+    A("global_store_dword %%[t4], %s, %%[exc]" % rm.flag)
+    A("s_waitcnt vmcnt(0)")
+    return L, rm, dict(madd=len(Ea.order), vgpr_end=rm.end)
+
+
 def count_mults():
     rm = RegMap()
     cnt = lambda B: sum(1 for i in B.seq if i.op in ("mad", "mul_lo"))
@@ -885,6 +992,11 @@ def emit_header(path):
     out.append("#pragma once")
     out.append("#define G1_ASM29_MULT_INSTRS_LOOP %d\n#define G1_ASM29_MULT_INSTRS_TABLE %d" % (loop_m, table_m))
     out.append("#define G1_ASM29_JT_STRIDE %d" % JT_STRIDE)
+    w32 = lambda v: ", ".join("0x%08xu" % ((v >> (32 * i)) & M32) for i in range(8))
+    out.append("// member records of g1_msm_acc29_asm hold x 2^261 (this representation's Montgomery form) where the engine's records hold x 2^256:")
+    out.append("// FQ_MUL(record, TO29) converts there (x 2^256 * 2^261 / 2^256), FQ_MUL(record29, FROM29) back (x 2^261 * 2^251 / 2^256)")
+    out.append("__device__ constexpr u32 G1_ASM29_TO29[8] = {%s};" % w32((1 << 261) % Q))
+    out.append("__device__ constexpr u32 G1_ASM29_FROM29[8] = {%s};" % w32((1 << 251) % Q))
     out.append("__device__ __forceinline__ void g1_smul_loop29_asm(u32 tid, u32 n, u32 ptid, u32 np, const u64* tab, const u32* dig, u64* res, u32* exc) {")
     out.append("    asm volatile(")
     out.append(G.c_string(lines))
@@ -904,6 +1016,16 @@ def emit_header(path):
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(trm.first, trm.end)]
     out.append("        : " + ", ".join(clob) + ");")
     out.append("}")
+    mlines, mrm, mst = emit_msm_acc()
+    out.append("// bucket accumulation of the variable-base MSM / the fixed-base chain on the same mixed addition: %d asm lines, VGPRs v%d..v%d" % (len(mlines), mrm.first, mrm.end - 1))
+    out.append("__device__ __forceinline__ void g1_msm_acc29_asm(u32 lo4, u32 len, u32 maxlen, const u32* vals, const u64* aff, u64* dst, u32 t4, u32* exc) {")
+    out.append("    asm volatile(")
+    out.append(G.c_string(mlines))
+    out.append("        :")
+    out.append('        : [lo4] "v"(lo4), [len] "v"(len), [maxlen] "s"(maxlen), [vals] "s"(vals), [aff] "s"(aff), [dst] "v"(dst), [t4] "v"(t4), [exc] "s"(exc)')
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mrm.first, mrm.end)]
+    out.append("        : " + ", ".join(clob) + ");")
+    out.append("}")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
     import json
@@ -911,7 +1033,7 @@ def emit_header(path):
         json.dump({"mult_instrs_loop": loop_m, "mult_instrs_table": table_m, "mult_instrs_per_mul": cm["mul"], "mult_instrs_per_sqr": cm["sqr"],
                    "mult_instrs_double": cm["double"], "mult_instrs_madd": cm["madd"], "doublings": n_dbl, "mixed_additions": N_STEPS,
                    "double_body_instrs": st["double"], "madd_body_instrs": st["madd"]}, f, indent=1)
-    return st, len(lines) + len(tlines)
+    return st, len(lines) + len(tlines) + len(mlines)
 
 
 if __name__ == "__main__":
