@@ -391,9 +391,9 @@ def seq_pack(l, words):
 
 # ---- registers -------------------------------------------------------------------------------------------------------------------
 class RegMap:
-    """The loop needs the saved accumulator (SX, SY, SZ) and ends at v147: three waves per SIMD.  The table kernel has no saved accumulator
-    and no digit record, and fits 128 VGPRs: FOUR waves per SIMD -- at 2^18 columns that is the whole launch resident at once instead of
-    three quarters of it followed by a tail at one wave per SIMD."""
+    """Fixed VGPR allocation (v8 upwards).  All three kernels run at three waves per SIMD; the streams are VALU-issue-bound from two waves up
+    (PMC, config 4: 4.08 SIMD cycles per VALU instruction in the loop AND in the table kernel -- one wave-instruction per 4 cycles is the
+    hardware's limit; a table kernel squeezed into 120 VGPRs for four waves per SIMD measured no faster)."""
 
     def __init__(self, first=8, table_kernel=False, msm=False):
         rg = G.Regs(first)
@@ -401,9 +401,8 @@ class RegMap:
         self.X1, self.Y1, self.Z1 = blk[0:9], blk[9:18], blk[18:27]          # accumulator; contiguous: one jtab entry
         blk = rg.vec(27, 2)
         self.X2, self.Y2, self.SX = blk[0:9], blk[9:18], blk[18:27]          # table entry / operand; contiguous for the table kernel
-        if not table_kernel:
-            blk = rg.vec(18, 2)
-            self.SY, self.SZ = blk[0:9], blk[9:18]
+        blk = rg.vec(18, 2)
+        self.SY, self.SZ = blk[0:9], blk[9:18]                                # loop: saved accumulator; table kernel: (x, y) of P, second entry buffer
         self.T0, self.T1, self.T2 = rg.vec(9, 2), rg.vec(9, 2), rg.vec(9, 2)
         self.W = rg.vec(9, 2)                                                # doubled operand of a squaring / carries of norm
         self.m = rg.vec(9)
@@ -588,8 +587,10 @@ def selftest_extremes():
 
 # ---- the window loop -----------------------------------------------------------------------------------------------------------------
 def emit_loop():
-    """Operands as g1_smul_loop_asm (tools/gen_ec_asm.py): %[tid] %[ptid] (VGPR), %[n] %[np] (SGPR), %[tab] %[dig] %[res] %[exc] (SGPR pairs)."""
-    rm = RegMap()
+    """Operands as g1_smul_loop_asm (tools/gen_ec_asm.py): %[tid] %[ptid] (VGPR), %[n] %[np] (SGPR), %[tab] %[dig] %[res] %[exc] (SGPR pairs).
+    The digit record and the table entry of step s + 1 are requested before the addition of step s (landing registers LD1 / LD2, which no
+    body touches), so a step never waits for memory."""
+    rm = RegMap(msm=True)
     L = []
     A = L.append
     ld, st = mem_ops(A)
@@ -602,6 +603,12 @@ def emit_loop():
         L.extend(E.lines)
         return E
 
+    def load_entry():                                                           # table entry named by rm.rec -> LD1 / LD2
+        A("v_and_b32_e32 %s, 31, %s" % (rm.tmp, rm.rec))
+        A("v_mul_lo_u32 %s, %s, %s" % (rm.tmp, rm.tmp, S_N64))
+        A("v_add_u32_e32 %s, %s, %s" % (rm.off, rm.tmp, rm.tid64))
+        ld(rm.LD1, rm.off, "tab", 0); ld(rm.LD2, rm.off, "tab", 32)
+
     prologue(A, rm)
     beta = const_to(A, mont(EC.unmont(EC.BETA)))           # stays in S_C until the epilogue's constant replaces it
     A("v_lshlrev_b32_e32 %s, 2, %%[tid]" % rm.tid4)
@@ -609,6 +616,7 @@ def emit_loop():
     A("v_mul_u32_u24_e32 %s, 96, %%[tid]" % rm.tid96)
     A("s_lshl_b32 %s, %%[n], 2" % S_N4)
     A("s_lshl_b32 %s, %%[np], 6" % S_N64)
+    A("global_load_dword %s, %s, %%[dig]" % (rm.rec, rm.tid4))                   # record of step 0
     # accumulator = table entry 16 (R0 on the isomorphic curve), Z = 1 (Montgomery form)
     A("s_mul_i32 %s, %s, 16" % (S_TMP, S_N64))
     A("v_add_u32_e32 %s, %s, %s" % (rm.off, S_TMP, rm.tid64))
@@ -616,13 +624,18 @@ def emit_loop():
     for j, l in enumerate(limbs29(RP % Q)):
         A("v_mov_b32_e32 %s, 0x%08x" % (rm.Z1[j], l))
     A("s_waitcnt vmcnt(0)")
+    load_entry()
     sched(seq_unpack(rm.T1[:8], rm.X1) + seq_unpack(rm.T2[:8], rm.Y1))
     A("s_mov_b32 %s, 0" % S_STEP)
     EC.align_head(A)
     A(lbl("L_step") + ":")
-    A("s_mul_i32 %s, %s, %s" % (S_TMP, S_STEP, S_N4))
+    # record of the NEXT step (the last step asks for its own again)
+    A("s_add_u32 %s, %s, 1" % (S_TMP, S_STEP))
+    A("s_min_u32 %s, %s, %d" % (S_TMP, S_TMP, N_STEPS - 1))
+    A("s_mul_i32 %s, %s, %s" % (S_TMP, S_TMP, S_N4))
     A("v_add_u32_e32 %s, %s, %s" % (rm.off, S_TMP, rm.tid4))
-    A("global_load_dword %s, %s, %%[dig]" % (rm.rec, rm.off))
+    A("global_load_dword %s, %s, %%[dig]" % (rm.rec2, rm.off))
+    # five doublings before the first half of every window but the top one (steps 2, 4, ..., 52)
     A("s_and_b32 %s, %s, 1" % (S_TMP, S_STEP))
     A("s_cmp_eq_u32 %s, 1" % S_TMP)
     A("s_cbranch_scc1 " + lbl("L_nodbl"))
@@ -639,11 +652,7 @@ def emit_loop():
     A("s_cmp_lg_u32 %s, 0" % S_DBL)
     A("s_cbranch_scc1 " + lbl("L_dbl"))
     A(lbl("L_nodbl") + ":")
-    A("s_waitcnt vmcnt(0)")
-    A("v_and_b32_e32 %s, 31, %s" % (rm.tmp, rm.rec))
-    A("v_mul_lo_u32 %s, %s, %s" % (rm.tmp, rm.tmp, S_N64))
-    A("v_add_u32_e32 %s, %s, %s" % (rm.off, rm.tmp, rm.tid64))
-    ld(rm.T1[:8], rm.off, "tab", 0); ld(rm.T2[:8], rm.off, "tab", 32)
+    # masks from this step's record (bits 0-4 table index, bit 5 negate, bit 6 digit non-zero); the accumulator is saved
     A("v_and_b32_e32 %s, 32, %s" % (rm.tmp, rm.rec))
     A("v_cmp_ne_u32_e64 %s, 0, %s" % (S_NEG, rm.tmp))
     A("v_and_b32_e32 %s, 64, %s" % (rm.tmp, rm.rec))
@@ -651,7 +660,10 @@ def emit_loop():
     for d, s_ in zip(rm.SX + rm.SY + rm.SZ, rm.X1 + rm.Y1 + rm.Z1):
         A("v_mov_b32_e32 %s, %s" % (d, s_))
     A("s_waitcnt vmcnt(0)")
-    sched(seq_unpack(rm.T1[:8], rm.X2) + seq_unpack(rm.T2[:8], rm.Y2))
+    sched(seq_unpack(rm.LD1, rm.X2) + seq_unpack(rm.LD2, rm.Y2))
+    # the next step's entry flies during this step's addition
+    A("v_mov_b32_e32 %s, %s" % (rm.rec, rm.rec2))
+    load_entry()
     # phi half (odd steps): x -> beta x
     A("s_and_b32 %s, %s, 1" % (S_TMP, S_STEP))
     A("s_cmp_eq_u32 %s, 0" % S_TMP)
@@ -676,6 +688,7 @@ def emit_loop():
     A("s_add_u32 %s, %s, 1" % (S_STEP, S_STEP))
     A("s_cmp_lt_u32 %s, %d" % (S_STEP, N_STEPS))
     A("s_cbranch_scc1 " + lbl("L_step"))
+    A("s_waitcnt vmcnt(0)")                                                   # the last prefetch is not used
     # epilogue: back to R = 2^256 (one multiplication by the plain integer 2^256 mod q), packed lazy words; flag = (Z == 0 mod q)
     c256 = const_to(A, R32 % Q)
     Bo = Bld(rm)
@@ -710,7 +723,7 @@ def emit_table():
     products and no inversion.  Scratch (jtab) entry e = (X_e, Y_e, g_e), 27 words in eight 16-byte chunks, chunk-major: chunk k of entry e
     of lane t sits at ((8 e + k) n + t) 16, so every load / store instruction of a wave covers one contiguous kilobyte."""
     rm = RegMap(table_kernel=True)
-    assert rm.end <= 128, "the table kernel must stay at four waves per SIMD"
+    assert rm.end <= 168
     L = []
     A = L.append
     ld, st = mem_ops(A)
@@ -778,17 +791,17 @@ def emit_table():
     sched(Bc.seq)
     A("v_mov_b32_e32 %s, %s" % (rm.off, tid16))
     jt_io("st", rm.off, [XY1])
+    for d, s_ in zip(rm.SY + rm.SZ, XY1):                                    # (x, y) of P stay in registers for the 14 additions
+        A("v_mov_b32_e32 %s, %s" % (d, s_))
     Ed = sched(seq_double(rm).seq)                                           # T_1 = 2 P; g_1 = Z3 = 2 Y
     A("s_mov_b32 %s, 1" % S_E)
     jt_off(rm.off, S_E)
     jt_io("st", rm.off, [XY1, rm.Z1])
-    # ---- T_e = T_{e-1} + P, e = 2 .. 15; (x, y) of P come back from entry 0 every time (L2-resident); g_e = 2 H
+    # ---- T_e = T_{e-1} + P, e = 2 .. 15; g_e = 2 H.  No waits in this loop: the stores drain while the next addition runs.
     A("s_mov_b32 %s, 2" % S_E)
     A(lbl("T_build") + ":")
-    A("s_waitcnt vmcnt(0)")
-    A("v_mov_b32_e32 %s, %s" % (rm.off, tid16))
-    jt_io("ld", rm.off, [XY2])
-    A("s_waitcnt vmcnt(0)")
+    for d, s_ in zip(XY2, rm.SY + rm.SZ):
+        A("v_mov_b32_e32 %s, %s" % (d, s_))
     Ba = seq_madd(rm, h2_out=rm.SX)
     Ea = sched(Ba.seq)
     g_bounds = Ba.h2
@@ -798,27 +811,48 @@ def emit_table():
     A("s_cmp_lt_u32 %s, 16" % S_E)
     A("s_cbranch_scc1 " + lbl("T_build"))
     A("s_waitcnt vmcnt(0)")
-    # ---- backward: c = g_{e+1} ... g_15 (c = 1 for e = 15); x' = X c^2, y' = Y c^3; packed stores; then c *= g_e
+    # ---- backward: c = g_{e+1} ... g_15 (c = 1 for e = 15); x' = X c^2, y' = Y c^3; packed stores; then c *= g_e.
+    # Two entry buffers, the loop unrolled by two: entry e - 1 is requested before entry e is used, and the wait is COUNTED (vmcnt(8): the eight
+    # loads just issued may stay in flight; everything older -- this entry's loads, the previous stores -- has returned: VMEM returns in order).
+    bufs = [(rm.X2, rm.Y2, rm.SX), (rm.X1, rm.Y1, rm.SY)]
+    m2 = lambda r: fv_mulout(r, 4 * Q * Q)
+    gz = fv_z(rm.SX)
+
+    def half(cur, nxt, may_be_last):
+        Xc, Yc, Gc = cur
+        if may_be_last:
+            A("s_cmp_eq_u32 %s, 0" % S_E)
+            A("s_cbranch_scc1 " + lbl("T_last"))
+        A("s_sub_u32 %s, %s, 1" % (S_IDX, S_E))
+        jt_off(rm.off, S_IDX)
+        jt_io("ld", rm.off, [nxt[0] + nxt[1], nxt[2]])
+        A("s_waitcnt vmcnt(8)")
+        if may_be_last:
+            A("s_branch " + lbl("T_go"))
+            A(lbl("T_last") + ":")
+            A("s_waitcnt vmcnt(0)")
+            A(lbl("T_go") + ":")
+        Bk = Bld(rm)
+        c = m2(rm.T0)
+        c2 = Bk.mul([(c, c)], rm.T1)                                           # c^2
+        Bk.mul([(fv_acc(Xc), c2)], Xc)                                         # x'
+        c3 = Bk.mul([(c2, c)], rm.T1)                                          # c^3
+        Bk.mul([(fv_acc(Yc), c3)], Yc)                                         # y'
+        g = FV(Gc, max(g_bounds.lmax, gz.lmax), max(g_bounds.tmax, gz.tmax), max(g_bounds.vmax, gz.vmax))     # 2 H of an addition, or Z3 of the doubling (entry 1)
+        Bk.mul([(c, g)], rm.T0)                                                # c *= g_e  (entry 0 has no g: the product is not used)
+        Bk.seq += seq_pack(Xc, rm.T1[:8]) + seq_pack(Yc, rm.T2[:8])
+        sched(Bk.seq)
+        entry_off(rm.off, S_E, S_N64, rm.tid64)
+        st(rm.T1[:8], rm.off, "tab", 0); st(rm.T2[:8], rm.off, "tab", 32)
+
     mov_const(rm.T0, one)
     A("s_mov_b32 %s, 15" % S_E)
-    A(lbl("T_back") + ":")
     jt_off(rm.off, S_E)
-    jt_io("ld", rm.off, [XY2, rm.SX])
-    A("s_waitcnt vmcnt(0)")
-    Bk = Bld(rm)
-    m2 = lambda r: fv_mulout(r, 4 * Q * Q)
-    c = m2(rm.T0)
-    c2 = Bk.mul([(c, c)], rm.T1)                                               # c^2
-    Bk.mul([(fv_acc(rm.X2), c2)], rm.X2)                                       # x'
-    c3 = Bk.mul([(c2, c)], rm.T1)                                              # c^3
-    Bk.mul([(fv_acc(rm.Y2), c3)], rm.Y2)                                       # y'
-    gz = fv_z(rm.SX)
-    g = FV(rm.SX, max(g_bounds.lmax, gz.lmax), max(g_bounds.tmax, gz.tmax), max(g_bounds.vmax, gz.vmax))     # 2 H of an addition, or Z3 of the doubling (entry 1)
-    Bk.mul([(c, g)], rm.T0)                                                    # c *= g_e  (entry 0's g is never stored: the product is not used)
-    Bk.seq += seq_pack(rm.X2, rm.T1[:8]) + seq_pack(rm.Y2, rm.T2[:8])
-    sched(Bk.seq)
-    entry_off(rm.off, S_E, S_N64, rm.tid64)
-    st(rm.T1[:8], rm.off, "tab", 0); st(rm.T2[:8], rm.off, "tab", 32)
+    jt_io("ld", rm.off, [bufs[0][0] + bufs[0][1], bufs[0][2]])
+    A(lbl("T_back") + ":")
+    half(bufs[0], bufs[1], False)                                              # e odd: e - 1 exists
+    A("s_sub_u32 %s, %s, 1" % (S_E, S_E))
+    half(bufs[1], bufs[0], True)                                               # e even: the last one is e = 0
     A("s_cmp_eq_u32 %s, 0" % S_E)
     A("s_cbranch_scc1 " + lbl("T_back_done"))
     A("s_sub_u32 %s, %s, 1" % (S_E, S_E))
