@@ -11,6 +11,7 @@
 #include "arkmpc_internal.hpp"
 #include "fp_asm.hpp"
 #include <cstdlib>
+#include <cstring>
 
 #define TPB_ED 128
 constexpr int EQ = F_CURVE25519_FQ;
@@ -127,6 +128,11 @@ __device__ __forceinline__ Ed ed_scalar_mul_plain(const Ed& p, const Fe& s_mont)
 //   finish  values below 2^255 -> canonical, stored as ark-ec's (x, y, t, z)
 // ---------------------------------------------------------------------------------------------
 #include "ed_asm_kernels.inc"
+#include "ed29_asm_kernels.inc"     // the same three streams on nine 29-bit limbs (tools/gen_ed29_asm.py): the default; ARKMPC_ED_LIMBS=32 selects the ones above
+static bool ed_limbs29() {
+    static const bool on = !(getenv("ARKMPC_ED_LIMBS") && !strcmp(getenv("ARKMPC_ED_LIMBS"), "32"));
+    return on;
+}
 #define TPB_EDLOOP 256
 #define ED_ASM_WS_BYTES (ED_ASM_TABLE * 128 + ED_ASM_WINDOWS * 4 + 128)
 struct EdAsmWs { u64* tab; u64* res; u32* dig; };
@@ -170,6 +176,16 @@ __global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_table(u32 n, const u64* 
     const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
     if (i >= n) return;
     ed_smul_table_asm(i, p_stride * 8u * (i / p_div), n, points, tab);
+}
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_table29(u32 n, const u64* points, u32 p_stride, u32 p_div, u64* tab) {
+    const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
+    if (i >= n) return;
+    ed_smul_table29_asm(i, p_stride * 8u * (i / p_div), n, points, tab);
+}
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_smul_loop29(u32 n, u32 tdiv, const u64* tab, const u32* dig, u64* res) {
+    const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
+    if (i >= n) return;
+    ed_smul_loop29_asm(i, n, i / tdiv, n / tdiv, tab, dig, res);
 }
 // compiled form of both (generator base, ARKMPC_ED_ASM_PREP=0)
 __global__ void __launch_bounds__(TPB_ED) k_ed_smul_prep(u32 n, const u64* points, u32 p_stride, u32 p_div, const u64* scalars, u32 s_stride, u32 s_div,
@@ -559,6 +575,11 @@ __global__ void __launch_bounds__(TPB_EDLOOP) k_ed_gen_chain(u32 n, const u32* d
     if (i >= n) return;
     ed_gen_chain_asm(i, n, dig, table, res);
 }
+__global__ void __launch_bounds__(TPB_EDLOOP) k_ed_gen_chain29(u32 n, const u32* dig, const u64* table, u64* res) {
+    const u32 i = blockIdx.x * TPB_EDLOOP + threadIdx.x;
+    if (i >= n) return;
+    ed_gen_chain29_asm(i, n, dig, table, res);
+}
 static u64* g_ed_gen2_table[16] = {nullptr};
 static std::mutex g_ed_gen_mu;
 static u64* g_ed_gen_table[16] = {nullptr};
@@ -625,11 +646,14 @@ static void ed_smul_launch(arkmpc_ctx* ctx, size_t m, const u64* points, u32 p_s
             hipLaunchKernelGGL(k_ed_smul_digits, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, (u32)cnt, sp, s_stride, s_div, ws.dig);
             if (p_div > 1 && cnt % p_div == 0) tdiv = p_div;          // p_div lanes multiply the same point: one table column serves them
             const u32 ncol = (u32)(cnt / tdiv);
-            hipLaunchKernelGGL(k_ed_smul_table, dim3(blocks_for(ncol, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.tab);
+            if (ed_limbs29()) hipLaunchKernelGGL(k_ed_smul_table29, dim3(blocks_for(ncol, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.tab);
+            else hipLaunchKernelGGL(k_ed_smul_table, dim3(blocks_for(ncol, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, ncol, pp, p_stride, p_div / tdiv, ws.tab);
         } else {
             hipLaunchKernelGGL(k_ed_smul_prep, dim3(blocks_for(cnt, TPB_ED)), dim3(TPB_ED), 0, ctx->stream, (u32)cnt, pp, p_stride, p_div, sp, s_stride, s_div, ws);
         }
-        hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res);
+        // both loops read the same table format (8 x 32-bit words per coordinate, any value below 2^256), whichever kernel built it
+        if (ed_limbs29()) hipLaunchKernelGGL(k_ed_smul_loop29, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res);
+        else hipLaunchKernelGGL(k_ed_smul_loop, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, tdiv, ws.tab, ws.dig, ws.res);
         hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, ws.res, out + 16 * lo);
     }
 }
@@ -747,7 +771,8 @@ static int ed_smul_impl(arkmpc_ctx* ctx, size_t m, const uint64_t* points, size_
                 const size_t cnt = (m - lo < chunk) ? (m - lo) : chunk;
                 const u64* sp = st.in<u64>(is) + (size_t)s_stride * (lo / s_div);
                 hipLaunchKernelGGL(k_ed_gen_digits, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, (u32)cnt, sp, s_stride, s_div, st.scratch<u32>(igd));
-                hipLaunchKernelGGL(k_ed_gen_chain, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, st.scratch<u32>(igd), t2, st.scratch<u64>(igr));
+                if (ed_limbs29()) hipLaunchKernelGGL(k_ed_gen_chain29, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, st.scratch<u32>(igd), t2, st.scratch<u64>(igr));
+                else hipLaunchKernelGGL(k_ed_gen_chain, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, st.scratch<u32>(igd), t2, st.scratch<u64>(igr));
                 hipLaunchKernelGGL(k_ed_smul_finish, dim3(blocks_for(cnt, TPB_EDLOOP)), dim3(TPB_EDLOOP), 0, ctx->stream, (u32)cnt, st.scratch<u64>(igr), st.out<u64>(io) + 16 * lo);
             }
             return st.finish();

@@ -256,3 +256,26 @@ def test_committed_ed_header_is_current(tmp_path):
     out = tmp_path / "ed_asm_kernels.inc"
     ed.emit_header(str(out))
     assert out.read_text() == open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ed_asm_kernels.inc")).read(), "regenerate with: python tools/gen_ed_asm.py"
+
+
+# ---- round 3: the Curve25519 streams on nine 29-bit limbs (tools/gen_ed29_asm.py -> csrc/ed29_asm_kernels.inc) ---------------------------
+import gen_ed29_asm as ed29  # noqa: E402
+
+
+def test_ed29_bodies_match_the_affine_edwards_law():
+    """Doubling (with / without T), cached addition, Niels addition on unsaturated limbs in plain arithmetic mod 2^255 - 19, scheduled as emitted,
+    against the affine law (identity, P + P, P + (-P) included: the law is complete); the cached form, the packing (every stored word string
+    below 2^256) and the in-place unpacking round-trip."""
+    r = ed29.selftest(trials=36, seed=20260929)
+    assert len(r[False][0].order) < 1000 and len(r[False][1].order) < 1100
+
+
+def test_ed29_every_multiplication_at_its_operand_bounds():
+    assert ed29.selftest_extremes() >= 10
+
+
+def test_committed_ed29_header_is_current(tmp_path):
+    out = tmp_path / "ed29_asm_kernels.inc"
+    ed29.emit_header(str(out))
+    committed = open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ed29_asm_kernels.inc")).read()
+    assert out.read_text() == committed, "regenerate with: python tools/gen_ed29_asm.py"

@@ -363,3 +363,44 @@ def test_unsaturated_field_arithmetic_at_the_edges(pkg):
         want = [x * y % q, (x + y) % q, (x - y) % q, (x - y) * (x + y) % q, pow(x, q - 2, q)]
         assert list(got[i]) == want, (hex(x), hex(y))
     e.close()
+
+
+def test_both_limb_forms_of_the_edwards_kernels_agree_with_the_oracle():
+    """The 32-bit-limb window loop / table / fixed-base chain stay selectable (ARKMPC_ED_LIMBS=32; default: nine 29-bit limbs).  The same batch --
+    identity, small and extreme scalars, random lanes, an EdPointShare x Scalar batch, generator multiples at the digit edges -- must equal the
+    oracle in both forms, and the canonical affine outputs must be the same bytes."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import importlib, sys, os, hashlib
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, pyref, oracle_api
+        from helpers import mont_array, rand_values
+        import test_gpu_edwards as T
+        pkg = importlib.import_module("ark-mpc_amd"); eng = pkg.Engine("curve25519_fr", device=0, host_buffers=True); ora = oracle_api.load()
+        n = 200
+        pts, P = T.rand_points(n, 31)
+        ks = [0, 1, 2, pyref.EL - 1, 15, 16, 17, 31, 32, 33, (1 << 252), pyref.EL - 2] + rand_values(2, n - 12, 32)
+        S = mont_array(2, ks)
+        o = np.zeros(16 * n, dtype=np.uint64); eng.ed_scalar_mul(n, P, S, o)
+        ok1 = T.aff_equal(eng, ora, o, ora.ed_batch_scalar_mul(P, S))
+        o2 = np.zeros(16 * n, dtype=np.uint64); eng.edshare_mul_public(n // 2, P, S[:4 * (n // 2)], o2)
+        ok2 = T.aff_equal(eng, ora, o2, ora.ed_batch_scalar_mul(P, S[:4 * (n // 2)], n=n, s_div=2))
+        edge = [0, 1, 1023, 1024, 1025, 2047, 2048, 2049, (1 << 11) - 1, (1 << 22) + 1024, pyref.EL - 1] + rand_values(2, 53, 33)
+        SG = mont_array(2, edge); o3 = np.zeros(16 * len(edge), dtype=np.uint64); eng.ed_generator_mul(len(edge), SG, o3)
+        ok3 = T.aff_equal(eng, ora, o3, ora.ed_batch_scalar_mul(T.ext([pyref.ED_B] * len(edge), [1] * len(edge)), SG))
+        h = hashlib.sha256()
+        for arr in (o, o2, o3):
+            xa = np.zeros(len(arr) // 2, dtype=np.uint64); eng.ed_to_affine(len(arr) // 16, arr, xa); h.update(xa.tobytes())
+        print(int(ok1), int(ok2), int(ok3), h.hexdigest())
+    """ % (root, root))
+    outs = {}
+    for limbs in ("29", "32"):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, ARKMPC_ED_LIMBS=limbs), timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[limbs] = r.stdout.strip().splitlines()[-1].split()
+        assert outs[limbs][:3] == ["1", "1", "1"], (limbs, outs[limbs])
+    assert outs["29"][3] == outs["32"][3]
