@@ -381,8 +381,13 @@ MADS_PER_FQ_MUL = 136           # 64 product + 64 reduction v_mad_u64_u32 + 8 v_
 FQ_MULS_PER_SMUL_R01 = 27 * (5 * 7 + 2 * 16 + 1) + 8 * 7 + 7 * 16
 
 
+def ec_limbs():
+    return 32 if os.environ.get("ARKMPC_EC_LIMBS") == "32" else 29
+
+
 def ec_mult_instrs():
-    st = json.load(open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec_asm_stats.json")))
+    """the shipped kernels compute on nine 29-bit limbs (tools/gen_ec29_asm.py); ARKMPC_EC_LIMBS=32 selects the round-2 32-bit-limb ones"""
+    st = json.load(open(os.path.join(ROOT, "ark-mpc_amd", "csrc", "ec29_asm_stats.json" if ec_limbs() == 29 else "ec_asm_stats.json")))
     return st["mult_instrs_loop"] + st["mult_instrs_table"], st
 
 
@@ -423,13 +428,18 @@ def leg_config4(eng):
     return {"workload": "2^18 PointShare x Scalar over BN254 G1 = 2^19 scalar-muls (BASELINE.json configs[3])", "ms": ms,
             "secondary_op": config4_secondary(),
             "scalar_muls_per_s": smuls, "bound": "integer ALU",
-            "algorithm": "GLV + signed 5-bit windows; effective-affine window table (common Z), blinded accumulator, mixed additions, "
-                         "squaring rows; digits / table / window loop / finish kernels, table + loop hand-scheduled (tools/gen_ec_asm.py)",
+            "algorithm": "GLV + signed 5-bit windows; effective-affine window table (common Z), blinded accumulator, mixed additions; digits / table / "
+                         "window loop / finish kernels, table + loop hand-scheduled on %s" % (
+                             "nine unsaturated 29-bit limbs, product-scanning Montgomery multiplier with one 64-bit column accumulator (tools/gen_ec29_asm.py)"
+                             if ec_limbs() == 29 else "eight 32-bit limbs, CIOS rows (tools/gen_ec_asm.py)"),
+            "limbs": ec_limbs(),
             "mult_instrs_per_scalar_mul": per_smul, "mult_instrs_per_s": smuls * per_smul,
             "frac_of_int_alu_peak": smuls * per_smul / MAD_PEAK_PER_S,
             "int_alu_peak_note": "v_mad_u64_u32 + v_mul_lo_u32 instructions executed per second / 31.2e12 measured chip-wide v_mad_u64_u32 lane-ops/s",
-            "ceiling_note": "a bare chain of the hand-scheduled Montgomery block reaches 0.61 of this peak (probes/mulrate.hip, profiles/r02/mulrate.jsonl): "
-                            "162 of its 298 instructions are carries and moves",
+            "ceiling_note": ("PMC (profiles/r03_ec/pmc_limbs29.txt): 4.08 SIMD cycles per VALU instruction in loop and table -- the issue limit; "
+                             "70 % of the instructions are multiplier instructions") if ec_limbs() == 29 else
+                            ("a bare chain of the hand-scheduled Montgomery block reaches 0.61 of this peak (probes/mulrate.hip, profiles/r02/mulrate.jsonl): "
+                             "162 of its 298 instructions are carries and moves"),
             "r01_accounting": {"fq_muls_per_scalar_mul": FQ_MULS_PER_SMUL_R01, "fq_muls_per_s": smuls * FQ_MULS_PER_SMUL_R01,
                                "frac_of_mad_only_peak": smuls * FQ_MULS_PER_SMUL_R01 * MADS_PER_FQ_MUL / MAD_PEAK_PER_S,
                                "note": "round 1's work definition (2004 general multiplications per scalar-mul) at this round's speed"},
