@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Soak of the hand-scheduled point kernels against the compiled ones: the same seeded random inputs are pushed through
 PointShare x Scalar (BN254 G1 and Curve25519), the variable-base MSM and its authenticated form in two child processes --
-one with the asm kernels (default), one with ARKMPC_EC_ASM=0 ARKMPC_ED_ASM=0 ARKMPC_MSM_ASM=0 -- and the SHA-256 digests of
-the AFFINE outputs must agree, seed by seed.  (Jacobian / extended representatives legitimately differ between the paths.)
+the hand-scheduled kernels on 29-bit limbs (default), the same on 32-bit limbs (ARKMPC_EC_LIMBS=32 ARKMPC_ED_LIMBS=32), and the compiled
+kernels (ARKMPC_EC_ASM=0 ARKMPC_ED_ASM=0 ARKMPC_MSM_ASM=0) -- and the SHA-256 digests of the AFFINE outputs (the fixed-base generator
+multiples that serve as inputs included) must agree, seed by seed.  (Jacobian / extended representatives legitimately differ between the paths.)
 usage: python tools/soak_ec.py [seeds] [log2n]"""
 import hashlib, importlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -23,6 +24,12 @@ def child(seeds, lg):
             pw = 12 if name == "bn254" else 16
             shares = torch.empty(2 * pw * n, dtype=torch.int64, device="cuda")
             (e.scalarshare_mul_generator if name == "bn254" else e.scalarshare_mul_ed_generator)(n, rnd(2 * n), shares)
+            gxy = torch.empty(8 * 2 * n, dtype=torch.int64, device="cuda")
+            if name == "bn254":
+                ginf = torch.empty(2 * n, dtype=torch.uint8, device="cuda"); e.g1_to_affine(2 * n, shares, gxy, ginf)
+            else:
+                e.ed_to_affine(2 * n, shares, gxy)
+            res["%s/genmul/%d" % (name, seed)] = hashlib.sha256(gxy.cpu().numpy().tobytes()).hexdigest()
             sc = rnd(n)
             sc.view(n, 4)[: 8] = 0                                   # a few zero scalars
             out = torch.empty_like(shares)
@@ -55,14 +62,15 @@ if __name__ == "__main__":
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     lg = int(sys.argv[2]) if len(sys.argv) > 2 else 17
     runs = {}
-    for tag, env in (("asm", {}), ("compiled", {"ARKMPC_EC_ASM": "0", "ARKMPC_ED_ASM": "0", "ARKMPC_MSM_ASM": "0"})):
+    for tag, env in (("asm", {}), ("asm32", {"ARKMPC_EC_LIMBS": "32", "ARKMPC_ED_LIMBS": "32"}),
+                     ("compiled", {"ARKMPC_EC_ASM": "0", "ARKMPC_ED_ASM": "0", "ARKMPC_MSM_ASM": "0"})):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(seeds), str(lg)], capture_output=True, text=True,
                            env=dict(os.environ, **env), timeout=3000)
         if r.returncode != 0:
             print(r.stderr[-2000:]); sys.exit(2)
         runs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
-    bad = [k for k in runs["asm"] if runs["asm"][k] != runs["compiled"][k]]
-    print("soak_ec: %d cases (%d seeds, 2^%d PointShares per case), %d differing between the hand-scheduled and the compiled kernels"
+    bad = [k for k in runs["asm"] if not (runs["asm"][k] == runs["compiled"][k] == runs["asm32"][k])]
+    print("soak_ec: %d cases (%d seeds, 2^%d PointShares per case), %d differing between the hand-scheduled kernels (29-bit limbs, 32-bit limbs) and the compiled ones"
           % (len(runs["asm"]), seeds, lg, len(bad)))
     for k in bad: print("  DIFFERS:", k)
     sys.exit(1 if bad else 0)
