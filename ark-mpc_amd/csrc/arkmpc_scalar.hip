@@ -237,8 +237,11 @@ __global__ void __launch_bounds__(TPB) k_share_extract(size_t n, const u64* a, u
 // K1: d_i = x_i.share - a_i.share ; e_i = y_i.share - b_i.share ; out = d || e  (:863-868, :141-145).
 // The MAC halves of d and e are dead in the reference (only `.share()` is sent), so they are not computed.
 template <int F, int NT>   // NT bit0: x,y non-temporal ; bit1: a,b non-temporal ; bit2: d||e stores non-temporal
-__global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col a, Col b, u64* out_d, u64* out_e, u64* dup_d, u64* dup_e) {
-    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+__global__ void __launch_bounds__(TPB) k_beaver_mask(size_t n, Col x, Col y, Col a, Col b, u64* out_d, u64* out_e, u64* dup_d, u64* dup_e, u32 xcd_blocks) {
+    // xcd_blocks != 0 (a multiple of 8 = the grid size): workgroup b, which the dispatcher hands to XCD b % 8, takes the (b / 8)-th block of that
+    // XCD's contiguous eighth of the batch instead of block b (experiment: ARKMPC_K1_XCD=1)
+    const u32 blk = xcd_blocks ? (blockIdx.x & 7u) * (xcd_blocks >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    size_t i = (size_t)blk * TPB + threadIdx.x;
     if (i >= n) return;
     Fe xs = (NT & 1) ? fe_load_nt(x.p + (size_t)x.stride * i) : fe_load(x.p + (size_t)x.stride * i);
     Fe as = (NT & 2) ? fe_load_nt(a.p + (size_t)a.stride * i) : fe_load(a.p + (size_t)a.stride * i);
@@ -454,14 +457,16 @@ static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u
     dim3 g(blocks_for(n, TPB)), t(TPB);
     const bool split = x.stride == 4 && y.stride == 4 && a.stride == 4 && b.stride == 4;
     static const int aos_mode = getenv("ARKMPC_K1_NT_AOS") ? atoi(getenv("ARKMPC_K1_NT_AOS")) & 7 : 0;
+    static const bool xcd_map = getenv("ARKMPC_K1_XCD") && getenv("ARKMPC_K1_XCD")[0] == '1';
+    const u32 xcd = (xcd_map && g.x % 8 == 0 && n % TPB == 0) ? g.x : 0u;
     switch (split ? k1_nt_mode() : aos_mode) {
-        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
-        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
-        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
-        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
-        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
-        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
-        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out, out_e, dup, dup_e); break;
+        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
     }
 }
 
