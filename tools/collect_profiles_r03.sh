@@ -9,5 +9,5 @@ cp $S/trace_default/trace_kernel_stats.csv profiles/r03/trace_default_kernel_sta
 cp $S/trace_split/trace_kernel_stats.csv profiles/r03/trace_split_kernel_stats.csv
 cp $S/traffic_split.json profiles/traffic_split.json
 cp $S/host_latency.jsonl $S/host_mode.jsonl $S/kernel_suite.txt profiles/r03_host/
-cp $S/ec_bench.json profiles/r03_ec/    # ed_bench / msm_bench: re-run after the MSM work, copied from gpurun_out/*_final.jsonl
+cp $S/ec_bench.json $S/ed_bench.jsonl $S/msm_bench.jsonl profiles/r03_ec/
 ls -la profiles/r03 profiles/r03_host profiles/r03_ec

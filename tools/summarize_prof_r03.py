@@ -144,13 +144,16 @@ if os.path.exists(sp):
         except Exception as ex:
             print("  unparsable line: %r" % ex)
 
-print("== VALU occupancy of the hand-scheduled kernels (per launch; SQ_INSTS_VALU wave-instructions, GRBM_GUI_ACTIVE summed over the 8 XCDs)")
-print("   cycle model from profiles/ubench_r01.log: v_mad_u64_u32 31.2e12 lane-ops/s chip-wide = 5.04 cycles per wave64 instruction on one of the 1024 SIMDs at 2.4 GHz, other VALU 1.8x faster = 2.8 cycles")
+print("== VALU issue rate of the hand-scheduled kernels (per launch; SQ_INSTS_VALU wave-instructions, GRBM_GUI_ACTIVE summed over the 8 XCDs)")
+print("   SIMD cycles per VALU instruction = 1024 SIMDs x busy cycles per XCD / (waves x VALU per wave).  A wave64 instruction occupies a SIMD16 for 4 cycles: 4.0 is the issue limit,")
+print("   whatever the instruction (the round-1 cost model, 5.04 cycles per v_mad_u64_u32 and 2.8 per other VALU instruction, over-predicts these streams and is superseded);")
+print("   a denser multiplier mix shows up as a LOWER CLOCK (busy cycles / wall time), not as more cycles per instruction")
 import json as _json
-try:
-    st = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ark-mpc_amd", "csrc", "ec_asm_stats.json")))
-except Exception:
-    st = {}
+def _stats(name):
+    try:
+        return _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ark-mpc_amd", "csrc", name)))
+    except Exception:
+        return {}
 for sub, tags in (("pmc_ec", ("k_g1_smul_loop", "k_g1_smul_table")), ("pmc_k3", ("k_beaver_finish_asm", "k_beaver_mask"))):
     cs = {n: counter(sub, n) for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_INST_ANY")}
     for tag in tags:
@@ -158,14 +161,13 @@ for sub, tags in (("pmc_ec", ("k_g1_smul_loop", "k_g1_smul_table")), ("pmc_k3", 
         if not ks:
             continue
         k = ks[0]
+        name = k.split("(")[0]
+        st = _stats("ec29_asm_stats.json" if name.endswith("29") else "ec_asm_stats.json")
         w, valu, gui = cs["SQ_WAVES"][k], cs["SQ_INSTS_VALU"][k], cs["GRBM_GUI_ACTIVE"][k]
         per_wave = valu / max(w, 1)
-        mult = {"k_g1_smul_loop": st.get("mult_instrs_loop"), "k_g1_smul_table": st.get("mult_instrs_table"), "k_beaver_finish_asm": 576 * 64, "k_beaver_mask": 0}.get(tag)
-        line = "  %-24s waves %6d  VALU/wave %9.0f  GUI_ACTIVE/XCD %11.0f  SQ_ACTIVE_INST_VALU %s  SQ_BUSY_CYCLES %s" % (
-            tag, w, per_wave, gui / 8, cs["SQ_ACTIVE_INST_VALU"].get(k), cs["SQ_BUSY_CYCLES"].get(k))
-        if mult is not None:
-            mult_per_wave = mult if tag.startswith("k_g1") else (576 if tag == "k_beaver_finish_asm" else 0)      # a wave instruction serves its 64 lanes: per-lane count = per-wave count
-            need = w * (mult_per_wave * 5.04 + (per_wave - mult_per_wave) * 2.8)
-            avail = 1024 * gui / 8
-            line += "  | multiplier instrs/wave %d  modelled VALU cycles / available SIMD cycles = %.2f" % (mult_per_wave, need / max(avail, 1))
+        mult = {"k_g1_smul_loop": st.get("mult_instrs_loop"), "k_g1_smul_table": st.get("mult_instrs_table"), "k_beaver_finish_asm": 576, "k_beaver_mask": 0}.get(tag)
+        line = "  %-24s waves %6d  VALU/wave %9.0f  busy cycles/XCD %11.0f  SIMD cycles per VALU instruction %.2f" % (
+            name, w, per_wave, gui / 8, 1024 * (gui / 8) / max(w * per_wave, 1))
+        if mult:
+            line += "  | multiplier instructions/wave %d = %.2f of the stream" % (mult, mult / per_wave)
         print(line)
