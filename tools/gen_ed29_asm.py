@@ -33,8 +33,7 @@ import gen_ec_asm as EC
 import gen_ec29_asm as E29
 import gen_ed_asm as ED
 from gen_asm_kernels import Ins, Emitter, M32, regs_of
-from gen_ec29_asm import (FV, NL, M29, limbs29, val29, i_mad, i_and, i_shr64, i_mov, i_add, i_sub, i_shl, i_lshr, i_lshl_add, i_cnd, seq_unpack, seq_pack, vrange,
-                          mem_ops)
+from gen_ec29_asm import FV, NL, M29, limbs29, val29, i_mad, i_and, i_shr64, i_mov, i_add, i_sub, i_shl, i_lshr, i_cnd, seq_unpack, seq_pack, mem_ops
 
 Q = ED.Q
 D_ED = ED.D_ED
