@@ -271,7 +271,13 @@ def test_ed29_bodies_match_the_affine_edwards_law():
 
 
 def test_ed29_every_multiplication_at_its_operand_bounds():
-    assert ed29.selftest_extremes() >= 10
+    assert ed29.selftest_extremes() >= 14
+
+
+def test_ed29_msm_member_path():
+    """The MSM fold's per-member work on the emulator: affine (x, y) -> Niels form on the fly, negative-digit and past-the-end selection (the
+    identity's Niels form), Niels addition -- against the affine law, identity / same point / opposite point as members included."""
+    assert ed29.selftest_member(trials=36, seed=5)
 
 
 def test_committed_ed29_header_is_current(tmp_path):

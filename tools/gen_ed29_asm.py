@@ -230,12 +230,14 @@ def entry_fvs(rm, qt=None):
     return n(rm.QP), n(rm.QM), qt or n(rm.QT), n(rm.QZ)
 
 
-def seq_add(rm, with_t, B=None, qt=None, niels=False):
+def seq_add(rm, with_t, B=None, qt=None, niels=False, qpm=None):
     """add-2008-hwcd-3 (a = -1) with a cached second operand (Y2+X2, Y2-X2, 2d T2, 2 Z2) in QP, QM, QT, QZ; niels: the operand is affine
     (Z2 = 1: D = 2 Z1 is a limb shift).  Complete on this curve.  qt: bounds of the 2dT operand (the loop negates it conditionally)."""
     B = B or Bld(rm)
     X, Y, Z, T = acc_fvs(rm)
     QP, QM, QT, QZ = entry_fvs(rm, qt)
+    if qpm is not None:                                     # (y + x, y - x) formed in registers (the MSM fold): wider bounds than unpacked words
+        QP, QM = FV(rm.QP, qpm.lmax, qpm.tmax, qpm.vmax), FV(rm.QM, qpm.lmax, qpm.tmax, qpm.vmax)
     s1 = B.sub(Y, X, rm.A)
     s2 = B.add(Y, X, rm.Bv)
     PA = B.mul(s1, QM, rm.Cv)
@@ -425,6 +427,11 @@ def selftest_extremes():
     Bn = Bld(rm)
     qn = Bn.neg(FV(rm.QT, M29, (1 << 24) - 1, (1 << 256) - 1), rm.A)
     sigs |= set(seq_add(rm, True, qt=FV(rm.QT, qn.lmax, qn.tmax, qn.vmax)).sigs)
+    d2v = 2 * D_ED % Q
+    l2 = limbs29(d2v)
+    Bm, qp, qt_in = seq_member(rm, FV(S_C, max(l2[:8]), l2[8], d2v))
+    _, qt = seq_member_select(rm, qt_in, "s[44:45]")
+    sigs |= set(Bm.sigs) | set(seq_add(rm, True, qt=qt, niels=True, qpm=qp).sigs)
     for (al, at, bl, bt, sq) in sorted(sigs):
         B = Bld(rm)
         la, lb = [al] * 8 + [at], [bl] * 8 + [bt]
@@ -655,8 +662,135 @@ def emit_gen_chain():
     return L, rm, dict(add=len(Ea.order), chain_mults=GEN_WINDOWS * mult, vgpr_end=rm.end)
 
 
+def seq_member(rm, d2, unpack=False):
+    """a plain affine member (x, y) -- eight words each in ST / LD when `unpack`, else nine limbs in A / Bv -- to its Niels form
+    (QP, QM, QT) = (y + x, y - x, 2d x y); QP and QM both normalised (a negative digit swaps them).  Returns (builder, bounds of QP / QM, bounds of QT)."""
+    B = Bld(rm)
+    if unpack:
+        B.seq += seq_unpack(rm.ST, rm.A) + seq_unpack(rm.LD, rm.Bv)
+    n = lambda r: FV(r, M29, (1 << 24) - 1, (1 << 256) - 1)
+    x, y = n(rm.A), n(rm.Bv)
+    qp_ = B.norm(B.add(y, x, rm.QP))
+    qm_ = B.norm(B.sub(y, x, rm.QM))
+    xy = B.mul(x, y, rm.Cv)
+    qt = B.mul(xy, d2, rm.QT)
+    return B, FV(rm.QP, max(qp_.lmax, qm_.lmax), max(qp_.tmax, qm_.tmax), max(qp_.vmax, qm_.vmax)), qt
+
+
+def seq_member_select(rm, qt_in, S_NZ):
+    """negative digit (mask S_NEG): (QP, QM, QT) -> (QM, QP, K - QT); lane past the end of its task (mask S_NZ clear): the identity (1, 1, 0)"""
+    B = Bld(rm)
+    qn = B.neg(qt_in, rm.A)
+    B.seq += [i_mov(rm.Bv[j], rm.QP[j]) for j in range(NL)]
+    B.seq += [i_cnd(rm.QP[j], rm.QP[j], rm.QM[j], S_NEG) for j in range(NL)]
+    B.seq += [i_cnd(rm.QM[j], rm.QM[j], rm.Bv[j], S_NEG) for j in range(NL)]
+    B.seq += [i_cnd(rm.QT[j], rm.QT[j], rm.A[j], S_NEG) for j in range(NL)]
+    for q_, one in ((rm.QP, 1), (rm.QM, 1), (rm.QT, 0)):
+        B.seq += [i_cnd(q_[j], one if j == 0 else 0, q_[j], S_NZ) for j in range(NL)]
+    return B, FV(rm.QT, max(qt_in.lmax, qn.lmax), max(qt_in.tmax, qn.tmax), max(qt_in.vmax, qn.vmax))
+
+
+def selftest_member(trials=24, seed=17):
+    """the MSM fold's member path on the emulator: (x, y) -> Niels form, sign / past-the-end selection, Niels addition, against the affine law"""
+    rng = random.Random(seed)
+    rm = RegMap()
+    d2v = 2 * D_ED % Q
+    l2 = limbs29(d2v)
+    S_NZ = "s[44:45]"
+    Bm, qp, qt_in = seq_member(rm, FV(S_C, max(l2[:8]), l2[8], d2v))
+    Bn, qt = seq_member_select(rm, qt_in, S_NZ)
+    Ba = seq_add(rm, True, qt=qt, niels=True, qpm=qp)
+    E = Emitter(); E.schedule(Bm.seq); E.schedule(Bn.seq); E.schedule(Ba.seq)
+    for t in range(trials):
+        P = ED.ed_mul_aff(ED.ED_B, rng.randrange(1, ED.L_ORD)) if t % 5 else (0, 1)
+        z = rng.randrange(1, Q)
+        kind = t % 6
+        Qp = (0, 1) if kind == 0 else (P if kind == 1 else ((Q - P[0]) % Q, P[1]) if kind == 2 else ED.ed_mul_aff(ED.ED_B, rng.randrange(1, ED.L_ORD)))
+        neg, nz = (t // 2) % 2, 0 if t % 7 == 3 else 1
+        em = emu_for()
+        for j, l in enumerate(l2):
+            em.s[S_C[j]] = l
+        for regs, v in zip((rm.X1, rm.Y1, rm.Z1, rm.T1), (P[0] * z % Q, P[1] * z % Q, z, P[0] * P[1] * z % Q)):
+            em.set9(regs, _rep(rng, v, t % 4 == 3))
+        em.set9(rm.A, limbs29(Qp[0] + (Q if t % 3 == 0 else 0))); em.set9(rm.Bv, limbs29(Qp[1]))
+        em.c[S_NEG], em.c[S_NZ] = neg, nz
+        em.run(E.order)
+        gx, gy, gz, gt = (em.get9(r_) % Q for r_ in (rm.X1, rm.Y1, rm.Z1, rm.T1))
+        zi = pow(gz, -1, Q)
+        member = (0, 1) if not nz else (((Q - Qp[0]) % Q, Qp[1]) if neg else Qp)
+        want = ED.ed_add_aff(P, member)
+        assert (gx * zi % Q, gy * zi % Q) == want and gt * zi % Q == want[0] * want[1] % Q, ("member", t, kind, neg, nz)
+    return True
+
+
+def emit_msm_acc():
+    """Bucket accumulation of the Curve25519 MSM (arkmpc_ed_msm.inc, k_edmsm_accumulate) as one stream: a lane folds the `len` members of its task
+    -- vals[first .. first + len): point index | sign << 31, members are 64-byte plain affine (x, y) records -- into an extended sum that starts at
+    the identity.  The law is complete: no flags.  A member becomes its Niels form on the fly (y + x, y - x, 2d x y: two products); a lane whose
+    task is shorter than the wave's longest adds the identity's Niels form (1, 1, 0) instead.  The next member's index and coordinates are requested
+    before the addition.  The sum leaves as the 36-word record of arkmpc_ed_msm.inc (x, y, t, z: nine limbs each, normalised).
+    Operands: %[lo4] %[len] (VGPR), %[maxlen] (SGPR), %[vals] %[aff] (SGPR pairs), %[dst] (VGPR pair)."""
+    rm = RegMap()
+    rec2, last = rm.tid4, rm.tid128
+    L = []
+    A = L.append
+    ld, st = mem_ops(A)
+    lbl = lambda s_: "%s_%%=" % s_
+    S_NZ = "s[44:45]"
+    prologue(A)
+    d2 = const_to(A, 2 * D_ED % Q)
+    for j in range(NL):
+        A("v_mov_b32_e32 %s, 0" % rm.X1[j])
+        A("v_mov_b32_e32 %s, %d" % (rm.Y1[j], 1 if j == 0 else 0))
+        A("v_mov_b32_e32 %s, %d" % (rm.Z1[j], 1 if j == 0 else 0))
+        A("v_mov_b32_e32 %s, 0" % rm.T1[j])
+
+    def load_xy():
+        A("v_lshlrev_b32_e32 %s, 6, %s" % (rm.off, rm.rec))                 # 64 bytes per member; the shift drops the sign bit
+        ld(rm.ST, rm.off, "aff", 0); ld(rm.LD, rm.off, "aff", 32)
+
+    A("v_add_u32_e32 %s, -1, %%[len]" % last)
+    A("global_load_dword %s, %%[lo4], %%[vals]" % rm.rec)
+    A("s_waitcnt vmcnt(0)")
+    load_xy()
+    A("s_mov_b32 %s, 0" % S_STEP)
+    EC.align_head(A)
+    A(lbl("M_step") + ":")
+    A("s_add_u32 %s, %s, 1" % (S_TMP, S_STEP))
+    A("v_min_u32_e32 %s, %s, %s" % (rm.tmp, S_TMP, last))
+    A("v_lshl_add_u32 %s, %s, 2, %%[lo4]" % (rm.tmp, rm.tmp))
+    A("global_load_dword %s, %s, %%[vals]" % (rec2, rm.tmp))
+    A("v_cmp_gt_u32_e64 %s, %%[len], %s" % (S_NZ, S_STEP))                  # this lane still has a member at this step
+    A("v_cmp_gt_i32_e64 %s, 0, %s" % (S_NEG, rm.rec))
+    A("s_waitcnt vmcnt(1)")
+    Bm, qp, qt_in = seq_member(rm, d2, unpack=True)
+    _sched(L, Bm.seq)
+    # the member after this one: index -> coordinates, in flight during the addition
+    A("s_waitcnt vmcnt(0)")
+    A("v_mov_b32_e32 %s, %s" % (rm.rec, rec2))
+    load_xy()
+    Bn, qt = seq_member_select(rm, qt_in, S_NZ)
+    _sched(L, Bn.seq, pre={S_NEG: -1, S_NZ: -1})
+    Ea = _sched(L, seq_add(rm, True, qt=qt, niels=True, qpm=qp).seq)
+    A("s_add_u32 %s, %s, 1" % (S_STEP, S_STEP))
+    A("s_cmp_lt_u32 %s, %%[maxlen]" % S_STEP)
+    A("s_cbranch_scc1 " + lbl("M_step"))
+    A("s_waitcnt vmcnt(0)")                                                   # the last prefetch (clamped to the last member) is not used
+    Bo = Bld(rm)
+    for e in acc_fvs(rm):
+        Bo.norm(e)
+    _sched(L, Bo.seq)
+    for k, regs in enumerate((rm.X1, rm.Y1, rm.T1, rm.Z1)):                   # record order x, y, t, z
+        for j in range(NL):
+            A("global_store_dword %%[dst], %s, off offset:%d" % (regs[j], 4 * (9 * k + j)))
+    A("s_waitcnt vmcnt(0)")
+    mult = sum(1 for i in Ea.order if i.op in ("mad", "mad24")) + sum(1 for i in Bm.seq if i.op in ("mad", "mad24"))
+    return L, rm, dict(add=len(Ea.order), member_mults=mult, vgpr_end=rm.end)
+
+
 def emit_header(path):
     selftest(trials=14)
+    selftest_member(trials=12)
     lines, rm, st = emit_loop()
     out = ["// GENERATED by tools/gen_ed29_asm.py -- do not edit.  The Curve25519 window loop, table kernel and fixed-base chain on NINE 29-bit limbs, plain",
            "// arithmetic mod 2^255 - 19 (2^261 = 1216 folds the high columns of a product into the low ones); operands and memory formats of ed_asm_kernels.inc.",
@@ -681,9 +815,15 @@ def emit_header(path):
             G.c_string(glines), "        :", '        : [tid] "v"(tid), [n] "s"(n), [dig] "s"(dig), [tab] "s"(tab), [res] "s"(res)']
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(grm.first, grm.end)]
     out += ["        : " + ", ".join(clob) + ");", "}"]
+    mlines, mrm, mst = emit_msm_acc()
+    out += ["// bucket accumulation of the MSM: members become Niels points on the fly, complete addition, no flags: %d asm lines, %d instructions per addition" % (len(mlines), mst["add"]),
+            "__device__ __forceinline__ void ed_msm_acc29_asm(u32 lo4, u32 len, u32 maxlen, const u32* vals, const u64* aff, u32* dst) {", "    asm volatile(",
+            G.c_string(mlines), "        :", '        : [lo4] "v"(lo4), [len] "v"(len), [maxlen] "s"(maxlen), [vals] "s"(vals), [aff] "s"(aff), [dst] "v"(dst)']
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"%s"' % s_ for s_ in CLOBBER_SGPRS] + ['"v%d"' % i for i in range(mrm.first, mrm.end)]
+    out += ["        : " + ", ".join(clob) + ");", "}"]
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
-    return st, len(lines) + len(tlines) + len(glines)
+    return st, len(lines) + len(tlines) + len(glines) + len(mlines)
 
 
 if __name__ == "__main__":
@@ -693,6 +833,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.selftest:
         r = selftest(trials=120)
+        selftest_member(trials=60)
         print("multiplications at their operand bounds: %d distinct, ok" % selftest_extremes())
         print("ok:", {k: (len(v[0].order), len(v[1].order)) for k, v in r.items()})
         sys.exit(0)

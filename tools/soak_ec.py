@@ -2,7 +2,7 @@
 """Soak of the hand-scheduled point kernels against the compiled ones: the same seeded random inputs are pushed through
 PointShare x Scalar (BN254 G1 and Curve25519), the variable-base MSM and its authenticated form in two child processes --
 the hand-scheduled kernels on 29-bit limbs (default), the same on 32-bit limbs (ARKMPC_EC_LIMBS=32 ARKMPC_ED_LIMBS=32), and the compiled
-kernels (ARKMPC_EC_ASM=0 ARKMPC_ED_ASM=0 ARKMPC_MSM_ASM=0) -- and the SHA-256 digests of the AFFINE outputs (the fixed-base generator
+kernels (ARKMPC_EC_ASM=0 ARKMPC_ED_ASM=0 ARKMPC_MSM_ASM=0 ARKMPC_EDMSM_ASM=0) -- and the SHA-256 digests of the AFFINE outputs (the fixed-base generator
 multiples that serve as inputs included) must agree, seed by seed.  (Jacobian / extended representatives legitimately differ between the paths.)
 usage: python tools/soak_ec.py [seeds] [log2n]"""
 import hashlib, importlib, json, os, subprocess, sys
@@ -52,6 +52,15 @@ def child(seeds, lg):
                     a = torch.empty(8 * cols, dtype=torch.int64, device="cuda"); i2 = torch.empty(cols + 16, dtype=torch.uint8, device="cuda")
                     e.g1_to_affine(cols, o, a, i2)
                     res["%s/%s/%d" % (name, form, seed)] = hashlib.sha256(a.cpu().numpy().tobytes()).hexdigest()
+            else:
+                pts = shares.view(2 * n, 16)[:n].contiguous().view(-1)
+                scs = rnd(2 * n)
+                for form, fn, cols in (("msm", e.ed_msm, 1), ("msm_auth", e.ed_msm_authenticated, 2)):
+                    o = torch.empty(16 * cols, dtype=torch.int64, device="cuda")
+                    fn(n, pts, scs, o)
+                    a = torch.empty(8 * cols, dtype=torch.int64, device="cuda")
+                    e.ed_to_affine(cols, o, a)
+                    res["%s/%s/%d" % (name, form, seed)] = hashlib.sha256(a.cpu().numpy().tobytes()).hexdigest()
             e.close()
     print(json.dumps(res))
 
@@ -63,7 +72,7 @@ if __name__ == "__main__":
     lg = int(sys.argv[2]) if len(sys.argv) > 2 else 17
     runs = {}
     for tag, env in (("asm", {}), ("asm32", {"ARKMPC_EC_LIMBS": "32", "ARKMPC_ED_LIMBS": "32"}),
-                     ("compiled", {"ARKMPC_EC_ASM": "0", "ARKMPC_ED_ASM": "0", "ARKMPC_MSM_ASM": "0"})):
+                     ("compiled", {"ARKMPC_EC_ASM": "0", "ARKMPC_ED_ASM": "0", "ARKMPC_MSM_ASM": "0", "ARKMPC_EDMSM_ASM": "0"})):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(seeds), str(lg)], capture_output=True, text=True,
                            env=dict(os.environ, **env), timeout=3000)
         if r.returncode != 0:
