@@ -367,6 +367,34 @@ __global__ void __launch_bounds__(TPB) k_beaver_finish_asm_so(u32 n, u32 mask, F
         }
     }
 }
+// The same with WAVE-local staging: a wave writes out exactly the 128 chunks of each column its own 64 lanes produced (chunk 128 w + lane + 64 k),
+// so the only ordering it needs is its own LDS writes (the body ends on s_waitcnt lgkmcnt(0)) -- no workgroup barrier, a wave retires without
+// waiting for the other three (ARKMPC_K3_NT=4).
+template <int F>
+__global__ void __launch_bounds__(TPB) k_beaver_finish_asm_sw(u32 n, u32 mask, Fe key, const u64* my_d, const u64* my_e, const u64* peer_d,
+                                                              const u64* peer_e, const u64* a_s, const u64* a_m, const u64* b_s, const u64* b_m,
+                                                              const u64* c_s, const u64* c_m, u64* out_s, u64* out_m) {
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    __shared__ v4u lds[2 * TPB * 2];
+    const u32 first = blockIdx.x * TPB, i = first + threadIdx.x;
+    const u32 cnt = (n - first < TPB) ? n - first : TPB;
+    const u32 lds_base = (u32)(size_t)(__attribute__((address_space(3))) char*)lds;
+    if (i < n) beaver_finish_asm_so<F>(i * 32u, i * 32u, lds_base + threadIdx.x * 32u, my_d, my_e, peer_d, peer_e, a_s, a_m, b_s, b_m, c_s, c_m, key, mask);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    v4u* os = reinterpret_cast<v4u*>(out_s) + 2 * (size_t)first;
+    v4u* om = reinterpret_cast<v4u*>(out_m) + 2 * (size_t)first;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 idx = 128u * wave + lane + 64u * k;
+        if (idx < 2 * cnt) {
+            __builtin_nontemporal_store(lds[idx], os + idx);
+            __builtin_nontemporal_store(lds[2 * TPB + idx], om + idx);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // batch open + MAC check (authenticated_scalar.rs:278-354)
@@ -498,7 +526,7 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                 // once-streamed loads, result staged through LDS and written with whole-line non-temporal stores: 58.4 us; 1 = the same hints with the
                 // body's own 16-byte stores: 61.1 us (partial-line write amplification); 2 = hints on the loads only: 66 us (plain stores keep the
                 // results in the cache K3's re-reads want); 0 = no hints: 74 us
-                static const int k3_nt = getenv("ARKMPC_K3_NT") ? atoi(getenv("ARKMPC_K3_NT")) : 3;
+                static const int k3_nt = getenv("ARKMPC_K3_NT") ? atoi(getenv("ARKMPC_K3_NT")) : 4;     // 4: LDS-staged whole-line stores, per wave (measured best; 3: per workgroup; 1 / 2: the body's own stores)
                 static const bool aos_lds = !(getenv("ARKMPC_K3_AOS_LDS") && getenv("ARKMPC_K3_AOS_LDS")[0] == '0');
                 const bool aos_records = a_s.stride == 8 && o_s.stride == 8 && a_m.p == a_s.p + 4 && b_m.p == b_s.p + 4 && c_m.p == c_s.p + 4 &&
                                          o_m.p == o_s.p + 4;
@@ -514,6 +542,9 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
              o_s.stride * 8u)
                 if (nt == 3)            // result staged through LDS, whole-line stores (split columns only)
                     launch_k(ctx, k_beaver_finish_asm_so<F>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo,
+                             peer_e + 4 * lo, a_s.p + cs, a_m.p + cs, b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os);
+                else if (nt == 4)       // the same with wave-local staging (no workgroup barrier)
+                    launch_k(ctx, k_beaver_finish_asm_sw<F>, dim3(blocks_for(cnt, TPB)), dim3(TPB), (u32)cnt, mask, k, my_d + 4 * lo, my_e + 4 * lo, peer_d + 4 * lo,
                              peer_e + 4 * lo, a_s.p + cs, a_m.p + cs, b_s.p + cs, b_m.p + cs, c_s.p + cs, c_m.p + cs, o_s.p + os, o_m.p + os);
                 else if (nt == 1) ARK_K3_LAUNCH(1);
                 else if (nt == 2) ARK_K3_LAUNCH(2);

@@ -832,7 +832,7 @@ def main():
                        "settle_ms": args.settle_ms, "settle_note": "untimed run of the same pipeline before the warm-up steps, every rank: keeps the timed region out of the "
                                    "power controller's transient after idle (profiles/r02/ramp_probe.txt); --settle-ms 0 disables",
                        "parallelism": "gate-range sharding, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": ("k_beaver_finish_asm_so<0>" if args.layout == "split" else "k_beaver_finish_asm_aos<0>") + " (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": ("k_beaver_finish_asm_sw<0>" if args.layout == "split" else "k_beaver_finish_asm_aos<0>") + " (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": m_launch * ALG_BYTES_K3, "gates_per_launch": m_launch, "avg_launch_ms": k3_ms,
                          "avg_launch_ms_note": "HIP events bound to the kernel dispatch (hipExtLaunchKernelGGL) on sampled steps of the timed region",
