@@ -293,7 +293,8 @@ __global__ void __launch_bounds__(TPB) k_beaver_finish(size_t n, int party, Fe k
 }
 
 // K2+K3, hand-scheduled: same semantics as k_beaver_finish<F, true>.  All 16 first-wave loads are issued before any
-// arithmetic, the six products are reduced by three Montgomery reductions (lazy reduction), c is loaded over dead
+// arithmetic, the gate is regrouped to FIVE products under three Montgomery reductions (share = d (e [P0] + b.s) + e a.s + c.s,
+// mac = d (key e + b.m) + e a.m + c.m: the same field elements as the reference's de + d[b] + e[a] + [c]), c is loaded over dead
 // registers while the MAC rows run.  Byte offsets are 32-bit: the launcher chunks batches above 2^25 gates.
 template <int F, int NT>
 __global__ void __launch_bounds__(TPB) k_beaver_finish_asm(u32 n, u32 mask, Fe key, const u64* my_d, const u64* my_e, const u64* peer_d,

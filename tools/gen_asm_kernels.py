@@ -429,44 +429,49 @@ def _build_beaver_finish(p, first_vgpr, key_names, sched, lds, ldsout=False):
         E.emit(i_mov(P[j], (p >> (32 * j)) & M32))
     for t in Tz:
         E.emit(i_mov(t[1], 0))
-    # ---- segment 1: K2 (d = my_d + peer_d, e = my_e + peer_e) and de = d*e
+    # ---- regrouping (exact in the field, so the canonical results are the reference's bit for bit):
+    #   share = de [PARTY0] + d b.s + e a.s + c.s = d (e [PARTY0] + b.s) + e a.s + c.s
+    #   mac   = key de + d b.m + e a.m + c.m     = d (key e + b.m)     + e a.m + c.m
+    # FIVE products and three reductions (key e; two sums of two products) instead of six and three (de; a sum of two; a sum of three --
+    # or, for moduli above ~2^254.4, six and FOUR).  The second factor of a product is only the row multiplier: it may be any 256-bit
+    # value, so the sums e + b.s and key e + b.m are left unreduced (< 2p) where the reduced sum of products still fits 8 limbs.
+    def lazy_ok():
+        return (3 * (p - 1) * (p - 1) + (R - 1) * p) // R + 1 < R
+
+    def plus(dst, a_, b_, cy):
+        """dst = a_ + b_: unreduced when the modulus leaves room, canonical otherwise; returns (sequence, value weight of dst as a row multiplier)"""
+        if lazy_ok():
+            return [i_addco(dst[0], a_[0], b_[0], cy)] + [i_addc(dst[j], a_[j], b_[j], cy) for j in range(1, 8)], 2
+        return fe_add_seq(P, a_, b_, dst, qflat[8:]), 1
+    # ---- segment 1: K2 (d = my_d + peer_d, e = my_e + peer_e) and ke = key * e
     E.emit(i_wait(0 if lds else 8))                                  # LDS variant: the eight d||e loads are the only global loads
-    d, e, de = dm, em, dp
+    d, e, ke = dm, em, dp
     seg = fe_add_seq(P, dm, dp, dm, qflat[:8]) + fe_add_seq(P, em, ep, em, qflat[8:])
-    mm, row = montmul_sum_seq(p, [(d, e)], T, Tz, q, m, P)
-    seg += mm + cond_sub_final(p, 1, T, P, qflat, de)
+    mm, row = montmul_sum_seq(p, [(key, e)], T, Tz, q, m, P)
+    seg += mm + cond_sub_final(p, 1, T, P, qflat, ke)
     run(seg)
-    # ---- segment 2: share' = d*b.s + e*a.s (one reduction); then c is loaded over the dead b.s / a.s registers
+    # ---- segment 2: share' = d (e [PARTY0] + b.s) + e a.s (one reduction); then c is loaded over the dead b.s / a.s registers
     E.emit(i_wait_lds(4) if lds else i_wait(4))
     rs = ep
+    seg = [i_and(qflat[j], "%[mask]", e[j]) for j in range(8)]
+    add, w = plus(bs, bs, qflat[:8], "vcc")
+    seg += add
     mm, row = montmul_sum_seq(p, [(d, bs), (e, as_)], T, Tz, q, m, P, row)
-    seg = mm + cond_sub_final(p, 2, T, P, qflat, rs)
+    seg += mm + cond_sub_final(p, 1 + w, T, P, qflat, rs)
     cs, cm = bs, as_
     for regs, nm in ((cs, "c_s"), (cm, "c_m")):
         for h in (0, 1):
             seg.append(i_load(regs[4 * h:4 * h + 4], "off_col", nm, h))
     run(seg)
-    # ---- segment 3: mac' = d*b.m + e*a.m + key*de (one reduction); the c loads' latency hides under these rows
+    # ---- segment 3: mac' = d (key e + b.m) + e a.m (one reduction); the c loads' latency hides under these rows
     E.emit(i_wait_lds(4) if lds else i_wait(4))
     rm = bm
-    if t_bounds(p, 3)[0] < (1 << 288):
-        mm, row = montmul_sum_seq(p, [(d, bm), (e, am), (key, de)], T, Tz, q, m, P, row)
-        run(mm + cond_sub_final(p, 3, T, P, qflat, rm))
-    else:
-        # moduli above ~2^254.4 (BLS12-381 Fr): three lazily summed products overflow the 9-limb accumulator, so the
-        # MAC is two reductions: REDC(d*b.m + e*a.m) and REDC(key*de), added mod p
-        mm, row = montmul_sum_seq(p, [(d, bm), (e, am)], T, Tz, q, m, P, row)
-        seg = mm + cond_sub_final(p, 2, T, P, qflat, rm)
-        kd = am                                                   # a.m is dead once its rows are done
-        mm, row = montmul_sum_seq(p, [(key, de)], T, Tz, q, m, P, row)
-        seg += mm + cond_sub_final(p, 1, T, P, qflat, kd)
-        seg += fe_add_seq(P, rm, kd, rm, qflat[:8])
-        run(seg)
-    # ---- segment 4: share = share' + c.s + (PARTY0 ? de : 0) ; mac = mac' + c.m ; stores
+    seg, w = plus(bm, bm, ke, CY2)
+    mm, row = montmul_sum_seq(p, [(d, bm), (e, am)], T, Tz, q, m, P, row)
+    run(seg + mm + cond_sub_final(p, 1 + w, T, P, qflat, rm))
+    # ---- segment 4: share = share' + c.s ; mac = mac' + c.m ; stores
     E.emit(i_wait_lds(0) if lds else i_wait(0))
-    dem = am
-    seg = [i_and(dem[j], "%[mask]", de[j]) for j in range(8)]
-    seg += fe_add_seq(P, rs, cs, rs, qflat[:8]) + fe_add_seq(P, rm, cm, rm, qflat[8:]) + fe_add_seq(P, rs, dem, rs, qflat[:8])
+    seg = fe_add_seq(P, rs, cs, rs, qflat[:8]) + fe_add_seq(P, rm, cm, rm, qflat[8:])
     for regs, nm in ((rs, "out_s"), (rm, "out_m")):
         for h in (0, 1):
             seg.append(i_store(regs[4 * h:4 * h + 4], "off_out", nm, h))

@@ -165,7 +165,7 @@ for sub, tags in (("pmc_ec", ("k_g1_smul_loop", "k_g1_smul_table")), ("pmc_k3", 
         st = _stats("ec29_asm_stats.json" if name.endswith("29") else "ec_asm_stats.json")
         w, valu, gui = cs["SQ_WAVES"][k], cs["SQ_INSTS_VALU"][k], cs["GRBM_GUI_ACTIVE"][k]
         per_wave = valu / max(w, 1)
-        mult = {"k_g1_smul_loop": st.get("mult_instrs_loop"), "k_g1_smul_table": st.get("mult_instrs_table"), "k_beaver_finish_asm": 576, "k_beaver_mask": 0}.get(tag)
+        mult = {"k_g1_smul_loop": st.get("mult_instrs_loop"), "k_g1_smul_table": st.get("mult_instrs_table"), "k_beaver_finish_asm": 536, "k_beaver_mask": 0}.get(tag)
         line = "  %-24s waves %6d  VALU/wave %9.0f  busy cycles/XCD %11.0f  SIMD cycles per VALU instruction %.2f" % (
             name, w, per_wave, gui / 8, 1024 * (gui / 8) / max(w * per_wave, 1))
         if mult:
