@@ -176,13 +176,26 @@ struct Stage {
 
 // launch on the context's stream; if a kernel-timer slot is armed, bind its start/stop events to this dispatch
 template <class K, class... A>
-static inline void launch_k(arkmpc_ctx* ctx, K kernel, dim3 grid, dim3 block, A... args) {
+static inline void launch_k_lds(arkmpc_ctx* ctx, unsigned lds_bytes, K kernel, dim3 grid, dim3 block, A... args) {      // launch_k with `lds_bytes` of dynamic LDS
     if (ctx->timer_slot >= 0) {
         const int s = ctx->timer_slot;
         ctx->timer_slot = -1;
-        hipExtLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->tev[2 * s], ctx->tev[2 * s + 1], 0, args...);
+        hipExtLaunchKernelGGL(kernel, grid, block, lds_bytes, ctx->stream, ctx->tev[2 * s], ctx->tev[2 * s + 1], 0, args...);
     } else {
-        hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, ctx->stream, args...);
+    }
+}
+template <typename K, typename... A>
+static inline void launch_k(arkmpc_ctx* ctx, K kernel, dim3 grid, dim3 block, A... args) {
+    // experiment hook: ARKMPC_TEST_DYN_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups a CU can hold (occupancy sensitivity
+    // of the streaming kernels: tools/k3_occupancy_probe.sh); 0 / unset in production
+    static const unsigned dyn_lds = getenv("ARKMPC_TEST_DYN_LDS") ? (unsigned)atoi(getenv("ARKMPC_TEST_DYN_LDS")) : 0u;
+    if (ctx->timer_slot >= 0) {
+        const int s = ctx->timer_slot;
+        ctx->timer_slot = -1;
+        hipExtLaunchKernelGGL(kernel, grid, block, dyn_lds, ctx->stream, ctx->tev[2 * s], ctx->tev[2 * s + 1], 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, dyn_lds, ctx->stream, args...);
     }
 }
 

@@ -376,7 +376,10 @@ __global__ void __launch_bounds__(TPB) k_beaver_finish_asm_sw(u32 n, u32 mask, F
                                                               const u64* peer_e, const u64* a_s, const u64* a_m, const u64* b_s, const u64* b_m,
                                                               const u64* c_s, const u64* c_m, u64* out_s, u64* out_m) {
     typedef u32 v4u __attribute__((ext_vector_type(4)));
-    __shared__ v4u lds[2 * TPB * 2];
+    // 16 KiB are used; the allocation is 44 KiB so that a CU holds THREE workgroups (three waves per SIMD), not the four the 115 VGPRs would allow:
+    // the kernel is bound by the memory system, not by latency -- measured with tools/k3_occupancy_probe.sh: 4 / 3 / 2 / 1 waves per SIMD =
+    // 57.8 / 57.0 / 59.4 / 82 us -- and the fourth wave only adds contention
+    __shared__ v4u lds[2816];
     const u32 first = blockIdx.x * TPB, i = first + threadIdx.x;
     const u32 cnt = (n - first < TPB) ? n - first : TPB;
     const u32 lds_base = (u32)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -488,14 +491,18 @@ static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u
     static const int aos_mode = getenv("ARKMPC_K1_NT_AOS") ? atoi(getenv("ARKMPC_K1_NT_AOS")) & 7 : 0;
     static const bool xcd_map = getenv("ARKMPC_K1_XCD") && getenv("ARKMPC_K1_XCD")[0] == '1';
     const u32 xcd = (xcd_map && g.x % 8 == 0 && n % TPB == 0) ? g.x : 0u;
+    // unused dynamic LDS caps the workgroups per CU (160 KB per CU): K1 is bound by the memory system and runs best with few waves in flight
+    // (tools/k1_occupancy_probe.sh, 2^20 gates: 8+ / 4 / 3 / 2 / 1 workgroups per CU = 36.5 / 36.0 / 35.9 / 35.1 / 36.0 us): two workgroups per CU for large batches
+    static const int k1_lds_env = getenv("ARKMPC_K1_LDS") ? atoi(getenv("ARKMPC_K1_LDS")) : -1;
+    const unsigned k1_lds = k1_lds_env >= 0 ? (unsigned)k1_lds_env : (n >= ((size_t)1 << 16) ? 80000u : 0u);
     switch (split ? k1_nt_mode() : aos_mode) {
-        case 1: launch_k(ctx, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
-        case 2: launch_k(ctx, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
-        case 3: launch_k(ctx, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
-        case 4: launch_k(ctx, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
-        case 5: launch_k(ctx, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
-        case 7: launch_k(ctx, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
-        default: launch_k(ctx, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 1: launch_k_lds(ctx, k1_lds, k_beaver_mask<F, 1>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 2: launch_k_lds(ctx, k1_lds, k_beaver_mask<F, 2>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 3: launch_k_lds(ctx, k1_lds, k_beaver_mask<F, 3>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 4: launch_k_lds(ctx, k1_lds, k_beaver_mask<F, 4>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 5: launch_k_lds(ctx, k1_lds, k_beaver_mask<F, 5>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        case 7: launch_k_lds(ctx, k1_lds, k_beaver_mask<F, 7>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
+        default: launch_k_lds(ctx, k1_lds, k_beaver_mask<F, 0>, g, t, n, x, y, a, b, out, out_e, dup, dup_e, xcd); break;
     }
 }
 
