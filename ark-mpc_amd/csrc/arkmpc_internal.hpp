@@ -45,6 +45,10 @@ struct arkmpc_ctx {
     // (with an event) above cache_cap.
     std::unordered_map<size_t, std::vector<void*>> cache;
     size_t cache_bytes = 0;
+    // host link of the streaming host-to-host path (arkmpc_stream.inc): one copy stream per direction beside the compute stream, created on
+    // first use, and a free list of timing-disabled events
+    hipStream_t up = nullptr, down = nullptr;
+    std::vector<hipEvent_t> link_ev;
     // kernel timer: event pairs bound to the dispatch of the NEXT K1 / K3 launch (hipExtLaunchKernelGGL)
     static constexpr int kTimerSlots = 64;
     hipEvent_t tev[2 * kTimerSlots] = {};

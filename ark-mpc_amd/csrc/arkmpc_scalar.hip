@@ -712,6 +712,9 @@ int arkmpc_ctx_destroy(arkmpc_ctx* ctx) {
             if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
         }
         for (auto& e : ctx->tev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ctx->link_ev) (void)hipEventDestroy(e);
+        if (ctx->up) { (void)hipStreamSynchronize(ctx->up); (void)hipStreamDestroy(ctx->up); }
+        if (ctx->down) { (void)hipStreamSynchronize(ctx->down); (void)hipStreamDestroy(ctx->down); }
         if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -765,8 +768,8 @@ const char* arkmpc_last_error(arkmpc_ctx* ctx) {
     return snapshot.c_str();
 }
 
-int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
-    ENTER(ctx);
+// body of arkmpc_malloc; the caller holds the context lock (ENTER)
+static int ark_malloc_locked(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
     if (!out_dptr) return ark_bad(ctx, "null out pointer");
     if (!pool_enabled() || ctx->device >= 16) {
         ARK_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 16));
@@ -807,8 +810,12 @@ int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
     p.live_[*out_dptr] = cls;
     return ARKMPC_OK;
 }
-int arkmpc_free(arkmpc_ctx* ctx, void* dptr) {
+int arkmpc_malloc(arkmpc_ctx* ctx, size_t bytes, void** out_dptr) {
     ENTER(ctx);
+    return ark_malloc_locked(ctx, bytes, out_dptr);
+}
+// body of arkmpc_free; the caller holds the context lock
+static int ark_free_locked(arkmpc_ctx* ctx, void* dptr) {
     if (!dptr) return ARKMPC_OK;
     if (pool_enabled() && ctx->device < 16) {
         DevicePool& p = g_pool[ctx->device];
@@ -840,6 +847,10 @@ int arkmpc_free(arkmpc_ctx* ctx, void* dptr) {
     ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ARK_HIP(ctx, hipFree(dptr));
     return ARKMPC_OK;
+}
+int arkmpc_free(arkmpc_ctx* ctx, void* dptr) {
+    ENTER(ctx);
+    return ark_free_locked(ctx, dptr);
 }
 int arkmpc_memcpy_h2d(arkmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
     ENTER(ctx);
@@ -1432,6 +1443,10 @@ int arkmpc_commit_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* values, const 
     host_from_be_bytes_mod_order(ctx->field_id, dig, out_commitment);
     return ARKMPC_OK;
 }
+
+}  // extern "C"
+#include "arkmpc_stream.inc"
+extern "C" {
 
 int arkmpc_sha3_256(const uint8_t* msg, size_t len, uint8_t out32[32]) {
     if ((!msg && len) || !out32) return ARKMPC_ERR_BAD_ARG;

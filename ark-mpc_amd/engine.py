@@ -228,6 +228,24 @@ class Engine:
     def share_mul_public_v(self, n, a_s, a_m, ast, pub, o_s, o_m, ost):
         self.call("share_mul_public_v", ("size", n), a_s, a_m, ("size", ast), pub, o_s, o_m, ("size", ost))
 
+    # ---- streaming host-to-host Beaver multiplication (arkmpc_hostmul_*): numpy arrays in, numpy arrays out
+    def hostmul_begin(self, n, x, y, a, b, c, out_de):
+        """Phase 1; returns the session handle.  The arrays must stay alive and unmodified until hostmul_finish / hostmul_abort."""
+        s = ctypes.c_void_p()
+        self.call("hostmul_begin", ("size", n), x, y, a, b, c, out_de, ("ref", ctypes.byref(s)))
+        return s
+    def hostmul_poll_de(self, s):
+        g = ctypes.c_size_t(0)
+        rc = self.lib.arkmpc_hostmul_poll_de(s, ctypes.byref(g))
+        if rc != 0:
+            self._ck(rc)
+        return int(g.value)
+    def hostmul_wait_de(self, s): self._ck(self.lib.arkmpc_hostmul_wait_de(s))
+    def hostmul_finish(self, s, party, key, peer_de, out):
+        arr, pk = _key(key)
+        self._ck(self.lib.arkmpc_hostmul_finish(s, ctypes.c_int(int(party)), pk, _ptr(peer_de), _ptr(out)))
+    def hostmul_abort(self, s): self._ck(self.lib.arkmpc_hostmul_abort(s))
+
     # ---- batch open + MAC check
     def mac_check_shares(self, n, key, opened, shares, out): self.call("mac_check_shares", ("size", n), ("key", key), opened, shares, out)
     def open_and_mac_check(self, n, key, shares, peer, out_opened, out_chk):

@@ -239,6 +239,34 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
                                     const uint64_t* c_share, const uint64_t* c_mac, size_t c_stride,
                                     uint64_t* out_share, uint64_t* out_mac, size_t out_stride);
 
+/* ---- streaming host-to-host forms (csrc/arkmpc_stream.inc) -----------------------------------------------------------------------
+ * For a caller whose operands ARE host memory -- the `Vec<ScalarShare<C>>`s a gate closure receives (fabric.rs:841-854) -- and who
+ * wants host vectors back: what benches/batch_ops.rs:19-39 times.  Over PCIe the path is bound by the host link (384 B up, 128 B down
+ * per party-gate), so these entry points run a three-stream pipeline (upload DMA | kernels | download DMA) that keeps the upload
+ * direction busy from the first byte to the last and hides the kernels and the downloads under it.  They take HOST pointers whatever
+ * the context's buffer mode, any alignment a Rust Vec has (8 bytes).  Buffers are pinned in place for the duration of the call
+ * (hipHostRegister; skipped for buffers that are already pinned); a caller that keeps its vectors across calls pins them once: */
+int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK */
+int arkmpc_host_unregister(void* ptr);
+int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc) */
+int arkmpc_host_free(void* ptr);
+/* AuthenticatedScalarResult::batch_mul (authenticated_scalar.rs:848-879) as a two-phase session around the d||e exchange:
+ *   _begin   x, y, a, b, c: n ScalarShares each (arkworks records); out_de: 2n Scalars, d then e -- the ScalarBatch this party sends
+ *            (:863-868, :141-145).  Enqueues the uploads, K1 chunk by chunk and the payload downloads, and returns.
+ *   _poll_de / _wait_de   how many leading gates of d AND e have landed in out_de (never blocks) / block until all have: the sender
+ *            of a real link can start transmitting before the batch is complete.
+ *   _finish  peer_de: the 2n Scalars received (:871-878); out: n ScalarShares.  Blocks until `out` is complete; ends the session (also
+ *            when it returns an error).  _abort ends a session without phase 2.
+ * The input vectors must stay valid and unmodified until _finish / _abort returns.  One session at a time per context is the intended
+ * use; sessions of different contexts (the two parties of a mock run, rayon workers) are independent. */
+typedef struct arkmpc_hostmul arkmpc_hostmul;
+int arkmpc_hostmul_begin(arkmpc_ctx* ctx, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a, const uint64_t* b,
+                         const uint64_t* c, uint64_t* out_de, arkmpc_hostmul** out_session);
+int arkmpc_hostmul_poll_de(arkmpc_hostmul* session, size_t* out_gates);
+int arkmpc_hostmul_wait_de(arkmpc_hostmul* session);
+int arkmpc_hostmul_finish(arkmpc_hostmul* session, int party_id, const uint64_t mac_key[4], const uint64_t* peer_de, uint64_t* out);
+int arkmpc_hostmul_abort(arkmpc_hostmul* session);
+
 /* ---- batch open + MAC check, authenticated_scalar.rs:278-354 ------------------------------- */
 /* the `.share()` projection sent by open_batch (:141-145): n ScalarShares -> n Scalars */
 int arkmpc_share_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64_t* out_share_values);

@@ -1,0 +1,242 @@
+"""GPU parity of the streaming host-to-host path (include/arkmpc.h arkmpc_hostmul_*, csrc/arkmpc_stream.inc): host arkworks records in,
+host records out, every word against the CPU oracle (authenticated_scalar.rs:848-879).  The pipeline itself computes nothing new -- these
+tests pin the plumbing: chunk boundaries (ragged last chunk), unaligned Rust-Vec-like pointers, aliased operands, pinned / pageable /
+pre-registered buffers, the d||e progress counter, error paths that must end the session."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import pyref
+from helpers import mont_array, from_mont_array, mixed_values, rand_values, authenticated_shares
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _inputs(fid, n, seed, tile_from=None):
+    """two-party authenticated shares of x, y and a Beaver triple.  Large n: a small python-int workload tiled (the oracle is the checker, so
+    repeated gates cost nothing in coverage of the plumbing: positions still differ chunk by chunk through the rolled tiling)."""
+    p = pyref.P[fid]
+    m = n if tile_from is None else min(n, tile_from)
+    key0, key1 = rand_values(fid, 2, seed + 1)
+    key = (key0 + key1) % p
+    x = mixed_values(fid, m, seed + 2)
+    y = mixed_values(fid, m, seed + 3)[::-1]
+    ta, tb = rand_values(fid, m, seed + 4), rand_values(fid, m, seed + 5)
+    tc = [(u * v) % p for u, v in zip(ta, tb)]
+    sh = {}
+    for i, (name, vals) in enumerate([("x", x), ("y", y), ("a", ta), ("b", tb), ("c", tc)]):
+        s0, s1 = authenticated_shares(fid, vals, key, seed + 10 * i)
+        if m < n:
+            reps = -(-n // m)
+            s0 = np.ascontiguousarray(np.tile(s0.reshape(m, 8), (reps, 1))[:n].reshape(-1))
+            s1 = np.ascontiguousarray(np.tile(s1.reshape(m, 8), (reps, 1))[:n].reshape(-1))
+        sh[name] = (s0, s1)
+    keys = [mont_array(fid, [key0]), mont_array(fid, [key1])]
+    vals = (x, y, key)
+    return vals, keys, sh
+
+
+def _oracle_two_party(oracle, fid, n, keys, sh):
+    big = n >= (1 << 16)
+    mask = oracle.beaver_mask_mt if big else oracle.beaver_mask
+    ode = [mask(fid, sh["x"][p], sh["y"][p], sh["a"][p], sh["b"][p]) for p in (0, 1)]
+    want = []
+    for p in (0, 1):
+        if big:
+            my_de, w = oracle.batch_mul_9pass_mt(fid, p, keys[p], sh["x"][p], sh["y"][p], sh["a"][p], sh["b"][p], sh["c"][p], ode[1 - p])
+        else:
+            my_de, w = oracle.batch_mul_9pass_local(fid, p, keys[p], sh["x"][p], sh["y"][p], sh["a"][p], sh["b"][p], sh["c"][p], ode[1 - p])
+        assert np.array_equal(my_de, ode[p])
+        want.append(w)
+    return ode, want
+
+
+def _run_two_party(eng, n, keys, sh, poll=False):
+    """both parties through the session API on one context, the mock link = handing over the host d||e buffers"""
+    de = [np.zeros(8 * n, dtype=np.uint64) for _ in (0, 1)]
+    out = [np.zeros(8 * n, dtype=np.uint64) for _ in (0, 1)]
+    seen = []
+    ses = []                    # both sessions are open at once on the one context: they are independent objects, only the streams are shared
+    for p in (0, 1):
+        s = eng.hostmul_begin(n, sh["x"][p], sh["y"][p], sh["a"][p], sh["b"][p], sh["c"][p], de[p])
+        ses.append(s)
+    for p in (0, 1):
+        if poll:
+            g = eng.hostmul_poll_de(ses[p]); seen.append(g)
+            assert 0 <= g <= n
+        eng.hostmul_wait_de(ses[p])
+        assert eng.hostmul_poll_de(ses[p]) == n
+    for p in (0, 1):
+        eng.hostmul_finish(ses[p], p, keys[p], de[1 - p], out[p])
+    return de, out
+
+
+@pytest.fixture(scope="module")
+def engs(pkg):
+    return {fid: pkg.Engine(fid, device=0) for fid in (0, 1, 2)}
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 2, 777, 16384, 70001])
+def test_hostmul_bitexact_vs_oracle(engs, oracle, fid, n):
+    """every word of d||e and of the result records, both parties; n = 70001 runs five chunks with a ragged last one"""
+    e = engs[fid]
+    p = pyref.P[fid]
+    vals, keys, sh = _inputs(fid, n, seed=4000 + n, tile_from=3000)
+    de, out = _run_two_party(e, n, keys, sh, poll=True)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for party in (0, 1):
+        assert np.array_equal(de[party], ode[party]), "d||e of party %d" % party
+        assert np.array_equal(out[party], want[party]), "result of party %d" % party
+    m = min(n, 3000)
+    x, y, key = vals
+    r0, r1 = out[0].reshape(-1, 8)[:m], out[1].reshape(-1, 8)[:m]
+    prod = [(u + v) % p for u, v in zip(from_mont_array(fid, r0[:, :4].reshape(-1)), from_mont_array(fid, r1[:, :4].reshape(-1)))]
+    macs = [(u + v) % p for u, v in zip(from_mont_array(fid, r0[:, 4:].reshape(-1)), from_mont_array(fid, r1[:, 4:].reshape(-1)))]
+    assert prod == [(u * v) % p for u, v in zip(x[:m], y[:m])]            # authenticated_scalar.rs test_batch_mul :1571-1594
+    assert macs == [(key * u * v) % p for u, v in zip(x[:m], y[:m])]
+
+
+def test_hostmul_empty_batch(engs):
+    e = engs[0]
+    z = np.zeros(0, dtype=np.uint64)
+    s = e.hostmul_begin(0, z, z, z, z, z, z)
+    assert e.hostmul_poll_de(s) == 0
+    e.hostmul_wait_de(s)
+    e.hostmul_finish(s, 0, np.array([1, 0, 0, 0], dtype=np.uint64), z, z)
+
+
+def test_hostmul_unaligned_and_aliased_operands(engs, oracle):
+    """a Rust Vec<ScalarShare> is 8-byte aligned, nothing more; batch_mul(&a, &a) passes the same vector twice (circuit_mul_throughput.rs:30)"""
+    fid, n = 0, 40000
+    e = engs[fid]
+    _, keys, sh = _inputs(fid, n, seed=77, tile_from=2000)
+    def shift(a):                       # the same words at an address that is 8 mod 16
+        buf = np.zeros(a.size + 3, dtype=np.uint64)
+        off = 1 if (buf.ctypes.data % 16) == 0 else 2
+        v = buf[off:off + a.size]; v[:] = a
+        assert v.ctypes.data % 16 == 8
+        return v
+    for party in (0, 1):
+        x = shift(sh["x"][party]); a = shift(sh["a"][party]); b = shift(sh["b"][party]); c = shift(sh["c"][party])
+        de = shift(np.zeros(8 * n, dtype=np.uint64)); out = shift(np.zeros(8 * n, dtype=np.uint64))
+        peer = shift(oracle.beaver_mask(fid, sh["x"][1 - party], sh["x"][1 - party], sh["a"][1 - party], sh["b"][1 - party]))
+        s = e.hostmul_begin(n, x, x, a, b, c, de)                  # x * x
+        e.hostmul_finish(s, party, keys[party], peer, out)
+        my_de, want = oracle.batch_mul_9pass_local(fid, party, keys[party], sh["x"][party], sh["x"][party], sh["a"][party], sh["b"][party],
+                                                   sh["c"][party], np.ascontiguousarray(peer))
+        assert np.array_equal(de, my_de) and np.array_equal(out, want)
+
+
+def test_hostmul_preregistered_and_pinned_buffers(pkg, engs, oracle):
+    """buffers the caller pinned itself (arkmpc_host_register) and buffers from arkmpc_host_alloc run the same pipeline with no pinning inside"""
+    fid, n = 0, 50000
+    e = engs[fid]
+    lib = pkg.load_library()
+    _, keys, sh = _inputs(fid, n, seed=91, tile_from=2000)
+    party = 1
+    names = "xyabc"
+    regs = []
+    for k in names:
+        arr = sh[k][party]
+        assert lib.arkmpc_host_register(ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes)) == 0
+        assert lib.arkmpc_host_register(ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes)) == 0      # twice = OK
+        regs.append(arr)
+    ptrs = []
+    def pinned(nwords):
+        q = ctypes.c_void_p()
+        assert lib.arkmpc_host_alloc(ctypes.c_size_t(8 * nwords), ctypes.byref(q)) == 0
+        ptrs.append(q)
+        return np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ctypes.c_uint64)), shape=(nwords,))
+    de, out, peer = pinned(8 * n), pinned(8 * n), pinned(8 * n)
+    peer[:] = oracle.beaver_mask(fid, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0])
+    s = e.hostmul_begin(n, *(sh[k][party] for k in names), de)
+    e.hostmul_finish(s, party, keys[party], peer, out)
+    my_de, want = oracle.batch_mul_9pass_local(fid, party, keys[party], *(sh[k][party] for k in names), np.array(peer))
+    assert np.array_equal(de, my_de) and np.array_equal(out, want)
+    for arr in regs:
+        assert lib.arkmpc_host_unregister(ctypes.c_void_p(arr.ctypes.data)) == 0
+    del de, out, peer
+    for q in ptrs:
+        assert lib.arkmpc_host_free(q) == 0
+
+
+def test_hostmul_error_paths_end_the_session(pkg, engs):
+    fid, n = 0, 1000
+    e = engs[fid]
+    lib = pkg.load_library()
+    _, keys, sh = _inputs(fid, n, seed=5)
+    de = np.zeros(8 * n, dtype=np.uint64); out = np.zeros(8 * n, dtype=np.uint64)
+    s = ctypes.c_void_p()
+    # a null operand is a status, not a crash, and no session is created
+    rc = lib.arkmpc_hostmul_begin(e.h, ctypes.c_size_t(n), None, ctypes.c_void_p(sh["y"][0].ctypes.data), ctypes.c_void_p(sh["a"][0].ctypes.data),
+                                  ctypes.c_void_p(sh["b"][0].ctypes.data), ctypes.c_void_p(sh["c"][0].ctypes.data), ctypes.c_void_p(de.ctypes.data), ctypes.byref(s))
+    assert rc == -1 and not s.value
+    # a bad party id in phase 2 returns BAD_ARG and still ends the session (nothing leaks, the context stays usable)
+    s = e.hostmul_begin(n, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], de)
+    with pytest.raises(pkg.ArkMpcError):
+        e.hostmul_finish(s, 2, keys[0], de, out)
+    # abort after phase 1
+    s = e.hostmul_begin(n, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], de)
+    e.hostmul_abort(s)
+    s = e.hostmul_begin(n, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], de)
+    e.hostmul_finish(s, 0, keys[0], de, out)
+
+
+def test_hostmul_two_contexts_two_threads(pkg, oracle):
+    """the two parties as two host threads with a context each (the shape of execute_mock_mpc, test_helpers.rs): each waits for its own
+    payload, hands it to the peer over a host 'link' (a barrier), finishes with the peer's"""
+    fid, n = 0, 1 << 18
+    _, keys, sh = _inputs(fid, n, seed=123, tile_from=4096)
+    es = [pkg.Engine(fid, device=0) for _ in (0, 1)]
+    de = [np.zeros(8 * n, dtype=np.uint64) for _ in (0, 1)]
+    out = [np.zeros(8 * n, dtype=np.uint64) for _ in (0, 1)]
+    bar = threading.Barrier(2)
+    errs = []
+
+    def party(p):
+        try:
+            torch.cuda.set_device(0)
+            s = es[p].hostmul_begin(n, sh["x"][p], sh["y"][p], sh["a"][p], sh["b"][p], sh["c"][p], de[p])
+            es[p].hostmul_wait_de(s)
+            bar.wait(timeout=60)
+            es[p].hostmul_finish(s, p, keys[p], de[1 - p], out[p])
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+            try:
+                bar.abort()
+            except Exception:        # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=party, args=(p,)) for p in (0, 1)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for p in (0, 1):
+        assert np.array_equal(de[p], ode[p]) and np.array_equal(out[p], want[p])
+    for e in es:
+        e.close()
+
+
+def test_hostmul_config2_all_2p20_gates_bitexact(pkg, oracle):
+    """BASELINE config 2 from host memory: 2^20 Beaver muls over BN254 Fr, seeded uniform data generated with the engine, brought to the
+    host as a Rust caller would hold it, run through the streaming sessions -- every gate == the oracle's literal 9-pass batch_mul."""
+    import test_gpu_fullsize as fs
+    fid, n = 0, 1 << 20
+    e = fs._eng(pkg, fid)
+    vals, shd, key, keys = fs._setup(e, n, 0xA11CE002)
+    torch.cuda.synchronize()
+    sh = {k: (fs._host(shd[k][0]), fs._host(shd[k][1])) for k in "xyabc"}
+    del shd, vals
+    torch.cuda.empty_cache()
+    de, out = _run_two_party(e, n, keys, sh)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for p in (0, 1):
+        assert np.array_equal(de[p], ode[p]), "party %d d||e" % p
+        bad = np.nonzero((out[p].reshape(n, 8) != want[p].reshape(n, 8)).any(axis=1))[0]
+        assert bad.size == 0, "party %d: %d of %d gates differ, first at %d" % (p, bad.size, n, bad[0])
+    e.close()
