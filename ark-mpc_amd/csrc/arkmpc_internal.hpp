@@ -99,30 +99,172 @@ static inline int arena_reserve(arkmpc_ctx* ctx, size_t bytes) {
     return ARKMPC_OK;
 }
 
-// Staging of one API call.  In device mode `in`/`out` are pass-through (with an alignment check);
-// in host mode they carve device buffers out of the arena, upload inputs and remember outputs.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Host link: what the streaming host-buffer paths share (Stage below, the sessions of arkmpc_stream.inc).
+// Over PCIe a host-buffer call is bound by the link (~56 GB/s per direction on this box, probes/pcie_probe.hip), so the job is to keep
+// the upload direction busy and hide the kernels and the downloads under it: three streams per context -- `up` (H2D DMA), the compute
+// stream, `down` (D2H DMA) -- ordered by events only, and the caller's buffers pinned in place so that the copies are true DMA.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#include <map>
+static inline int link_ensure(arkmpc_ctx* ctx) {
+    if (ctx->up) return ARKMPC_OK;
+    ARK_HIP(ctx, hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
+    ARK_HIP(ctx, hipStreamCreateWithFlags(&ctx->down, hipStreamNonBlocking));
+    return ARKMPC_OK;
+}
+
+// Process-wide registry of the ranges THIS library pinned (hipHostRegister), reference-counted: two sessions may name the same buffer (a
+// party's out_de is its in-process peer's peer_de; batch_mul(&a, &a) passes one vector twice), and the pinning must outlive the last DMA of
+// either.  ROCm accepts a second hipHostRegister of a registered range and the first hipHostUnregister then drops it for both, so ranges
+// pinned by somebody else (the caller's arkmpc_host_register / arkmpc_host_alloc, torch's pinned tensors) are detected up front
+// (hipPointerGetAttributes) and left alone.
+// true if the HIP runtime already tracks the address (pinned / registered host memory, device memory); plain malloc memory is reported
+// either as an error (older runtimes) or as hipMemoryTypeUnregistered
+static inline bool runtime_knows(const void* p) {
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type != hipMemoryTypeUnregistered;
+}
+struct PinRegistry {
+    std::mutex mu;
+    struct Ent { size_t bytes; int refs; };
+    std::map<uintptr_t, Ent> ents;
+    // returns the base of the entry that now holds a reference for [p, p + bytes), or 0 if the range is not ours to pin / could not be pinned
+    uintptr_t acquire(const void* p, size_t bytes) {
+        const uintptr_t a = (uintptr_t)p;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = ents.upper_bound(a);
+        if (it != ents.begin()) {
+            --it;
+            if (a >= it->first && a + bytes <= it->first + it->second.bytes) { it->second.refs++; return it->first; }
+        }
+        if (runtime_knows(p)) return 0;                                        // pinned by the caller already (or not host memory)
+        if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        ents[a] = Ent{bytes, 1};
+        return a;
+    }
+    void release(uintptr_t base) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = ents.find(base);
+        if (it == ents.end()) return;
+        if (--it->second.refs == 0) {
+            (void)hipHostUnregister((void*)base);
+            (void)hipGetLastError();
+            ents.erase(it);
+        }
+    }
+};
+// one registry per process (the engine is one shared object; inline + function-local static = one instance across its translation units)
+inline PinRegistry& pin_registry() { static PinRegistry r; return r; }
+
+// pins caller buffers in place for the lifetime of the object.  A buffer that cannot be pinned (read-only mapping, too small to matter: the
+// copy then takes the runtime's pageable path, slower but correct) is not an error.
+struct HostPins {
+    std::vector<uintptr_t> held;
+    static size_t min_bytes() { static const size_t v = getenv("ARKMPC_PIN_MIN_KB") ? (size_t)atoll(getenv("ARKMPC_PIN_MIN_KB")) << 10 : (size_t)1 << 20; return v; }
+    void pin(const void* p, size_t bytes) {
+        static const bool off = getenv("ARKMPC_NO_PIN") && getenv("ARKMPC_NO_PIN")[0] == '1';
+        if (off || !p || bytes < min_bytes()) return;
+        const uintptr_t base = pin_registry().acquire(p, bytes);
+        if (base) held.push_back(base);
+    }
+    void release() {
+        for (uintptr_t b : held) pin_registry().release(b);
+        held.clear();
+    }
+    ~HostPins() { release(); }
+};
+
+// the events of one streamed call: taken from the context's free list, returned when the call has drained
+struct LinkEvents {
+    arkmpc_ctx* ctx;
+    std::vector<hipEvent_t> used;
+    explicit LinkEvents(arkmpc_ctx* c) : ctx(c) {}
+    hipEvent_t take() {
+        hipEvent_t ev = nullptr;
+        if (!ctx->link_ev.empty()) { ev = ctx->link_ev.back(); ctx->link_ev.pop_back(); }
+        else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        used.push_back(ev);
+        return ev;
+    }
+    // `to` waits (on the device) for everything submitted to `from` so far; returns the event (also usable by the host)
+    int edge(hipStream_t from, hipStream_t to, hipEvent_t* out_ev = nullptr) {
+        hipEvent_t ev = take();
+        if (!ev) { ark_set_err(ctx, "hipEventCreate failed"); return ARKMPC_ERR_HIP; }
+        ARK_HIP(ctx, hipEventRecord(ev, from));
+        if (to) ARK_HIP(ctx, hipStreamWaitEvent(to, ev, 0));
+        if (out_ev) *out_ev = ev;
+        return ARKMPC_OK;
+    }
+    void give_back() {                     // only after the streams that recorded / waited on them have drained
+        for (hipEvent_t e : used) ctx->link_ev.push_back(e);
+        used.clear();
+    }
+};
+
+// Chunk schedule of the chunked array of a phase: [lo, lo + cnt) ranges covering n.  Full chunks are 2^18 elements (16 MiB of 64-byte
+// records: the DMA engines reach 54 of their 56 GB/s at that size, 49 at 4 MiB); the tail tapers by halves down to 2^16 so that what is left
+// AFTER the last upload byte (one kernel + one download of the last chunk) is short; small batches run in about four chunks, never below 2^14.
+static inline std::vector<std::pair<size_t, size_t>> stream_chunks(size_t n) {
+    static const int env = getenv("ARKMPC_STREAM_CHUNK_LOG2") ? atoi(getenv("ARKMPC_STREAM_CHUNK_LOG2")) : 0;
+    static const bool taper = !(getenv("ARKMPC_STREAM_TAPER") && getenv("ARKMPC_STREAM_TAPER")[0] == '0');
+    size_t full = (size_t)1 << 18;
+    if (env >= 10 && env <= 28) full = (size_t)1 << env;
+    else while (full > ((size_t)1 << 14) && full * 4 > n) full >>= 1;
+    const size_t cmin = full >= ((size_t)1 << 18) ? full >> 2 : full;
+    std::vector<std::pair<size_t, size_t>> v;
+    for (size_t lo = 0; lo < n;) {
+        const size_t rem = n - lo;
+        size_t cnt = full;
+        if (taper && rem < 2 * full) { cnt = (rem / 2 + 255) & ~(size_t)255; if (cnt < cmin) cnt = cmin; }
+        if (cnt > rem || rem - cnt < cmin / 4) cnt = rem;
+        v.emplace_back(lo, cnt);
+        lo += cnt;
+    }
+    return v;
+}
+
+// Staging of one API call.  In device mode `in`/`out` are pass-through (with an alignment check); in host mode they carve device
+// buffers out of the arena, upload inputs and remember outputs.
+//
+// Two protocols.  (1) Whole-batch: declare_*, commit(), launch on in<>()/out<>(), finish() -- all uploads, the kernels, all downloads,
+// one after the other on the context's stream.  (2) ELEMENTWISE ops (element i of every output depends on element i of every input)
+// add elementwise(n) before commit() and launch per chunk:
+//        size_t lo, cnt;  while (st.next_chunk(&lo, &cnt)) { launch on elements [lo, lo + cnt) }  return st.finish();
+// In device mode, for small host batches and for PAGEABLE host buffers that is one chunk (0, n): the runtime's own pageable copy (it pins
+// and DMAs piecewise, 54-56 GB/s on this box) is as fast as anything a single call can do -- pinning the buffers in place first costs
+// about 60 % of the DMA it would speed up, which eats the one gain on offer, the hidden downloads (measured: 13.8 ms pinned per call
+// vs 13.3 ms serial for K1 + K2+K3 at 2^20 gates).  For large batches in buffers the caller has ALREADY pinned (arkmpc_host_register /
+// arkmpc_host_alloc) the copies are true asynchronous DMA: commit() sends every input but the last up whole on the `up` stream;
+// next_chunk() uploads the last input chunk by chunk, the caller's launch for chunk k runs behind it on the compute stream and the
+// outputs of chunk k go down on the `down` stream while chunk k+1 is still going up.  Buffers of `segs` segments of n elements
+// (d||e: 2) are chunked per segment.
 struct Stage {
     arkmpc_ctx* ctx;
     int rc = ARKMPC_OK;
-    struct In { const void* host; size_t bytes; size_t off; };
+    struct In { const void* host; size_t bytes; size_t off; unsigned segs; };
     std::vector<In> ins;
-    struct OutPlan { void* host; size_t bytes; size_t off; };
+    struct OutPlan { void* host; size_t bytes; size_t off; unsigned segs; };
     std::vector<OutPlan> oplan;
     size_t total = 0;
-    explicit Stage(arkmpc_ctx* c) : ctx(c) {}
+    explicit Stage(arkmpc_ctx* c) : ctx(c), evs(c) {}
+    Stage(const Stage&) = delete;
+    Stage& operator=(const Stage&) = delete;
+    ~Stage() { if (streamed && !drained) drain(); }
 
     static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
     // pass 1 (host mode): declare buffers; pass 2: resolve.  To keep call sites linear we do a
     // two-phase protocol: declare_* returns an index, then commit() uploads, and ptr(i) resolves.
-    int declare_in(const void* p, size_t bytes) {
+    int declare_in(const void* p, size_t bytes, unsigned segs = 1) {
         if (!p && bytes) { rc = ark_bad(ctx, "null input pointer"); }
-        ins.push_back({p, bytes, total}); total += align_up(bytes);
+        ins.push_back({p, bytes, total, segs}); total += align_up(bytes);
         return (int)ins.size() - 1;
     }
-    int declare_out(void* p, size_t bytes) {
+    int declare_out(void* p, size_t bytes, unsigned segs = 1) {
         if (!p && bytes) { rc = ark_bad(ctx, "null output pointer"); }
-        oplan.push_back({p, bytes, total}); total += align_up(bytes);
+        oplan.push_back({p, bytes, total, segs}); total += align_up(bytes);
         return (int)oplan.size() - 1;
     }
     // device-only scratch (both buffer modes): carved from the arena
@@ -135,8 +277,84 @@ struct Stage {
     template <class T> T* scratch(int idx) const {
         return (T*)(ctx->arena + (ctx->host_buffers ? total : 0) + scratch_off[idx]);
     }
+
+    // ---- elementwise protocol ---------------------------------------------------------------------------------------------------
+    bool ew = false, streamed = false, drained = false, chunk_open = false;
+    size_t ew_n = 0, chunk_i = 0, cur_lo = 0, cur_cnt = 0;
+    std::vector<std::pair<size_t, size_t>> chunks;
+    LinkEvents evs;
+    void elementwise(size_t n) { ew = true; ew_n = n; }
+    static size_t stream_min_bytes() {       // below this the whole-batch protocol is as fast and has less to set up
+        static const size_t v = getenv("ARKMPC_STREAM_MIN_MB") ? (size_t)atoll(getenv("ARKMPC_STREAM_MIN_MB")) << 20 : (size_t)8 << 20;
+        return v;
+    }
+    static bool stream_enabled() { static const bool on = !(getenv("ARKMPC_NO_STREAM") && getenv("ARKMPC_NO_STREAM")[0] == '1'); return on; }
+
+    int fail_hip(hipError_t e, const char* what) { ark_set_err(ctx, std::string(what) + ": " + hipGetErrorString(e)); return rc = ARKMPC_ERR_HIP; }
+    // one chunk [lo, lo + cnt) of a declared buffer, segment by segment
+    template <class B> int copy_chunk(const B& b, size_t lo, size_t cnt, bool up) {
+        const size_t eb = b.bytes / ((size_t)b.segs * ew_n);
+        for (unsigned sg = 0; sg < b.segs; ++sg) {
+            const size_t o = ((size_t)sg * ew_n + lo) * eb;
+            hipError_t e = up ? hipMemcpyAsync(ctx->arena + b.off + o, (const char*)b.host + o, cnt * eb, hipMemcpyHostToDevice, ctx->up)
+                              : hipMemcpyAsync((char*)b.host + o, ctx->arena + b.off + o, cnt * eb, hipMemcpyDeviceToHost, ctx->down);
+            if (e != hipSuccess) return fail_hip(e, up ? "H2D" : "D2H");
+        }
+        return ARKMPC_OK;
+    }
+    int commit_streamed() {
+        if ((rc = arena_reserve(ctx, total + scratch_total))) return rc;
+        if ((rc = link_ensure(ctx))) return rc;
+        streamed = true;
+        if ((rc = evs.edge(ctx->stream, ctx->up))) return rc;        // the arena's last user ran on the compute stream
+        for (size_t i = 0; i + 1 < ins.size(); ++i) {
+            hipError_t e = hipMemcpyAsync(ctx->arena + ins[i].off, ins[i].host, ins[i].bytes, hipMemcpyHostToDevice, ctx->up);
+            if (e != hipSuccess) return fail_hip(e, "H2D");
+        }
+        chunks = stream_chunks(ew_n);
+        return ARKMPC_OK;
+    }
+    int close_chunk() {
+        chunk_open = false;
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail_hip(le, "kernel launch");
+        if ((rc = evs.edge(ctx->stream, ctx->down))) return rc;
+        for (auto& o : oplan) if (copy_chunk(o, cur_lo, cur_cnt, false)) return rc;
+        return ARKMPC_OK;
+    }
+    bool next_chunk(size_t* lo, size_t* cnt) {
+        if (rc) return false;
+        if (!streamed) {                                    // device pointers, or a host batch staged whole: one chunk
+            if (chunk_i++ == 0 && ew_n) { *lo = 0; *cnt = ew_n; return true; }
+            return false;
+        }
+        if (chunk_open && close_chunk()) return false;
+        if (chunk_i == chunks.size()) return false;
+        cur_lo = chunks[chunk_i].first; cur_cnt = chunks[chunk_i].second; ++chunk_i;
+        if (!ins.empty() && copy_chunk(ins.back(), cur_lo, cur_cnt, true)) return false;
+        if ((rc = evs.edge(ctx->up, ctx->stream))) return false;
+        chunk_open = true;
+        *lo = cur_lo; *cnt = cur_cnt;
+        return true;
+    }
+    int drain() {
+        drained = true;
+        hipError_t e1 = hipStreamSynchronize(ctx->up), e2 = hipStreamSynchronize(ctx->stream), e3 = hipStreamSynchronize(ctx->down);
+        evs.give_back();
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+            if (!rc) fail_hip(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "streamed call");
+        }
+        return rc;
+    }
+
     int commit() {
         if (rc) return rc;
+        if (ew && ctx->host_buffers && stream_enabled() && ew_n && total >= stream_min_bytes()) {
+            bool go = true;                                  // every buffer: segs x n elements of a whole number of bytes, and pinned by the caller
+            for (auto& i : ins) go = go && i.bytes % ((size_t)i.segs * ew_n) == 0 && (i.bytes < ((size_t)1 << 20) || runtime_knows(i.host));
+            for (auto& o : oplan) go = go && o.bytes % ((size_t)o.segs * ew_n) == 0 && (o.bytes < ((size_t)1 << 20) || runtime_knows(o.host));
+            if (go) return commit_streamed();
+        }
         if (scratch_total) {
             rc = arena_reserve(ctx, (ctx->host_buffers ? total : 0) + scratch_total);
             if (rc) return rc;
@@ -163,6 +381,10 @@ struct Stage {
     }
     // download outputs (host mode) and, in host mode, block until they have landed
     int finish() {
+        if (streamed) {
+            if (!rc && chunk_open) close_chunk();
+            return drain();
+        }
         if (rc) return rc;
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { ark_set_err(ctx, std::string("kernel launch: ") + hipGetErrorString(le)); return ARKMPC_ERR_HIP; }

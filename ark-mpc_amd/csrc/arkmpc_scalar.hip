@@ -872,15 +872,17 @@ static int scalar_binop(arkmpc_ctx* ctx, int op, size_t n, const uint64_t* a, co
     ENTER(ctx);
     Stage st(ctx);
     int ia = st.declare_in(a, n * 32), ib = st.declare_in(b, n * 32), io = st.declare_out(out, n * 32);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
-        const u64 *da = st.in<u64>(ia), *db = st.in<u64>(ib);
-        u64* dout = st.out<u64>(io);
-        dim3 g(blocks_for(n, TPB)), t(TPB);
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
+        const u64 *da = st.in<u64>(ia) + 4 * lo, *db = st.in<u64>(ib) + 4 * lo;
+        u64* dout = st.out<u64>(io) + 4 * lo;
+        dim3 g(blocks_for(cnt, TPB)), t(TPB);
         DISPATCH_FIELD(ctx, {
-            if (op == OP_ADD) hipLaunchKernelGGL((k_scalar_binop<F, OP_ADD>), g, t, 0, ctx->stream, n, da, db, dout);
-            if (op == OP_SUB) hipLaunchKernelGGL((k_scalar_binop<F, OP_SUB>), g, t, 0, ctx->stream, n, da, db, dout);
-            if (op == OP_MUL) hipLaunchKernelGGL((k_scalar_binop<F, OP_MUL>), g, t, 0, ctx->stream, n, da, db, dout);
+            if (op == OP_ADD) hipLaunchKernelGGL((k_scalar_binop<F, OP_ADD>), g, t, 0, ctx->stream, cnt, da, db, dout);
+            if (op == OP_SUB) hipLaunchKernelGGL((k_scalar_binop<F, OP_SUB>), g, t, 0, ctx->stream, cnt, da, db, dout);
+            if (op == OP_MUL) hipLaunchKernelGGL((k_scalar_binop<F, OP_MUL>), g, t, 0, ctx->stream, cnt, da, db, dout);
         });
     }
     return st.finish();
@@ -894,15 +896,18 @@ static int scalar_unop(arkmpc_ctx* ctx, int which, size_t n, const uint64_t* a, 
     ENTER(ctx);
     Stage st(ctx);
     int ia = st.declare_in(a, n * 32), io = st.declare_out(out, n * out_elem_bytes);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
-        const u64* da = st.in<u64>(ia);
-        dim3 g(blocks_for(n, TPB)), t(TPB);
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
+        const u64* da = st.in<u64>(ia) + 4 * lo;
+        unsigned char* dout = st.out<unsigned char>(io) + out_elem_bytes * lo;
+        dim3 g(blocks_for(cnt, TPB)), t(TPB);
         DISPATCH_FIELD(ctx, {
-            if (which == 0) hipLaunchKernelGGL((k_scalar_neg<F>), g, t, 0, ctx->stream, n, da, st.out<u64>(io));
-            if (which == 1) hipLaunchKernelGGL((k_from_canonical<F>), g, t, 0, ctx->stream, n, da, st.out<u64>(io));
-            if (which == 2) hipLaunchKernelGGL((k_to_canonical<F>), g, t, 0, ctx->stream, n, da, st.out<u64>(io));
-            if (which == 3) hipLaunchKernelGGL((k_to_bytes_be<F>), g, t, 0, ctx->stream, n, da, st.out<unsigned char>(io));
+            if (which == 0) hipLaunchKernelGGL((k_scalar_neg<F>), g, t, 0, ctx->stream, cnt, da, (u64*)dout);
+            if (which == 1) hipLaunchKernelGGL((k_from_canonical<F>), g, t, 0, ctx->stream, cnt, da, (u64*)dout);
+            if (which == 2) hipLaunchKernelGGL((k_to_canonical<F>), g, t, 0, ctx->stream, cnt, da, (u64*)dout);
+            if (which == 3) hipLaunchKernelGGL((k_to_bytes_be<F>), g, t, 0, ctx->stream, cnt, da, dout);
         });
     }
     return st.finish();
@@ -979,13 +984,17 @@ static int share_binop(arkmpc_ctx* ctx, int op, size_t n, const uint64_t* a, con
     ENTER(ctx);
     Stage st(ctx);
     int ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64), io = st.declare_out(out, n * 64);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
-        dim3 g(blocks_for(n, TPB)), t(TPB);
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
+        const dim3 t(TPB);
+        const u64 *da = st.in<u64>(ia) + 8 * lo, *db = st.in<u64>(ib) + 8 * lo;
+        u64* dout = st.out<u64>(io) + 8 * lo;
         DISPATCH_FIELD(ctx, {
-            const dim3 g2(blocks_for(2 * n, TPB));                // one thread per field element: 2n of them
-            if (op == OP_ADD) hipLaunchKernelGGL((k_scalar_binop<F, OP_ADD>), g2, t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
-            if (op == OP_SUB) hipLaunchKernelGGL((k_scalar_binop<F, OP_SUB>), g2, t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.in<u64>(ib), st.out<u64>(io));
+            const dim3 g2(blocks_for(2 * cnt, TPB));              // one thread per field element: 2 per share
+            if (op == OP_ADD) hipLaunchKernelGGL((k_scalar_binop<F, OP_ADD>), g2, t, 0, ctx->stream, 2 * cnt, da, db, dout);
+            if (op == OP_SUB) hipLaunchKernelGGL((k_scalar_binop<F, OP_SUB>), g2, t, 0, ctx->stream, 2 * cnt, da, db, dout);
         });
     }
     return st.finish();
@@ -997,28 +1006,33 @@ int arkmpc_share_neg(arkmpc_ctx* ctx, size_t n, const uint64_t* a, uint64_t* out
     ENTER(ctx);
     Stage st(ctx);
     int ia = st.declare_in(a, n * 64), io = st.declare_out(out, n * 64);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        (void)g;
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_scalar_neg<F>), dim3(blocks_for(2 * n, TPB)), t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.out<u64>(io)));
-    }
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt))
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_scalar_neg<F>), dim3(blocks_for(2 * cnt, TPB)), dim3(TPB), 0, ctx->stream, 2 * cnt, st.in<u64>(ia) + 8 * lo, st.out<u64>(io) + 8 * lo));
     return st.finish();
 }
 int arkmpc_share_split(arkmpc_ctx* ctx, size_t n, const uint64_t* aos, uint64_t* out_share_col, uint64_t* out_mac_col) {
     ENTER(ctx);
     Stage st(ctx);
     int ia = st.declare_in(aos, n * 64), is = st.declare_out(out_share_col, n * 32), im = st.declare_out(out_mac_col, n * 32);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_share_split, dim3(blocks_for(n, TPB)), dim3(TPB), 0, ctx->stream, n, st.in<u64>(ia), st.out<u64>(is), st.out<u64>(im));
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt))
+        hipLaunchKernelGGL(k_share_split, dim3(blocks_for(cnt, TPB)), dim3(TPB), 0, ctx->stream, cnt, st.in<u64>(ia) + 8 * lo, st.out<u64>(is) + 4 * lo, st.out<u64>(im) + 4 * lo);
     return st.finish();
 }
 int arkmpc_share_join(arkmpc_ctx* ctx, size_t n, const uint64_t* share_col, const uint64_t* mac_col, uint64_t* out_aos) {
     ENTER(ctx);
     Stage st(ctx);
     int is = st.declare_in(share_col, n * 32), im = st.declare_in(mac_col, n * 32), io = st.declare_out(out_aos, n * 64);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) hipLaunchKernelGGL(k_share_join, dim3(blocks_for(n, TPB)), dim3(TPB), 0, ctx->stream, n, st.in<u64>(is), st.in<u64>(im), st.out<u64>(io));
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt))
+        hipLaunchKernelGGL(k_share_join, dim3(blocks_for(cnt, TPB)), dim3(TPB), 0, ctx->stream, cnt, st.in<u64>(is) + 4 * lo, st.in<u64>(im) + 4 * lo, st.out<u64>(io) + 8 * lo);
     return st.finish();
 }
 int arkmpc_fill(arkmpc_ctx* ctx, size_t n, size_t words, const uint64_t* record, uint64_t* out) {
@@ -1038,11 +1052,11 @@ int arkmpc_share_extract(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint
     ENTER(ctx);
     Stage st(ctx);
     int ia = st.declare_in(shares, n * 64), io = st.declare_out(out, n * 32);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_extract<F>), g, t, 0, ctx->stream, n, st.in<u64>(ia), st.out<u64>(io)));
-    }
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt))
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_extract<F>), dim3(blocks_for(cnt, TPB)), dim3(TPB), 0, ctx->stream, cnt, st.in<u64>(ia) + 8 * lo, st.out<u64>(io) + 4 * lo));
     return st.finish();
 }
 
@@ -1053,15 +1067,18 @@ static int share_addsub_public(arkmpc_ctx* ctx, bool sub, size_t n, int party, c
     if (!key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int ia = st.declare_in(a, n * 64), ip = st.declare_in(pub, n * 32), io = st.declare_out(out, n * 64);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
         Fe k = fe_from_host(key);
-        dim3 g(blocks_for(n, TPB)), t(TPB);
+        const dim3 t(TPB);
+        const u64 *da = st.in<u64>(ia) + 8 * lo, *dp = st.in<u64>(ip) + 4 * lo;
+        u64* dout = st.out<u64>(io) + 8 * lo;
         DISPATCH_FIELD(ctx, {
-            const dim3 g2(blocks_for(2 * n, TPB));
-            (void)g;
-            if (sub) hipLaunchKernelGGL((k_share_addsub_public_flat<F, true>), g2, t, 0, ctx->stream, 2 * n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
-            else hipLaunchKernelGGL((k_share_addsub_public_flat<F, false>), g2, t, 0, ctx->stream, 2 * n, party, k, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io));
+            const dim3 g2(blocks_for(2 * cnt, TPB));
+            if (sub) hipLaunchKernelGGL((k_share_addsub_public_flat<F, true>), g2, t, 0, ctx->stream, 2 * cnt, party, k, da, dp, dout);
+            else hipLaunchKernelGGL((k_share_addsub_public_flat<F, false>), g2, t, 0, ctx->stream, 2 * cnt, party, k, da, dp, dout);
         });
     }
     return st.finish();
@@ -1076,12 +1093,12 @@ int arkmpc_share_mul_public(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const 
     ENTER(ctx);
     Stage st(ctx);
     int ia = st.declare_in(a, n * 64), ip = st.declare_in(pub, n * 32), io = st.declare_out(out, n * 64);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        (void)g;
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_mul_public_flat<F>), dim3(blocks_for(2 * n, TPB)), t, 0, ctx->stream, 2 * n, st.in<u64>(ia), st.in<u64>(ip), st.out<u64>(io)));
-    }
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt))
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_share_mul_public_flat<F>), dim3(blocks_for(2 * cnt, TPB)), dim3(TPB), 0, ctx->stream, 2 * cnt, st.in<u64>(ia) + 8 * lo,
+                                               st.in<u64>(ip) + 4 * lo, st.out<u64>(io) + 8 * lo));
     return st.finish();
 }
 
@@ -1151,13 +1168,13 @@ int arkmpc_beaver_mask(arkmpc_ctx* ctx, size_t n, const uint64_t* x, const uint6
     ENTER(ctx);
     Stage st(ctx);
     int ix = st.declare_in(x, n * 64), iy = st.declare_in(y, n * 64), ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64);
-    int io = st.declare_out(out_de, 2 * n * 32);
+    int io = st.declare_out(out_de, 2 * n * 32, 2);            // two segments of n Scalars: d, then e
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        Col cx{st.in<u64>(ix), 8}, cy{st.in<u64>(iy), 8}, ca{st.in<u64>(ia), 8}, cb{st.in<u64>(ib), 8};
-        (void)g; (void)t;
-        DISPATCH_FIELD(ctx, launch_mask<F>(ctx, n, cx, cy, ca, cb, st.out<u64>(io)));
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
+        Col cx{st.in<u64>(ix) + 8 * lo, 8}, cy{st.in<u64>(iy) + 8 * lo, 8}, ca{st.in<u64>(ia) + 8 * lo, 8}, cb{st.in<u64>(ib) + 8 * lo, 8};
+        DISPATCH_FIELD(ctx, launch_mask<F>(ctx, cnt, cx, cy, ca, cb, st.out<u64>(io) + 4 * lo, st.out<u64>(io) + 4 * (n + lo)));
     }
     return st.finish();
 }
@@ -1170,14 +1187,16 @@ int arkmpc_beaver_finish(arkmpc_ctx* ctx, size_t n, int party_id, const uint64_t
     Stage st(ctx);
     int id = st.declare_in(d, n * 32), ie = st.declare_in(e, n * 32);
     int ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64), ic = st.declare_in(c, n * 64), io = st.declare_out(out, n * 64);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
         Fe k = fe_from_host(mac_key);
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        const u64 *pa = st.in<u64>(ia), *pb = st.in<u64>(ib), *pc = st.in<u64>(ic);
-        u64* po = st.out<u64>(io);
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_finish<F, false>), g, t, 0, ctx->stream, n, party_id, k, st.in<u64>(id),
-                                               st.in<u64>(ie), (const u64*)nullptr, (const u64*)nullptr, Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8}, Col{pb + 4, 8},
+        dim3 g(blocks_for(cnt, TPB)), t(TPB);
+        const u64 *pa = st.in<u64>(ia) + 8 * lo, *pb = st.in<u64>(ib) + 8 * lo, *pc = st.in<u64>(ic) + 8 * lo;
+        u64* po = st.out<u64>(io) + 8 * lo;
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_beaver_finish<F, false>), g, t, 0, ctx->stream, cnt, party_id, k, st.in<u64>(id) + 4 * lo,
+                                               st.in<u64>(ie) + 4 * lo, (const u64*)nullptr, (const u64*)nullptr, Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8}, Col{pb + 4, 8},
                                                Col{pc, 8}, Col{pc + 4, 8}, ColOut{po, 8}, ColOut{po + 4, 8}));
     }
     return st.finish();
@@ -1189,17 +1208,18 @@ int arkmpc_beaver_finish_fused(arkmpc_ctx* ctx, size_t n, int party_id, const ui
     if (!party_ok(party_id)) return ark_bad(ctx, "party_id must be 0 or 1");
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
-    int i0 = st.declare_in(my_de, 2 * n * 32), i1 = st.declare_in(peer_de, 2 * n * 32);
+    int i0 = st.declare_in(my_de, 2 * n * 32, 2), i1 = st.declare_in(peer_de, 2 * n * 32, 2);
     int ia = st.declare_in(a, n * 64), ib = st.declare_in(b, n * 64), ic = st.declare_in(c, n * 64), io = st.declare_out(out, n * 64);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
         Fe k = fe_from_host(mac_key);
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        const u64 *pa = st.in<u64>(ia), *pb = st.in<u64>(ib), *pc = st.in<u64>(ic);
-        u64* po = st.out<u64>(io);
-        (void)g; (void)t;
-        DISPATCH_FIELD(ctx, launch_finish_fused<F>(ctx, n, party_id, k, st.in<u64>(i0), st.in<u64>(i1), Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8},
-                                                   Col{pb + 4, 8}, Col{pc, 8}, Col{pc + 4, 8}, ColOut{po, 8}, ColOut{po + 4, 8}));
+        const u64 *pa = st.in<u64>(ia) + 8 * lo, *pb = st.in<u64>(ib) + 8 * lo, *pc = st.in<u64>(ic) + 8 * lo;
+        u64* po = st.out<u64>(io) + 8 * lo;
+        const u64 *myde = st.in<u64>(i0), *prde = st.in<u64>(i1);
+        DISPATCH_FIELD(ctx, launch_finish_fused<F>(ctx, cnt, party_id, k, myde + 4 * lo, prde + 4 * lo, Col{pa, 8}, Col{pa + 4, 8}, Col{pb, 8},
+                                                   Col{pb + 4, 8}, Col{pc, 8}, Col{pc + 4, 8}, ColOut{po, 8}, ColOut{po + 4, 8}, myde + 4 * (n + lo), prde + 4 * (n + lo)));
     }
     return st.finish();
 }
@@ -1301,12 +1321,14 @@ int arkmpc_mac_check_shares(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[4]
     if (!mac_key) return ark_bad(ctx, "null mac_key");
     Stage st(ctx);
     int iv = st.declare_in(opened, n * 32), is = st.declare_in(shares, n * 64), io = st.declare_out(out_chk, n * 32);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
         Fe k = fe_from_host(mac_key);
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_mac_check<F, false>), g, t, 0, ctx->stream, n, k, st.in<u64>(iv), st.in<u64>(is),
-                                               (const u64*)nullptr, (u64*)nullptr, st.out<u64>(io)));
+        dim3 g(blocks_for(cnt, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_mac_check<F, false>), g, t, 0, ctx->stream, cnt, k, st.in<u64>(iv) + 4 * lo, st.in<u64>(is) + 8 * lo,
+                                               (const u64*)nullptr, (u64*)nullptr, st.out<u64>(io) + 4 * lo));
     }
     return st.finish();
 }
@@ -1317,12 +1339,14 @@ int arkmpc_open_and_mac_check(arkmpc_ctx* ctx, size_t n, const uint64_t mac_key[
     Stage st(ctx);
     int is = st.declare_in(shares, n * 64), ip = st.declare_in(peer, n * 32);
     int iv = st.declare_out(out_opened, n * 32), io = st.declare_out(out_chk, n * 32);
+    st.elementwise(n);
     if (st.commit()) return st.rc;
-    if (n) {
+    size_t lo, cnt;
+    while (st.next_chunk(&lo, &cnt)) {
         Fe k = fe_from_host(mac_key);
-        dim3 g(blocks_for(n, TPB)), t(TPB);
-        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_mac_check<F, true>), g, t, 0, ctx->stream, n, k, (const u64*)nullptr, st.in<u64>(is),
-                                               st.in<u64>(ip), st.out<u64>(iv), st.out<u64>(io)));
+        dim3 g(blocks_for(cnt, TPB)), t(TPB);
+        DISPATCH_FIELD(ctx, hipLaunchKernelGGL((k_mac_check<F, true>), g, t, 0, ctx->stream, cnt, k, (const u64*)nullptr, st.in<u64>(is) + 8 * lo,
+                                               st.in<u64>(ip) + 4 * lo, st.out<u64>(iv) + 4 * lo, st.out<u64>(io) + 4 * lo));
     }
     return st.finish();
 }

@@ -240,3 +240,120 @@ def test_hostmul_config2_all_2p20_gates_bitexact(pkg, oracle):
         bad = np.nonzero((out[p].reshape(n, 8) != want[p].reshape(n, 8)).any(axis=1))[0]
         assert bad.size == 0, "party %d: %d of %d gates differ, first at %d" % (p, bad.size, n, bad[0])
     e.close()
+
+
+# ---- host-buffer contexts (arkmpc_ctx_set_host_buffers): large elementwise calls on buffers the caller has pinned run the streamed staging
+# ---- of csrc/arkmpc_internal.hpp (last input + kernels + downloads pipelined chunk by chunk); pageable or small ones the whole-batch staging
+def _tile(arr, words, n):
+    m = arr.size // words
+    return np.ascontiguousarray(np.tile(arr.reshape(m, words), (-(-n // m), 1))[:n].reshape(-1))
+
+
+class _PinnedArena:
+    """numpy arrays in memory pinned through the C ABI (arkmpc_host_alloc), so that host-buffer calls take the streamed path"""
+
+    def __init__(self, pkg):
+        self.lib = pkg.load_library()
+        self.ptrs = []
+
+    def zeros(self, nwords, dtype=np.uint64):
+        q = ctypes.c_void_p()
+        nbytes = max(16, nwords * np.dtype(dtype).itemsize)
+        assert self.lib.arkmpc_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(q)) == 0
+        self.ptrs.append(q)
+        ct = ctypes.c_uint64 if dtype == np.uint64 else ctypes.c_uint8
+        a = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ct)), shape=(nwords,))
+        a[:] = 0
+        return a
+
+    def copy(self, arr):
+        a = self.zeros(arr.size, arr.dtype)
+        a[:] = arr
+        return a
+
+    def free(self):
+        for q in self.ptrs:
+            self.lib.arkmpc_host_free(q)
+        self.ptrs = []
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("n", [150001])
+def test_host_buffer_mode_large_ops_vs_oracle(pkg, oracle, fid, n, pinned):
+    """every elementwise entry point at a size above the streaming threshold (ragged last chunk), host buffers, == oracle: pinned buffers take
+    the three-stream pipeline, pageable numpy buffers the whole-batch staging"""
+    e = pkg.Engine(fid, device=0, host_buffers=True)
+    arena = _PinnedArena(pkg)
+    z = (lambda cnt, w: arena.zeros(cnt * w)) if pinned else (lambda cnt, w: np.zeros(cnt * w, dtype=np.uint64))
+    H = arena.copy if pinned else (lambda arr: arr)
+    base = 2048
+    a = H(_tile(mont_array(fid, mixed_values(fid, base, 1)), 4, n))
+    b = H(_tile(mont_array(fid, rand_values(fid, base - 1, 2)), 4, n))         # a different period: pairs differ along the batch
+    for name, ora in (("scalar_add", oracle.scalar_add), ("scalar_sub", oracle.scalar_sub), ("scalar_mul", oracle.scalar_mul), ("open_combine", oracle.open_combine)):
+        out = z(n, 4); getattr(e, name)(n, a, b, out)
+        assert np.array_equal(out, ora(fid, a, b)), name
+    out = z(n, 4); e.scalar_neg(n, a, out); assert np.array_equal(out, oracle.scalar_neg(fid, a))
+    out = z(n, 4); e.scalar_to_canonical(n, a, out); assert np.array_equal(out, oracle.to_canonical(fid, a))
+    outb = arena.zeros(32 * n, np.uint8) if pinned else np.zeros(32 * n, dtype=np.uint8)
+    e.scalar_to_bytes_be(n, a, outb); assert np.array_equal(outb, oracle.to_bytes_be(fid, a))
+    _, keys, sh = _inputs(fid, n, seed=300 + fid, tile_from=base)
+    sh = {k: (H(v[0]), H(v[1])) for k, v in sh.items()}
+    sa, sb = sh["x"][0], sh["y"][1]
+    out = z(n, 8); e.share_add(n, sa, sb, out); assert np.array_equal(out, oracle.share_add(fid, sa, sb))
+    out = z(n, 8); e.share_sub(n, sa, sb, out); assert np.array_equal(out, oracle.share_sub(fid, sa, sb))
+    out = z(n, 8); e.share_neg(n, sa, out); assert np.array_equal(out, oracle.share_neg(fid, sa))
+    out = z(n, 8); e.share_mul_public(n, sa, b, out); assert np.array_equal(out, oracle.share_mul_public(fid, sa, b))
+    for party in (0, 1):
+        out = z(n, 8); e.share_add_public(n, party, keys[party], sa, b, out)
+        assert np.array_equal(out, oracle.share_add_public(fid, party, keys[party], sa, b))
+        out = z(n, 8); e.share_sub_public(n, party, keys[party], sa, b, out)
+        assert np.array_equal(out, oracle.share_add_public(fid, party, keys[party], sa, b, sub=True))
+    out = z(n, 4); e.share_extract(n, sa, out); assert np.array_equal(out.reshape(-1, 4), sa.reshape(-1, 8)[:, :4])
+    s_col, m_col = z(n, 4), z(n, 4); e.share_split(n, sa, s_col, m_col)
+    assert np.array_equal(s_col.reshape(-1, 4), sa.reshape(-1, 8)[:, :4]) and np.array_equal(m_col.reshape(-1, 4), sa.reshape(-1, 8)[:, 4:])
+    out = z(n, 8); e.share_join(n, s_col, m_col, out); assert np.array_equal(out, sa)
+    # Beaver multiplication through the two staged calls (a, b and d||e go up again for K2+K3: the sessions above avoid that)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    opened = oracle.open_combine(fid, ode[0], ode[1])
+    ode_h = [H(ode[0]), H(ode[1])]
+    for party in (0, 1):
+        de = z(2 * n, 4); e.beaver_mask(n, sh["x"][party], sh["y"][party], sh["a"][party], sh["b"][party], de)
+        assert np.array_equal(de, ode[party])
+        out = z(n, 8); e.beaver_finish_fused(n, party, keys[party], ode_h[party], ode_h[1 - party], sh["a"][party], sh["b"][party], sh["c"][party], out)
+        assert np.array_equal(out, want[party])
+        out = z(n, 8); e.beaver_finish(n, party, keys[party], H(opened[:4 * n].copy()), H(opened[4 * n:].copy()), sh["a"][party], sh["b"][party], sh["c"][party], out)
+        assert np.array_equal(out, want[party])
+    # batch open + MAC-check shares
+    mine = [H(np.ascontiguousarray(sh["x"][p].reshape(-1, 8)[:, :4].reshape(-1))) for p in (0, 1)]
+    for party in (0, 1):
+        o, c = z(n, 4), z(n, 4)
+        e.open_and_mac_check(n, keys[party], sh["x"][party], mine[1 - party], o, c)
+        o_ref = oracle.open_combine(fid, np.array(mine[party]), np.array(mine[1 - party]))
+        c_ref = oracle.mac_check_shares(fid, keys[party], o_ref, np.array(sh["x"][party]))
+        assert np.array_equal(o, o_ref) and np.array_equal(c, c_ref)
+        c2 = z(n, 4); e.mac_check_shares(n, keys[party], H(o_ref), sh["x"][party], c2)
+        assert np.array_equal(c2, c_ref)
+    e.close()
+    del a, b, sh, sa, sb, mine, ode_h, de, out, o, c, c2, s_col, m_col, outb
+    arena.free()
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_buffer_mode_in_place_and_repeated_operands(pkg, oracle, pinned):
+    """out aliases an input (ScalarResult ops are often written in place by callers), and one vector passed twice"""
+    fid, n = 0, 300000
+    e = pkg.Engine(fid, device=0, host_buffers=True)
+    arena = _PinnedArena(pkg)
+    a0 = _tile(mont_array(fid, mixed_values(fid, 1000, 9)), 4, n)
+    want = oracle.scalar_mul(fid, a0, a0)
+    a = arena.copy(a0) if pinned else a0
+    out = arena.zeros(4 * n) if pinned else np.zeros(4 * n, dtype=np.uint64)
+    e.scalar_mul(n, a, a, out)
+    assert np.array_equal(out, want)
+    buf = arena.copy(a0) if pinned else a0.copy()
+    e.scalar_mul(n, buf, buf, buf)
+    assert np.array_equal(buf, want)
+    e.close()
+    del a, out, buf
+    arena.free()
