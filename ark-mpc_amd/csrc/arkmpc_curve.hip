@@ -758,7 +758,7 @@ __global__ void __launch_bounds__(TPB_EC) k_g1_smul_finish(u32 n, const u64* poi
 #define G1_ASM_WS_BYTES (16 * G1_ASM29_JT_STRIDE + G1_ASM_TABLE * 64 + G1_ASM_STEPS * 4 + 96 + 32 + 8)
 static inline G1AsmWs g1_asm_carve(char* base, size_t n) {
     G1AsmWs w;
-    w.jtab = (u64*)base; base += n * 16 * G1_ASM29_JT_STRIDE;     // 112 B per entry for the 29-bit table kernel, 96 used otherwise
+    w.jtab = (u64*)base; base += n * 16 * G1_ASM29_JT_STRIDE;     // G1_ASM29_JT_STRIDE = 128 B per entry for the 29-bit table kernel (112 used), 96 used otherwise
     w.tab = (u64*)base; base += n * G1_ASM_TABLE * 64;
     w.res = (u64*)base; base += n * 96;
     w.zc = (u64*)base; base += n * 32;

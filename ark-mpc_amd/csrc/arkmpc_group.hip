@@ -29,6 +29,7 @@ struct arkmpc_group {
     std::vector<int> dev;
     std::vector<unsigned char> peer;          // peer[from * G + to] = 1: `from` may address `to`'s memory
     std::vector<hipEvent_t> ev;               // one per member: "my pushes are done"
+    std::vector<hipEvent_t> wev;              // one per member: "what I had queued on the buffer you are about to overwrite is done"
     std::mutex mu;                            // group calls are serialised
     std::mutex err_mu;
     std::string err;
@@ -81,6 +82,14 @@ int push(arkmpc_group* g, int from, int to, void* dst, const void* src, size_t b
     else GHIP(g, hipMemcpyPeerAsync(dst, g->dev[to], src, g->dev[from], bytes, st));
     return ARKMPC_OK;
 }
+// write-after-read ordering of a cross-member write: whatever member `to` has already queued (a kernel of the previous round still reading
+// the destination buffer) must finish before any source member starts writing into it: every source stream waits for `to`'s stream.
+int sources_wait_for(arkmpc_group* g, int to) {
+    GHIP(g, hipSetDevice(g->dev[to]));
+    GHIP(g, hipEventRecord(g->wev[to], g->ctx[to]->stream));
+    for (int m = 0; m < g->G; ++m) if (m != to) { GHIP(g, hipSetDevice(g->dev[m])); GHIP(g, hipStreamWaitEvent(g->ctx[m]->stream, g->wev[to], 0)); }
+    return ARKMPC_OK;
+}
 int shards_ok(arkmpc_group* g, size_t n, const void* const* shards, const char* what) {
     if (!shards) return gbad(g, what);
     for (int m = 0; m < g->G; ++m) {
@@ -106,12 +115,14 @@ int arkmpc_group_create(int field_id, int n_devices, const int* device_ids, arkm
     g->dev.assign(device_ids, device_ids + n_devices);
     g->ctx.assign(n_devices, nullptr);
     g->ev.assign(n_devices, nullptr);
+    g->wev.assign(n_devices, nullptr);
     g->pin.assign(2 * n_devices, nullptr); g->dstage.assign(2 * n_devices, nullptr); g->cev.assign(2 * n_devices, nullptr);
     g->peer.assign((size_t)n_devices * n_devices, 0);
     int rc = ARKMPC_OK;
     for (int i = 0; i < n_devices && rc == ARKMPC_OK; ++i) {
         rc = arkmpc_ctx_create(field_id, device_ids[i], &g->ctx[i]);
-        if (rc == ARKMPC_OK && (hipSetDevice(device_ids[i]) != hipSuccess || hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess)) rc = ARKMPC_ERR_HIP;
+        if (rc == ARKMPC_OK && (hipSetDevice(device_ids[i]) != hipSuccess || hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess ||
+                                hipEventCreateWithFlags(&g->wev[i], hipEventDisableTiming) != hipSuccess)) rc = ARKMPC_ERR_HIP;
     }
     // peer mappings between every pair of DISTINCT devices (xGMI is a full mesh inside a node); a refusal is recorded, not fatal:
     // copies then fall back to what hipMemcpyPeerAsync does without a mapping, and the *_gathered forms to local + gather
@@ -142,6 +153,7 @@ int arkmpc_group_destroy(arkmpc_group* g) {
             if (g->cev[2 * i + s]) (void)hipEventDestroy(g->cev[2 * i + s]);
         }
         if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+        if (g->wev[i]) (void)hipEventDestroy(g->wev[i]);
     }
     for (int i = 0; i < g->G; ++i) if (g->ctx[i]) arkmpc_ctx_destroy(g->ctx[i]);
     delete g;
@@ -170,6 +182,24 @@ int arkmpc_group_sync(arkmpc_group* g) {
     if (!g) return ARKMPC_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(g->mu);
     for (int m = 0; m < g->G; ++m) GCALL(g, m, arkmpc_sync(g->ctx[m]));
+    return ARKMPC_OK;
+}
+
+// Ordering between TWO groups built on the same devices (the two parties of an in-process run hand each other shard pointers member by
+// member): member m of `grp` waits -- on the device -- for everything member m of `producer` has submitted so far.  One call per edge of
+// the protocol: after the producer's K1 and before this group's K2+K3 (read after write of the d||e shards), and after this group's K2+K3
+// before the producer's next K1 overwrites them (write after read).
+int arkmpc_group_wait_group(arkmpc_group* g, arkmpc_group* producer) {
+    if (!g || !producer) return ARKMPC_ERR_BAD_ARG;
+    if (g == producer) return ARKMPC_OK;
+    if (g->G != producer->G) return gbad(g, "group_wait_group: the groups differ in size");
+    for (int m = 0; m < g->G; ++m) if (g->dev[m] != producer->dev[m]) return gbad(g, "group_wait_group: member devices differ");
+    std::lock_guard<std::mutex> lk(g->mu);                 // (the event belongs to the waiter: two waiters on one producer do not share it)
+    for (int m = 0; m < g->G; ++m) {
+        GHIP(g, hipSetDevice(g->dev[m]));
+        GHIP(g, hipEventRecord(g->wev[m], producer->ctx[m]->stream));
+        GHIP(g, hipStreamWaitEvent(g->ctx[m]->stream, g->wev[m], 0));
+    }
     return ARKMPC_OK;
 }
 
@@ -295,6 +325,7 @@ int arkmpc_group_gather(arkmpc_group* g, size_t n, size_t segs, size_t elem_word
     int rc = shards_ok(g, n, (const void* const*)shards, "null shard pointer");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
+    if ((rc = sources_wait_for(g, root))) return rc;
     for (int m = 0; m < g->G; ++m) {
         size_t lo, cnt; range(g, n, m, &lo, &cnt);
         for (size_t s = 0; s < segs && cnt; ++s) {
@@ -317,6 +348,7 @@ int arkmpc_group_allgather(arkmpc_group* g, size_t n, size_t segs, size_t elem_w
     if (rc) return rc;
     for (int m = 0; m < g->G; ++m) if (n && !outs[m]) return gbad(g, "null output");
     std::lock_guard<std::mutex> lk(g->mu);
+    for (int to = 0; to < g->G; ++to) if ((rc = sources_wait_for(g, to))) return rc;
     for (int step = 0; step < g->G; ++step)
         for (int m = 0; m < g->G; ++m) {
             const int to = (m + step) % g->G;
@@ -371,6 +403,7 @@ static int group_mask(arkmpc_group* g, int layout, size_t n, const uint64_t* con
     if (!rc && !out_on_root) rc = shards_ok(g, n, (const void* const*)out_de, "null d||e shard");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
+    if (out_on_root && (rc = sources_wait_for(g, root))) return rc;       // the kernels below store into root's buffer
     for (int m = 0; m < g->G; ++m) {
         size_t lo, cnt; range(g, n, m, &lo, &cnt);
         if (!cnt) continue;

@@ -49,6 +49,7 @@ struct arkmpc_ctx {
     // first use, and a free list of timing-disabled events
     hipStream_t up = nullptr, down = nullptr;
     std::vector<hipEvent_t> link_ev;
+    unsigned lds_per_wg = 0;          // hipDeviceAttributeMaxSharedMemoryPerBlock of THIS context's device (queried on first use)
     // kernel timer: event pairs bound to the dispatch of the NEXT K1 / K3 launch (hipExtLaunchKernelGGL)
     static constexpr int kTimerSlots = 64;
     hipEvent_t tev[2 * kTimerSlots] = {};

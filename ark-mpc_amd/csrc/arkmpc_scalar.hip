@@ -495,7 +495,8 @@ static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u
     // (tools/k1_occupancy_probe.sh, 2^20 gates: 8+ / 4 / 3 / 2 / 1 workgroups per CU = 36.5 / 36.0 / 35.9 / 35.1 / 36.0 us): two workgroups per CU for large batches
     static const int k1_lds_env = getenv("ARKMPC_K1_LDS") ? atoi(getenv("ARKMPC_K1_LDS")) : -1;
     // the cap is only applied where a workgroup may own that much LDS (gfx950: 160 KB); elsewhere the launch would fail, so it is dropped
-    static const unsigned lds_per_wg = [] { int v = 0; return hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, 0) == hipSuccess && v > 0 ? (unsigned)v : 65536u; }();
+    if (!ctx->lds_per_wg) { int v = 0; ctx->lds_per_wg = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0 ? (unsigned)v : 65536u; }
+    const unsigned lds_per_wg = ctx->lds_per_wg;
     unsigned k1_lds = k1_lds_env >= 0 ? (unsigned)k1_lds_env : (n >= ((size_t)1 << 16) ? 80000u : 0u);
     if (k1_lds > lds_per_wg) k1_lds = 0;
     switch (split ? k1_nt_mode() : aos_mode) {

@@ -28,12 +28,12 @@ const uint64_t RC[24] = {
     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 }
 
-extern "C" int arkmpc_cpu_has_avx512(void) {
+extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_avx512(void) {
     return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
 }
 
 // absorb `nblocks` full 136-byte blocks (SHA3-256 rate) into the 25-lane state
-extern "C" ARK_T512 void arkmpc_keccak_absorb136_avx512(uint64_t st[25], const unsigned char* data, size_t nblocks) {
+extern "C" __attribute__((visibility("hidden"))) ARK_T512 void arkmpc_keccak_absorb136_avx512(uint64_t st[25], const unsigned char* data, size_t nblocks) {
     const __mmask8 m5 = 0x1F, m2 = 0x03;
     __m512i P0 = _mm512_maskz_loadu_epi64(m5, st), P1 = _mm512_maskz_loadu_epi64(m5, st + 5), P2 = _mm512_maskz_loadu_epi64(m5, st + 10),
             P3 = _mm512_maskz_loadu_epi64(m5, st + 15), P4 = _mm512_maskz_loadu_epi64(m5, st + 20);
@@ -119,15 +119,15 @@ static inline __attribute__((always_inline)) void absorb136_body(uint64_t* A, co
     A[19] = a19; A[20] = a20; A[21] = a21; A[22] = a22; A[23] = a23; A[24] = a24;
 }
 }  // namespace
-extern "C" void arkmpc_keccak_absorb136_scalar(uint64_t st[25], const unsigned char* data, size_t nblocks) { absorb136_body(st, data, nblocks); }
-extern "C" __attribute__((target("bmi,bmi2"))) void arkmpc_keccak_absorb136_bmi(uint64_t st[25], const unsigned char* data, size_t nblocks) {
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_scalar(uint64_t st[25], const unsigned char* data, size_t nblocks) { absorb136_body(st, data, nblocks); }
+extern "C" __attribute__((visibility("hidden"))) __attribute__((target("bmi,bmi2"))) void arkmpc_keccak_absorb136_bmi(uint64_t st[25], const unsigned char* data, size_t nblocks) {
     absorb136_body(st, data, nblocks);
 }
-extern "C" int arkmpc_cpu_has_bmi(void) { return __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2"); }
+extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_bmi(void) { return __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2"); }
 #else
-extern "C" int arkmpc_cpu_has_bmi(void) { return 0; }
-extern "C" void arkmpc_keccak_absorb136_scalar(uint64_t*, const unsigned char*, size_t) {}
-extern "C" void arkmpc_keccak_absorb136_bmi(uint64_t*, const unsigned char*, size_t) {}
-extern "C" int arkmpc_cpu_has_avx512(void) { return 0; }
-extern "C" void arkmpc_keccak_absorb136_avx512(uint64_t*, const unsigned char*, size_t) {}
+extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_bmi(void) { return 0; }
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_scalar(uint64_t*, const unsigned char*, size_t) {}
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_bmi(uint64_t*, const unsigned char*, size_t) {}
+extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_avx512(void) { return 0; }
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_avx512(uint64_t*, const unsigned char*, size_t) {}
 #endif

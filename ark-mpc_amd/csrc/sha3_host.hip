@@ -65,11 +65,11 @@ inline void absorb136(uint64_t* st, const unsigned char* blk) {
 // Inner loops from keccak_avx512.cpp.  Which one is fastest depends on the host (measured: the AVX-512 form wins 1.7x on a
 // 2.1 GHz Xeon, the 64-bit form compiled with BMI wins on EPYC 9575F), so the first multi-block update times each candidate
 // on 64 blocks and keeps the winner.  ARKMPC_KECCAK=portable|scalar|bmi|avx512 forces one.
-extern "C" int arkmpc_cpu_has_avx512(void);
-extern "C" int arkmpc_cpu_has_bmi(void);
-extern "C" void arkmpc_keccak_absorb136_avx512(uint64_t st[25], const unsigned char* data, size_t nblocks);
-extern "C" void arkmpc_keccak_absorb136_scalar(uint64_t st[25], const unsigned char* data, size_t nblocks);
-extern "C" void arkmpc_keccak_absorb136_bmi(uint64_t st[25], const unsigned char* data, size_t nblocks);
+extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_avx512(void);
+extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_bmi(void);
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_avx512(uint64_t st[25], const unsigned char* data, size_t nblocks);
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_scalar(uint64_t st[25], const unsigned char* data, size_t nblocks);
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_bmi(uint64_t st[25], const unsigned char* data, size_t nblocks);
 typedef void (*absorb_fn)(uint64_t*, const unsigned char*, size_t);
 void absorb136_portable(uint64_t* st, const unsigned char* data, size_t nblocks) {
     for (size_t i = 0; i < nblocks; ++i) absorb136(st, data + 136 * i);

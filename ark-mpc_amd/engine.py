@@ -405,6 +405,10 @@ class Group:
     def sync(self):
         self._ck(self.lib.arkmpc_group_sync(self.h))
 
+    def wait_group(self, producer):
+        """member m of this group waits (on the device) for what member m of `producer` has submitted so far"""
+        self._ck(self.lib.arkmpc_group_wait_group(self.h, producer.h))
+
     def malloc(self, n, segs, elem_words):
         out = (ctypes.c_void_p * self.G)()
         self._ck(self.lib.arkmpc_group_malloc(self.h, ctypes.c_size_t(int(n)), ctypes.c_size_t(int(segs)), ctypes.c_size_t(int(elem_words)), out))

@@ -1290,8 +1290,8 @@ class ShardedBuf {
 };
 struct ShardedShares {              // Vec<AuthenticatedScalarResult<C>> range-sharded over the group, in the fabric's share layout
     size_t n = 0;
+    std::shared_ptr<GroupFabric> fabric;   // declared BEFORE buf: members die in reverse order, and buf's destructor frees through the group this keeps alive
     ShardedBuf buf;
-    std::shared_ptr<GroupFabric> fabric;
 };
 class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
   public:

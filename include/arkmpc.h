@@ -468,6 +468,11 @@ int arkmpc_group_shard_range(const arkmpc_group* grp, size_t n, int member, size
 /* 1 if member `from` can address member `to`'s memory (same device, or xGMI peer mapping enabled at group creation) */
 int arkmpc_group_peer_access(const arkmpc_group* grp, int from_member, int to_member);
 int arkmpc_group_sync(arkmpc_group* grp);                       /* blocks until every member's stream has drained */
+/* device-side ordering between two groups on the same devices: member m of `grp` waits for what member m of `producer` has submitted so far.
+ * REQUIRED between two in-process parties that hand each other shard pointers: call it on the consumer after the producer's K1 (its K2+K3 reads
+ * the producer's d||e shards) and on the producer's group after the consumer's K2+K3 before the next K1 overwrites those shards -- the two
+ * groups' streams are otherwise unordered. */
+int arkmpc_group_wait_group(arkmpc_group* grp, arkmpc_group* producer);
 const char* arkmpc_group_last_error(arkmpc_group* grp);
 /* sharded storage: out_shards / shards = arrays of G pointers */
 int arkmpc_group_malloc(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, uint64_t** out_shards);
@@ -489,7 +494,8 @@ int arkmpc_group_scatter(arkmpc_group* grp, size_t n, size_t segs, size_t elem_w
 /* Beaver multiplication, range-sharded (authenticated_scalar.rs:848-879): x, y, a, b, c, out = sharded ScalarShare vectors in
  * `layout`; my_de / peer_de / out_de = sharded d||e vectors.  In a two-party deployment the d||e payload leaves through
  * arkmpc_group_gather_d2h and the peer's arrives through arkmpc_group_scatter_h2d; two in-process parties built on the same devices
- * hand each other their shard pointers member by member (the device form of network/mock.rs). */
+ * hand each other their shard pointers member by member (the device form of network/mock.rs) and order the hand-over with
+ * arkmpc_group_wait_group -- each party's group has its own streams, nothing else orders one party's K1 before the other's K2+K3. */
 int arkmpc_group_beaver_mask(arkmpc_group* grp, int layout, size_t n, const uint64_t* const* x, const uint64_t* const* y,
                              const uint64_t* const* a, const uint64_t* const* b, uint64_t* const* out_de);
 /* K1 whose stores ARE the gather: every member's kernel writes its d / e range straight into the full 2n-Scalar buffer on `root`

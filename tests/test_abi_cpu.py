@@ -17,6 +17,19 @@ def test_library_exports_every_declared_symbol(pkg):
     assert b"gfx950" in lib.arkmpc_version()
 
 
+def test_library_exports_nothing_the_headers_do_not_declare(pkg):
+    """the dynamic symbol table of the built library: every exported `arkmpc_*` function is declared in include/arkmpc.h (the boundary) or in
+    include/arkmpc_test_hooks.h (test-only hooks) -- nothing rides along undeclared"""
+    import os, subprocess
+    eng = importlib.import_module("ark-mpc_amd.engine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set(eng.declared_symbols()) | set(eng.declared_symbols(os.path.join(root, "include", "arkmpc_test_hooks.h")))
+    out = subprocess.run(["nm", "-D", "--defined-only", eng.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in ("T", "W") and ln.split()[-1].startswith("arkmpc_")}
+    assert exported - declared == set(), sorted(exported - declared)
+    assert declared - exported == set(), sorted(declared - exported)
+
+
 def test_no_cpu_fallback(pkg):
     import torch
     if torch.cuda.is_available():
