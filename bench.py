@@ -62,6 +62,12 @@ def parse():
                     "(members then share a GPU: how the mode is exercised on a one-GPU box)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold pass (same W + K region with --settle-ms 0, run first) reported as value_cold / frac_cold")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs reported next to the headline at N=1 (AoS layout, config 4, config 5)")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="the timed region repeats the K steps in whole rounds until it is at least this long "
+                    "(K = 20 steps of 0.19 ms would be a 3.8 ms region: too short for the driver's clock and the power controller); 0 = exactly K steps. "
+                    "Reported: steps = K, timed_rounds, timed_steps_total, timed_region_ms; ms_per_step and value are over the whole region")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: --log2n gates per GPU per step whatever N (the default, what the driver runs); "
+                    "strong: 2^--total-log2n gates per step in total (BASELINE config 3: 2^24), cut into N contiguous ranges")
+    ap.add_argument("--total-log2n", type=int, default=24, help="--scaling strong: total gates per step over all GPUs")
     ap.add_argument("--only-e2e", action="store_true", help="run only the end-to-end (host records in, host records out) leg and print its JSON")
     ap.add_argument("--e2e-log2n", type=int, default=20, help="gates per party of the end-to-end leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the timed ordered all-gather of opened-value buffers (config 5 shape, 64 MiB per rank)")
@@ -257,7 +263,7 @@ def cpu_baseline(parties, n, log2n_cpu, layout):
     }, res, myde, m
 
 
-def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier, settle_ms=None):
+def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier, settle_ms=None, rounds=1):
     """`warmup` untimed and `steps` timed passes of the pipeline over the rotated workload sets.  The timed region is
     bracketed by barrier() (dist.barrier + torch.cuda.synchronize) on both sides; on sampled steps every launch carries a
     dispatch-bound HIP event pair (arkmpc_kernel_timer_*, on the context's own stream = torch's current stream)."""
@@ -284,8 +290,11 @@ def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier, settle_ms=N
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev_begin.record()
-    for s in range(steps):
+    for s in range(steps):                          # round 0: sampled steps carry per-kernel events
         step(call_sets[s % len(call_sets)], eng, slot_of.get(s))
+    for r in range(1, rounds):                      # the same K steps again, until the region is long enough to time (--min-timed-ms)
+        for s in range(steps):
+            step(call_sets[s % len(call_sets)])
     ev_end.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -294,8 +303,8 @@ def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier, settle_ms=N
         k1_ms, k3_ms = float(seg[:, :, :2].mean()), float(seg[:, :, 2:].mean())
     else:
         k1_ms = k3_ms = float("nan")
-    return {"elapsed": elapsed, "k1_ms": k1_ms, "k3_ms": k3_ms, "dev_ms_per_step": ev_begin.elapsed_time(ev_end) / steps,
-            "chunks": chunks, "sampled": len(sampled)}
+    return {"elapsed": elapsed, "k1_ms": k1_ms, "k3_ms": k3_ms, "dev_ms_per_step": ev_begin.elapsed_time(ev_end) / (steps * rounds),
+            "chunks": chunks, "sampled": len(sampled), "rounds": rounds}
 
 
 def oracle_bitexact(parties, n, m, chunks, layout, res, myde):
@@ -379,6 +388,7 @@ def leg_aos(eng, n, args):
 # utilisation.  The round-1 figure counted 2004 general multiplications of 136 multiplier instructions for the then algorithm (GLV, signed
 # 5-bit windows, Jacobian table); it is kept as `r01_accounting` so the two rounds can be compared on equal work.
 MAD_PEAK_PER_S = 31.2e12        # v_mad_u64_u32 lane-ops/s chip-wide, measured (profiles/ubench_r01.log)
+VALU_NOMINAL_PER_S = 256 * 4 * 16 * 2.4e9     # nominal VALU issue rate: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-ops/s
 MADS_PER_FQ_MUL = 136           # 64 product + 64 reduction v_mad_u64_u32 + 8 v_mul_lo_u32 (the m = t0 * inv words)
 FQ_MULS_PER_SMUL_R01 = 27 * (5 * 7 + 2 * 16 + 1) + 8 * 7 + 7 * 16
 
@@ -437,7 +447,10 @@ def leg_config4(eng):
             "limbs": ec_limbs(),
             "mult_instrs_per_scalar_mul": per_smul, "mult_instrs_per_s": smuls * per_smul,
             "frac_of_int_alu_peak": smuls * per_smul / MAD_PEAK_PER_S,
-            "int_alu_peak_note": "v_mad_u64_u32 + v_mul_lo_u32 instructions executed per second / 31.2e12 measured chip-wide v_mad_u64_u32 lane-ops/s",
+            "frac_of_nominal_valu_rate": smuls * per_smul / VALU_NOMINAL_PER_S,
+            "int_alu_peak_note": "multiplier instructions (v_mad_u64_u32 + v_mul_lo_u32) executed per second, against two denominators: frac_of_int_alu_peak = / 31.2e12 "
+                                 "lane-ops/s, the chip-wide v_mad_u64_u32 rate MEASURED on this part (probes/ubench.hip); frac_of_nominal_valu_rate = / 39.3e12, the nominal "
+                                 "VALU issue rate (256 CU x 4 SIMD x 16 lanes x 2.4 GHz), which no multiplier stream reaches",
             "ceiling_note": ("PMC (profiles/r03_ec/pmc_limbs29.txt): 4.08 SIMD cycles per VALU instruction in loop and table -- the issue limit; "
                              "70 % of the instructions are multiplier instructions") if ec_limbs() == 29 else
                             ("a bare chain of the hand-scheduled Montgomery block reaches 0.61 of this peak (probes/mulrate.hip, profiles/r02/mulrate.jsonl): "
@@ -555,7 +568,10 @@ def leg_config5(pkg, dev):
                                       "224 B of traffic per party-share against the 256 B algorithmic figure, which counts the payload write"},
             "host_sha3_ms_one_commitment": ms_one, "host_sha3_MBps": 32 * n / (ms_one * 1e-3) / 1e6,
             "host_sha3_note": "one sequential SHA3-256 over 512 MiB (commitment.rs:36-40 hashes one message); 4 such per batch (2 per party)",
-            "end_to_end_ms": ms_e2e, "end_to_end_what": "device part + commit phase + verify phase; the two parties hash concurrently (one host thread each), "
+            "end_to_end_ms": ms_e2e, "host_sha3_share_of_end_to_end": max(0.0, 1.0 - ms_dev / ms_e2e),
+            "lead": "end to end this configuration is host SHA3: %.0f ms of %.0f ms (%.1f %%) are the four sequential sponges (commitment.rs:36-40 hashes ONE message per "
+                    "commitment); the device part is %.2f ms, so the device fractions below describe a stage nobody waits for" % (ms_e2e - ms_dev, ms_e2e, 100 * (1 - ms_dev / ms_e2e), ms_dev),
+            "end_to_end_what": "device part + commit phase + verify phase; the two parties hash concurrently (one host thread each), "
             "a party's own two sponges are ordered by the commit-then-reveal protocol and cannot overlap",
             "results_check": "opened == value on all shares, both MAC checks verify, each recomputed commitment == the peer's: %s" % ("ok" if ok else "FAILED")}, ok
 
@@ -579,11 +595,14 @@ def pcie_calibration(mib=256):
     out = {}
     for name, fn, vol in (("h2d", lambda: dev.copy_(h, non_blocking=True), m), ("d2h", lambda: h2.copy_(dev2, non_blocking=True), m), ("both", both, 2 * m)):
         fn(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(4):
-            fn()
-        torch.cuda.synchronize()
-        out[name + "_GBps"] = vol / ((time.perf_counter() - t0) / 4) / 1e9
+        best = 0.0
+        for _ in range(3):                               # best of three batches of four copies
+            t0 = time.perf_counter()
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
+            best = max(best, vol / ((time.perf_counter() - t0) / 4) / 1e9)
+        out[name + "_GBps"] = best
     return out
 
 
@@ -619,17 +638,35 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
         eng.hostmul_finish(s, p, keys[p], peer_de, out[p])
 
     def timed_one(label):
+        """back_to_back: `reps` sessions one after the other, as a circuit of many gates keeps the link busy (the throughput figure).  isolated: one
+        session after the link has idled for a few ms -- the first two 64 MiB uploads then run at ~43 GB/s instead of 56 (rocprofv3 copy trace,
+        profiles/r04_e2e): the link / fabric clocks ramp.  The output buffers alternate between two sets that are cleared before the timed runs."""
         nonlocal ok
         one_party(0, want_de[1])                       # warm: device block, streams, events
-        ts = []
-        for _ in range(reps):
-            out[0].fill(0); de[0].fill(0)
-            t0 = time.perf_counter()
-            one_party(0, want_de[1])
-            ts.append(time.perf_counter() - t0)
-        ok = ok and np.array_equal(de[0], want_de[0]) and np.array_equal(out[0], want_out[0])
-        t = float(np.median(ts))
-        return {"buffers": label, "ms": t * 1e3, "ms_min": min(ts) * 1e3, "party_gates_per_s": n / t, "h2d_GBps": n * E2E_UP_BYTES / t / 1e9,
+        alt_de, alt_out = np.zeros_like(de[0]), np.zeros_like(out[0])
+        sets_ = [(de[0], out[0]), (alt_de, alt_out)]
+        for d_, o_ in sets_:
+            d_.fill(0); o_.fill(0)
+
+        def run(k):
+            d_, o_ = sets_[k & 1]
+            s = eng.hostmul_begin(n, H[0]["x"], H[0]["y"], H[0]["a"], H[0]["b"], H[0]["c"], d_)
+            eng.hostmul_finish(s, 0, keys[0], want_de[1], o_)
+
+        t0 = time.perf_counter()
+        for k in range(reps):
+            run(k)
+        t = (time.perf_counter() - t0) / reps
+        for d_, o_ in sets_:
+            ok = ok and np.array_equal(d_, want_de[0]) and np.array_equal(o_, want_out[0])
+        iso = []
+        for k in range(4):
+            time.sleep(0.004)
+            t1 = time.perf_counter()
+            run(k)
+            iso.append(time.perf_counter() - t1)
+        return {"buffers": label, "ms": t * 1e3, "ms_isolated_call": float(np.median(iso)) * 1e3, "party_gates_per_s": n / t,
+                "party_gates_per_s_isolated_call": n / float(np.median(iso)), "h2d_GBps": n * E2E_UP_BYTES / t / 1e9,
                 "d2h_GBps": n * E2E_DOWN_BYTES / t / 1e9, "frac_of_measured_pcie": (n * E2E_UP_BYTES / t / 1e9) / cal["h2d_GBps"]}
 
     pageable = timed_one("pageable (numpy / Vec memory); pinned in place inside each call, unpinned at its end")
@@ -784,7 +821,13 @@ def main_single_process(args):
         grp[0].sync(); grp[1].sync()
 
     def step(k, arm_slot=None):
+        # each party's group has its own member streams: the d||e hand-over is ordered on the device, member by member (arkmpc_group_wait_group).
+        # Before the K1s: a party's K1 overwrites the d||e shards the PEER's previous K2+K3 read (write after read).  Before the K2+K3s: a
+        # party's K2+K3 reads the d||e shards the peer's K1 writes (read after write).  Both waits of a pair are issued before either launch, so
+        # the two parties' kernels of one phase stay free to overlap.
         for j, c in enumerate(calls[k]):
+            if j in (0, 2):
+                grp[0].wait_group(grp[1]); grp[1].wait_group(grp[0])
             if arm_slot is not None:            # dispatch-bound HIP events on every member's launch of this call
                 g = grp[0 if j in (0, 2) else 1]
                 for m in range(G):
@@ -873,6 +916,7 @@ def main_single_process(args):
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)", "data": "synthetic",
         "mode": "single-process: ONE process drives all members through arkmpc_group_* (include/arkmpc.h)",
+        "ordering": "the two parties' groups are ordered member by member with arkmpc_group_wait_group before every K1 pair (write after read) and every K2+K3 pair (read after write)",
         "ranks_seen": G, "devices": devs, "distinct_devices": distinct,
         "oversubscribed": distinct < G,
         "per_member": per_member,
@@ -900,6 +944,43 @@ def main_single_process(args):
         raise SystemExit("result check failed")
 
 
+def rank_identity(dev):
+    """what identifies the physical GPU this rank computes on: gathered over the process group into the N>1 line, so that `N ranks on N distinct
+    devices` can be read off the line itself"""
+    pr = torch.cuda.get_device_properties(dev)
+    ident = {"local_device": int(dev), "name": pr.name}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if hasattr(pr, k):
+            v = getattr(pr, k)
+            ident[k] = v if isinstance(v, int) else str(v)
+    ident["pid"] = os.getpid()
+    return ident
+
+
+def per_rank_oracle_check(parties, n, chunks, layout, m=1 << 12):
+    """every rank checks the first 2^12 gates of ITS timed buffers (both parties: d||e and result records) against the oracle -- N>1 runs are
+    not parity-blind.  Returns the number of gates on which every word matched (m = all)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    ora = oracle_api.load()
+    m = min(m, n // chunks)
+
+    def host_aos(t):
+        if layout == "aos":
+            return t[:8 * m].cpu().numpy().view(np.uint64).copy()
+        sh = t[:4 * m].cpu().numpy().view(np.uint64).reshape(m, 4)
+        mm = t[4 * n:4 * n + 4 * m].cpu().numpy().view(np.uint64).reshape(m, 4)
+        return np.ascontiguousarray(np.concatenate([sh, mm], axis=1).reshape(-1))
+
+    H = [{k: host_aos(getattr(p, k)) for k in "xyabc"} for p in parties]
+    ode = [ora.beaver_mask(FID, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"]) for p in (0, 1)]
+    res, myde = [], []
+    for p in (0, 1):
+        d_, r_ = ora.batch_mul_9pass_local(FID, p, parties[p].key, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], ode[1 - p])
+        myde.append(d_); res.append(r_)
+    return oracle_bitexact(parties, n, m, chunks, layout, res, myde), m
+
+
 def main():
     args = parse()
     if args.single_process:
@@ -922,6 +1003,7 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
+    cdev = "cuda" if args.dist_backend == "nccl" else "cpu"       # where collective tensors live
     pkg = importlib.import_module("ark-mpc_amd")
     eng = pkg.Engine(FID, device=dev, host_buffers=False, stream=torch.cuda.current_stream().cuda_stream)
     if args.only_e2e:
@@ -931,9 +1013,15 @@ def main():
         if not ok:
             raise SystemExit("result check failed")
         return
-    if args.log2n is None:
-        args.log2n = 21 if world == 8 else 20      # 8 ranks: BASELINE config 3 (2^24 gates over 8 GPUs)
-    n = 1 << args.log2n
+    if args.scaling == "strong":                   # fixed total work: 2^total_log2n gates per step cut into `world` contiguous ranges
+        if (1 << args.total_log2n) % world:
+            raise SystemExit("--scaling strong needs a power-of-two number of GPUs")
+        n = (1 << args.total_log2n) // world
+        args.log2n = int(np.log2(n))
+    else:
+        if args.log2n is None:
+            args.log2n = 21 if world == 8 else 20      # 8 ranks: BASELINE config 3 (2^24 gates over 8 GPUs)
+        n = 1 << args.log2n
     sets = [build_workload(eng, n, seed=0xA11CE002 + rank + 7919 * k, layout=args.layout) for k in range(max(1, args.sets))]
     parties, truth = sets[0]
 
@@ -942,31 +1030,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def max_over_ranks(v):
+    def reduce_over_ranks(v, op):
         if dist is None:
             return v
-        t = torch.tensor([v], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([v], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=op)
         return float(t.item())
 
-    # cold pass FIRST: the same W warm-up + K timed steps with no settle phase -- what the driver's shape measures on a GPU that was idle
-    # while the workload was built (the power controller's transient, profiles/r02/ramp_probe.txt).  Reported beside the headline.
+    def max_over_ranks(v):
+        return v if dist is None else reduce_over_ranks(v, dist.ReduceOp.MAX)
+
+    # who is here: every rank adds 1 over the collective backend (RCCL under the driver) and contributes the identity of its GPU
+    ranks_seen, idents = 1, [rank_identity(dev)]
+    if dist is not None:
+        ranks_seen = int(round(reduce_over_ranks(1.0, dist.ReduceOp.SUM)))
+        idents = [None] * world
+        dist.all_gather_object(idents, rank_identity(dev))
+
+    # cold pass FIRST: exactly W warm-up + K timed steps with no settle phase -- what a K-step region measures on a GPU that was idle while
+    # the workload was built (the power controller's transient, profiles/r02/ramp_probe.txt).  Reported beside the headline; its duration
+    # also sizes the number of rounds of the headline region.
     cold = None
     if not args.no_cold and args.settle_ms > 0:
         rc_ = run_pipeline(eng, n, sets, args.layout, args, args.steps, args.warmup, barrier, settle_ms=0)
         cold = {"elapsed": max_over_ranks(rc_["elapsed"]), "k3_ms": rc_["k3_ms"], "k1_ms": rc_["k1_ms"], "dev_ms_per_step": rc_["dev_ms_per_step"]}
-    r = run_pipeline(eng, n, sets, args.layout, args, args.steps, args.warmup, barrier)
-    elapsed, k1_ms, k3_ms, dev_ms_per_step, chunks = r["elapsed"], r["k1_ms"], r["k3_ms"], r["dev_ms_per_step"], r["chunks"]
-    elapsed = max_over_ranks(elapsed)
+        est_region_ms = cold["elapsed"] * 1e3
+    else:
+        rc_ = run_pipeline(eng, n, sets, args.layout, args, min(8, args.steps), 2, barrier, settle_ms=0)
+        est_region_ms = max_over_ranks(rc_["elapsed"]) * 1e3 * args.steps / min(8, args.steps)
+    rounds = 1
+    if args.min_timed_ms > 0 and est_region_ms > 0:
+        rounds = max(1, int(np.ceil(1.2 * args.min_timed_ms / est_region_ms)))     # (the sizing pass runs cold and a little slow: 20 % margin)
+    rounds = int(max_over_ranks(float(rounds)))       # one number on every rank
+    r = run_pipeline(eng, n, sets, args.layout, args, args.steps, args.warmup, barrier, rounds=rounds)
+    k1_ms, k3_ms, dev_ms_per_step, chunks = r["k1_ms"], r["k3_ms"], r["dev_ms_per_step"], r["chunks"]
+    own_elapsed = r["elapsed"]
+    elapsed = max_over_ranks(own_elapsed)
+    steps_total = args.steps * rounds
+    per_rank_ms = [own_elapsed / steps_total * 1e3]
+    if dist is not None:
+        t = torch.tensor([own_elapsed / steps_total * 1e3], dtype=torch.float64, device=cdev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [float(x.item()) for x in allt]
 
     ok = True if args.no_check else all(check_results(eng, n, ps, tr, args.layout) for ps, tr in sets[:min(len(sets), args.steps)])
+    # parity on every rank (N = 1 runs the full-size comparison below instead)
+    rank_exact = None
+    if dist is not None and not args.no_check:
+        exact_r, m_r = per_rank_oracle_check(parties, n, chunks, args.layout)
+        ok = ok and exact_r == m_r
+        rank_exact = {"gates_checked_per_rank": m_r, "ranks_all_exact": bool(reduce_over_ranks(1.0 if exact_r == m_r else 0.0, dist.ReduceOp.MIN) == 1.0)}
     gather = None
     if dist is not None and world > 1 and not args.no_gather:
         gather = leg_gather(dist, world, rank, args.dist_backend)
 
     out = None
     if rank == 0:
-        gates = n * world * args.steps
+        gates = n * world * steps_total
         value = gates / elapsed
         m_launch = n // chunks                       # gates per kernel launch
         ach = m_launch * ALG_BYTES_K3 / (k3_ms * 1e-3) / 1e9
@@ -978,18 +1099,27 @@ def main():
             traffic = kp["hbm_bytes_per_launch"]
             rocprof_ms = kp.get("rocprof_avg_launch_ms")
             traffic_source = "profiles/traffic_%s.json: %s -- committed rocprofv3 PMC passes of this workload, NOT measured in this run" % (args.layout, prof.get("source", ""))
-        if world == 8 and args.log2n == 21:
-            wl = "2^24 AuthenticatedScalar Beaver muls over BN254 Fr sharded across 8 GPUs, 2^21 contiguous gates per GPU per step (BASELINE.json configs[2])"
+        if n * world == (1 << 24) and world > 1:
+            wl = "2^24 AuthenticatedScalar Beaver muls over BN254 Fr sharded across %d GPUs, 2^%d contiguous gates per GPU per step (BASELINE.json configs[2])" % (world, args.log2n)
         else:
             wl = "2^%d AuthenticatedScalar Beaver muls over BN254 Fr per GPU per step, two parties in-process, mock net (BASELINE.json configs[1])" % args.log2n
+        uniq = {json.dumps({k: v for k, v in i.items() if k not in ("pid", "local_device")}, sort_keys=True) + ("" if ("uuid" in i or "pci_bus_id" in i) else str(i["local_device"]))
+                for i in idents}
         out = {
             "metric": METRIC, "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / steps_total * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u256 Montgomery (8 x u32 limbs, v_mad_u64_u32)", "data": "synthetic",
+            "timed_rounds": rounds, "timed_steps_total": steps_total, "timed_region_ms": elapsed * 1e3,
+            "ranks_seen": ranks_seen, "distinct_devices": len(uniq), "rank_devices": idents,
+            "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms},
             "config": {"workload": wl, "gates_per_gpu": n, "gates_per_step_all_gpus": n * world, "field": "bn254_fr", "layout": args.layout,
                        "launches_per_step": 4 * chunks, "gates_per_launch": m_launch, "workload_sets_rotated": len(sets),
+                       "timed_region": "the K = %d steps run %d time(s) back to back between one pair of barriers (--min-timed-ms %.0f: a region of K steps alone would be "
+                                       "%.1f ms); value and ms_per_step are over all %d steps" % (args.steps, rounds, args.min_timed_ms, est_region_ms, steps_total),
                        "settle_ms": args.settle_ms, "settle_note": "untimed run of the same pipeline before the warm-up steps, every rank: keeps the timed region out of the "
                                    "power controller's transient after idle (profiles/r02/ramp_probe.txt); --settle-ms 0 disables",
+                       "headline_layout_note": "engine-native split columns (what gate outputs are kept in between gates; north_star allows SoA).  The arkworks AoS records the "
+                                               "boundary receives run the same pipeline at the fraction reported as aos_pipeline_frac_of_hbm_peak",
                        "parallelism": "gate-range sharding, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": ("k_beaver_finish_asm_sw<0>" if args.layout == "split" else "k_beaver_finish_asm_aos<0>") + " (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
@@ -1000,6 +1130,8 @@ def main():
                          "frac_rocprof_note": "the same fraction priced with the committed rocprofv3 --kernel-trace average of this kernel (profiles/): the figure that "
                                               "follows from profiles/ alone.  `frac` uses this run's dispatch-bound HIP events; the two differ by the profiler's own "
                                               "effect on the kernel (see clock_effect)",
+                         "ceiling_note": "two-kernel pipeline: 580 B moved per 512 B counted per party-gate (the 64 B own-d||e re-read by K2+K3 and 4 B of K1 slack), so at the "
+                                         "~6.3 TB/s the memory system sustains the pipeline tops out at 6.3 x 512/580 / 8 = 0.695 of the 8 TB/s peak (DESIGN.md section 3)",
                          "clock_effect": clock_effect()},
             "pipeline": {"algorithmic_GBps": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9,
                          "frac_of_hbm_peak": n * ALG_BYTES_PER_GATE / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -1007,10 +1139,12 @@ def main():
                          "k1_achieved_GBps": m_launch * ALG_BYTES_K1 / (k1_ms * 1e-3) / 1e9},
             "results_check": "open(batch_mul(x,y)) == x*y and MAC shares sum to key*x*y: %s" % ("ok" if ok else "FAILED"),
         }
+        if rank_exact is not None:
+            out["per_rank_oracle_check"] = rank_exact
         if cold is not None:
-            out["value_cold"] = gates / cold["elapsed"]
+            out["value_cold"] = n * world * args.steps / cold["elapsed"]
             out["roofline"]["frac_cold"] = m_launch * ALG_BYTES_K3 / (cold["k3_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
-            out["cold"] = {"what": "the same %d warm-up + %d timed steps run FIRST with no settle phase (--settle-ms 0): the GPU idled while the workload was built" % (args.warmup, args.steps),
+            out["cold"] = {"what": "the same %d warm-up + exactly %d timed steps (one round) run FIRST with no settle phase (--settle-ms 0): the GPU idled while the workload was built" % (args.warmup, args.steps),
                            "ms_per_step": cold["elapsed"] / args.steps * 1e3, "k1_avg_launch_ms": cold["k1_ms"], "k3_avg_launch_ms": cold["k3_ms"],
                            "device_ms_per_step": cold["dev_ms_per_step"]}
         if gather is not None:
@@ -1026,11 +1160,19 @@ def main():
         if world == 1 and not args.no_extras:
             del sets, parties, truth
             torch.cuda.empty_cache()
+            out["end_to_end"], ok_e = leg_end_to_end(pkg, eng, dev, args.e2e_log2n)
+            torch.cuda.empty_cache()
             out["aos"], ok_a = leg_aos(eng, n, args)
             out["config4"], ok_4 = leg_config4(eng)
             torch.cuda.empty_cache()
             out["config5"], ok_5 = leg_config5(pkg, dev)
-            ok = ok and ok_a and ok_4 and ok_5
+            ok = ok and ok_e and ok_a and ok_4 and ok_5
+            # the figures a reader should not have to dig for, next to `value`
+            out["aos_pipeline_frac_of_hbm_peak"] = out["aos"]["pipeline_frac_of_hbm_peak"]
+            out["aos_gates_per_s"] = out["aos"]["gates_per_s"]
+            out["end_to_end_party_gates_per_s"] = out["end_to_end"]["party_gates_per_s"]
+            out["config5_end_to_end_ms"] = out["config5"]["end_to_end_ms"]
+            out["config5_host_sha3_share_of_end_to_end"] = out["config5"].get("host_sha3_share_of_end_to_end")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -11,19 +11,29 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-            "data", "config", "roofline"]
+            "data", "config", "roofline", "timed_rounds", "timed_steps_total", "timed_region_ms", "ranks_seen", "distinct_devices", "rank_devices",
+            "per_rank_ms_per_step"]
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _check(line, n_gpus, steps, warmup):
+def _check(line, n_gpus, steps, warmup, scaling="weak"):
     d = json.loads(line)
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
-    assert d["unit"] == "gates/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "gates/s" and d["higher_is_better"] is True and d["scaling"] == scaling and d["vs_baseline"] is None
+    # the timed region is whole rounds of the K steps, at least --min-timed-ms long, and the line says so
+    assert d["timed_rounds"] >= 1 and d["timed_steps_total"] == steps * d["timed_rounds"]
+    assert abs(d["ms_per_step"] * d["timed_steps_total"] - d["timed_region_ms"]) < 1e-6 * d["timed_region_ms"] + 1e-9
+    assert d["timed_region_ms"] >= 50.0 or d["timed_rounds"] > 1 or steps * d["ms_per_step"] >= 50.0
+    # self-proving rank / device census
+    assert d["ranks_seen"] == n_gpus and len(d["rank_devices"]) == n_gpus and 1 <= d["distinct_devices"] <= n_gpus
+    assert all("name" in i and "local_device" in i for i in d["rank_devices"])
+    pr = d["per_rank_ms_per_step"]
+    assert len(pr["all"]) == n_gpus and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
     assert d["metric"].startswith("authenticated Beaver mul-gates/sec over BN254 Fr")
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
@@ -39,6 +49,15 @@ def test_single_process_default_shape():
     d = _check(r.stdout.strip().splitlines()[-1], 1, 6, 2)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "gates/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # the N = 1 line leads with the figures a reader needs beside `value`: the arkworks-layout fraction, the host-to-host rate, config 5's wall time
+    for k in ("aos_pipeline_frac_of_hbm_peak", "end_to_end_party_gates_per_s", "config5_end_to_end_ms", "end_to_end"):
+        assert k in d, k
+    e2e = d["end_to_end"]
+    for k in ("party_gates_per_s", "two_party_gates_per_s", "h2d_GBps", "d2h_GBps", "frac_of_measured_pcie"):
+        assert k in e2e and e2e[k] is not None and e2e[k] > 0, k
+    assert e2e["results_check"].endswith("ok")
+    c4 = d["config4"]
+    assert 0 < c4["frac_of_nominal_valu_rate"] < c4["frac_of_int_alu_peak"] < 1
 
 
 def test_torchrun_two_ranks():
@@ -50,6 +69,59 @@ def test_torchrun_two_ranks():
     assert len(lines) == 1                       # rank 0 only
     d = _check(lines[0], 2, 4, 1)
     assert "cpu_baseline" not in d               # N = 1 only
+    assert d["per_rank_oracle_check"]["ranks_all_exact"] is True and d["per_rank_oracle_check"]["gates_checked_per_rank"] == 4096
+    assert d["distinct_devices"] == 1            # both ranks of this test sit on the box's one GPU, and the line says so
+
+
+def test_torchrun_two_ranks_strong_scaling():
+    """--scaling strong: a fixed total (here 2^17 gates per step) cut into one contiguous range per rank"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--scaling", "strong", "--total-log2n", "17", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    d = _check(lines[0], 2, 4, 1, scaling="strong")
+    assert d["config"]["gates_per_gpu"] == 1 << 16 and d["config"]["gates_per_step_all_gpus"] == 1 << 17
+
+
+def _need_two_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs 2 physical GPUs: torch.cuda.device_count() == %d on this box -- the cross-device legs (hipMemcpyPeerAsync between distinct devices, "
+                    "peer mappings, RCCL with world > 1) have NOT been exercised here" % n)
+
+
+def test_group_on_two_distinct_devices(tmp_path):
+    """tests/c/group_oversub.c with members on devices 0 and 1: range kernels, peer pushes over xGMI, the pipelined commitment and the AND-reduced verify
+    flag across two physical GPUs == one context"""
+    _need_two_gpus()
+    from test_abi_cpu import _build_c_smoke
+    r = subprocess.run([_build_c_smoke(tmp_path, "group_oversub"), "100003", "2", "0", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "group ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_config5_driver_on_two_distinct_devices():
+    """tools/config5_dist.py over RCCL with one rank per physical GPU"""
+    _need_two_gpus()
+    env = dict(os.environ, LOG2N="20", DIST_BACKEND="nccl")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "config5_dist.py")], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["verify_ok"] is True and d["equals_single_slice_run"] is True
+
+
+def test_bench_two_ranks_on_two_distinct_devices():
+    """the driver's N = 2 launch on two physical GPUs over RCCL: the line must show 2 ranks on 2 distinct devices"""
+    _need_two_gpus()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _check([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0], 2, 10, 2)
+    assert d["distinct_devices"] == 2 and d["per_rank_oracle_check"]["ranks_all_exact"] is True
 
 
 def test_config5_driver_two_ranks_equals_single_slice():
