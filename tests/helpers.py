@@ -141,5 +141,9 @@ class EngineAdapter:
     def ed_batch_add(self, a, b): n = len(a) // 16; o = self._o(n, 16); self.eng(2).ed_add(n, a, b, o); return o
     def ed_batch_neg(self, a): n = len(a) // 16; o = self._o(n, 16); self.eng(2).ed_neg(n, a, o); return o
     def ed_to_bytes(self, pts): n = len(pts) // 16; o = np.zeros(32 * n, dtype=np.uint8); self.eng(2).ed_to_bytes(n, pts, o); return o
+    def ed_from_bytes(self, data):
+        n = len(data) // 32; o = self._o(n, 16); ok = np.zeros(n, dtype=np.uint8); self.eng(2).ed_from_bytes(n, data, o, ok); return o, ok
+    def ed_batch_to_affine(self, pts): n = len(pts) // 16; o = self._o(n, 8); self.eng(2).ed_to_affine(n, pts, o); return o
+    def ed_generator_mul(self, sc): n = len(sc) // 4; o = self._o(n, 16); self.eng(2).ed_generator_mul(n, sc, o); return o
     def g1_from_bytes(self, data):
         n = len(data) // 32; o = self._o(n, 12); ok = np.zeros(n, dtype=np.uint8); self.eng(0).g1_from_bytes(n, data, o, ok); return o, ok
