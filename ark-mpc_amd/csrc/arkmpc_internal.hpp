@@ -189,13 +189,21 @@ struct LinkEvents {
         used.push_back(ev);
         return ev;
     }
-    // `to` waits (on the device) for everything submitted to `from` so far; returns the event (also usable by the host)
-    int edge(hipStream_t from, hipStream_t to, hipEvent_t* out_ev = nullptr) {
+    // `to` waits (on the device) for everything submitted to `from` so far.  (Either stream may be the NULL stream -- a context bound to
+    // torch's default stream has ctx->stream == nullptr -- so "no waiter" is its own entry point, mark(), not a null `to`.)
+    int edge(hipStream_t from, hipStream_t to) {
         hipEvent_t ev = take();
         if (!ev) { ark_set_err(ctx, "hipEventCreate failed"); return ARKMPC_ERR_HIP; }
         ARK_HIP(ctx, hipEventRecord(ev, from));
-        if (to) ARK_HIP(ctx, hipStreamWaitEvent(to, ev, 0));
-        if (out_ev) *out_ev = ev;
+        ARK_HIP(ctx, hipStreamWaitEvent(to, ev, 0));
+        return ARKMPC_OK;
+    }
+    // an event the HOST can query / wait for: everything submitted to `from` so far
+    int mark(hipStream_t from, hipEvent_t* out_ev) {
+        hipEvent_t ev = take();
+        if (!ev) { ark_set_err(ctx, "hipEventCreate failed"); return ARKMPC_ERR_HIP; }
+        ARK_HIP(ctx, hipEventRecord(ev, from));
+        *out_ev = ev;
         return ARKMPC_OK;
     }
     void give_back() {                     // only after the streams that recorded / waited on them have drained

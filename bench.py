@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--cpu-log2n", type=int, default=20, help="CPU baseline sample size (gates)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed: run the pipeline for this long BEFORE the W warm-up steps, on every rank, so that the "
-                    "timed region does not sit inside the power controller's transient after idle (tools/ramp_probe.py: a cold MI355X runs the first steps fast, "
+                    "timed region does not sit inside the power controller's transient after idle (probes/ramp_probe.py: a cold MI355X runs the first steps fast, "
                     "then creeps from 0.195 to 0.21-0.25 ms per step for several ms before settling at 0.198).  0 disables.  Reported in config.settle_ms.")
     ap.add_argument("--single-process", action="store_true", help="N GPUs driven by ONE process through the C ABI's multi-device group (arkmpc_group_*): what a "
                     "Rust party, which is one process, would run.  The driver's N>1 runs use torch.distributed.run (one process per GPU); this mode is the same "
@@ -639,32 +639,33 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
 
     def timed_one(label):
         """back_to_back: `reps` sessions one after the other, as a circuit of many gates keeps the link busy (the throughput figure).  isolated: one
-        session after the link has idled for a few ms -- the first two 64 MiB uploads then run at ~43 GB/s instead of 56 (rocprofv3 copy trace,
-        profiles/r04_e2e): the link / fabric clocks ramp.  The output buffers alternate between two sets that are cleared before the timed runs."""
+        session after the link has idled for a few ms.  Output buffers are cleared before the timed runs."""
         nonlocal ok
         one_party(0, want_de[1])                       # warm: device block, streams, events
-        alt_de, alt_out = np.zeros_like(de[0]), np.zeros_like(out[0])
-        sets_ = [(de[0], out[0]), (alt_de, alt_out)]
-        for d_, o_ in sets_:
-            d_.fill(0); o_.fill(0)
+        for p in (0, 1):
+            de[p].fill(0); out[p].fill(0)
 
         def run(k):
-            d_, o_ = sets_[k & 1]
-            s = eng.hostmul_begin(n, H[0]["x"], H[0]["y"], H[0]["a"], H[0]["b"], H[0]["c"], d_)
-            eng.hostmul_finish(s, 0, keys[0], want_de[1], o_)
+            # consecutive sessions alternate between the two parties' inputs: the device block is recycled from session to session, so a kernel
+            # that ran ahead of its upload would compute on the OTHER party's stale records and the check below would catch it
+            p = k & 1
+            s = eng.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p])
+            eng.hostmul_finish(s, p, keys[p], want_de[1 - p], out[p])
 
         t0 = time.perf_counter()
         for k in range(reps):
             run(k)
         t = (time.perf_counter() - t0) / reps
-        for d_, o_ in sets_:
-            ok = ok and np.array_equal(d_, want_de[0]) and np.array_equal(o_, want_out[0])
+        for p in (0, 1):
+            ok = ok and np.array_equal(de[p], want_de[p]) and np.array_equal(out[p], want_out[p])
         iso = []
         for k in range(4):
             time.sleep(0.004)
             t1 = time.perf_counter()
             run(k)
             iso.append(time.perf_counter() - t1)
+        for p in (0, 1):
+            ok = ok and np.array_equal(de[p], want_de[p]) and np.array_equal(out[p], want_out[p])
         return {"buffers": label, "ms": t * 1e3, "ms_isolated_call": float(np.median(iso)) * 1e3, "party_gates_per_s": n / t,
                 "party_gates_per_s_isolated_call": n / float(np.median(iso)), "h2d_GBps": n * E2E_UP_BYTES / t / 1e9,
                 "d2h_GBps": n * E2E_DOWN_BYTES / t / 1e9, "frac_of_measured_pcie": (n * E2E_UP_BYTES / t / 1e9) / cal["h2d_GBps"]}
@@ -768,10 +769,14 @@ def leg_gather(dist, world, rank, backend):
 
 
 def clock_effect():
-    """Measured effect of the profiler on the dominant kernel, from the committed PMC pass (profiles/r03/clock_effect.json, written by
-    tools/profile_r03.sh): GRBM_GUI_ACTIVE cycles / the kernel's wall time under rocprofv3 = the shader clock it ran at while profiled."""
-    f = os.path.join(ROOT, "profiles", "r03", "clock_effect.json")
-    return json.load(open(f)) if os.path.exists(f) else None
+    """Measured effect of the profiler on the dominant kernel, from the committed PMC pass (profiles/r0N/clock_effect.json, written by
+    tools/profile.sh): GRBM_GUI_ACTIVE cycles / the kernel's wall time under rocprofv3 = the shader clock it ran at while profiled."""
+    for rnd in ("r04", "r03"):
+        f = os.path.join(ROOT, "profiles", rnd, "clock_effect.json")
+        if os.path.exists(f):
+            d = json.load(open(f)); d["source"] = "profiles/%s/clock_effect.json" % rnd
+            return d
+    return None
 
 
 def main_single_process(args):

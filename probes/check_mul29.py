@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Checks the one product probes/mulrate29 prints (x * x / 2^261 mod q in 29-bit limbs) against Python integers, and its constants.
-usage: probes/mulrate29 | python tools/check_mul29.py"""
+usage: probes/mulrate29 | python probes/check_mul29.py"""
 import json, sys
 q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
 assert (-pow(q, -1, 1 << 29)) % (1 << 29) == 0x04866389

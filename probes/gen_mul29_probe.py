@@ -5,12 +5,12 @@ of v_mad_u64_u32 (no carry folds), the reduction term m_k q_0 clears the low 29 
 Two accumulators per column (even / odd terms) break the dependent chain.  The stream is executed by the single-lane emulator against Python
 integers before it is written (selftest below).
 
-usage: python tools/gen_mul29_probe.py  ->  probes/mul29_asm.inc"""
+usage: python probes/gen_mul29_probe.py  ->  probes/mul29_asm.inc"""
 import os
 import random
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
 import gen_asm_kernels as G
 from gen_asm_kernels import Ins, Emitter, Emu, M32, regs_of, pr, src
 
@@ -136,7 +136,7 @@ def selftest(trials=300, two_acc=True):
 
 def main():
     out = []
-    out.append("// GENERATED by tools/gen_mul29_probe.py -- do not edit.  Hand-scheduled 29-bit-limb Montgomery multiplication (BN254 Fq, R = 2^261) for probes/mulrate29.hip.")
+    out.append("// GENERATED by probes/gen_mul29_probe.py -- do not edit.  Hand-scheduled 29-bit-limb Montgomery multiplication (BN254 Fq, R = 2^261) for probes/mulrate29.hip.")
     for name, two in (("mul29_asm", True), ("mul29_asm_1acc", False), ("mul29_asm_1acc_split", False)):
         SPLIT_SHIFT[0] = name.endswith("_split")
         E, mp = selftest(two_acc=two)
