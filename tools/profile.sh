@@ -33,11 +33,13 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 wins, cur = [], [rows[0]]
 for r in rows[1:]:
-    if int(r["Start_Timestamp"]) - max(int(x["End_Timestamp"]) for x in cur) > 60_000:
+    if "HOST_TO_DEVICE" not in r["Direction"]:
+        continue
+    if int(r["Start_Timestamp"]) - max(int(x["End_Timestamp"]) for x in cur) > 2_000_000:
         wins.append(cur); cur = []
     cur.append(r)
 wins.append(cur)
-sess = [w for w in wins if len(w) == 22]                 # one party's session: x, y, a + 6 chunks of b + c + 12 peer chunks
+sess = [w for w in wins if len(w) == 22]                 # one ISOLATED party session: x, y, a + 6 chunks of b + c + 12 peer chunks of uploads
 w = sess[-1] if sess else max(wins, key=len)
 t0 = int(w[0]["Start_Timestamp"])
 wr = csv.writer(open(sys.argv[2], "w"))

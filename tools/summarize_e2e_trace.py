@@ -57,27 +57,36 @@ for r in copies:
     a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     cs.append((a, b, "up" if "HOST_TO_DEVICE" in d.upper() or "H2D" in d.upper() else ("down" if "DEVICE_TO_HOST" in d.upper() or "D2H" in d.upper() else "other"), r))
 cs.sort()
-# sessions: split the copy stream at gaps > 1.5 ms; keep windows whose volume looks like one party's 2^20-gate session (6 x 64 MiB up)
-wins, cur = [], [cs[0]]
-for c in cs[1:]:
-    if c[0] - max(x[1] for x in cur) > 1_500_000:
+# one party's session = 22 host-to-device copies (x, y, a, six chunks of b, c, twelve chunks of the peer's d||e).  The bench's e2e leg ends each
+# buffer mode with four ISOLATED sessions (4 ms of idle link before each): those are the windows of exactly 22 uploads between gaps > 2 ms
+ups = [c for c in cs if c[2] == "up"]
+wins, cur = [], [ups[0]]
+for c in ups[1:]:
+    if c[0] - max(x[1] for x in cur) > 2_000_000:
         wins.append(cur); cur = []
     cur.append(c)
 wins.append(cur)
 rows = []
 for w in wins:
-    up = [(a, b) for a, b, k, _ in w if k == "up"]
-    down = [(a, b) for a, b, k, _ in w if k == "down"]
-    if not up or not down:
+    if len(w) != 22:
         continue
-    t0, t1 = min(a for a, _ in up + down), max(b for _, b in up + down)
-    ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in kern if t0 <= int(r["Start_Timestamp"]) <= t1]
-    rows.append({"window_ms": (t1 - t0) / 1e6, "copies_up": len(up), "copies_down": len(down), "kernels": len(ks),
+    up = [(a, b) for a, b, _, _ in w]
+    t0, t_up_end = up[0][0], up[-1][1]
+    # downloads: device-to-host copies in the copy trace and the runtime's blit kernels (__amd_rocclr_copyBuffer: this ROCm moves D2H to pinned memory
+    # with a shader copy); kernels: everything else that started inside the session
+    down = [(a, b) for a, b, k, _ in cs if k == "down" and t0 <= a <= t_up_end + 2_000_000]
+    ks, blits = [], []
+    for r in kern:
+        a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if t0 <= a <= t_up_end + 2_000_000:
+            (blits if "copyBuffer" in r["Kernel_Name"] else ks).append((a, b))
+    down += blits
+    t1 = max([t_up_end] + [b for _, b in down])
+    rows.append({"window_ms": (t1 - t0) / 1e6, "copies_up": len(up), "downloads": len(down), "kernels": len(ks),
                  "up_busy_ms": total(union(up)) / 1e6, "down_busy_ms": total(union(down)) / 1e6, "kernel_busy_ms": total(union(ks)) / 1e6,
-                 "down_under_up_ms": overlap(down, up) / 1e6, "kernels_under_up_ms": overlap(ks, up) / 1e6,
                  "up_busy_frac_of_window": total(union(up)) / (t1 - t0),
                  "down_hidden_frac": overlap(down, up) / max(1, total(union(down))), "kernels_hidden_frac": overlap(ks, up) / max(1, total(union(ks))) if ks else None,
-                 "tail_after_last_upload_ms": (t1 - max(b for _, b in up)) / 1e6})
-sess = [r for r in rows if r["copies_up"] >= 8 and 5.0 < r["window_ms"] < 12.0]
-print(json.dumps({"windows_total": len(rows), "one_party_sessions": len(sess), "last_one_party_session": sess[-1] if sess else None,
-                  "median_window_ms": sorted(r["window_ms"] for r in sess)[len(sess) // 2] if sess else None}, indent=1))
+                 "tail_after_last_upload_ms": (t1 - t_up_end) / 1e6,
+                 "first_two_uploads_GBps": [round(64 * 1.048576e6 / ((b - a) / 1e9) / 1e9, 1) for a, b in up[:2]], "third_upload_GBps": round(64 * 1.048576e6 / ((up[2][1] - up[2][0]) / 1e9) / 1e9, 1)})
+print(json.dumps({"sessions_found": len(rows), "last_one_party_session": rows[-1] if rows else None,
+                  "median_window_ms": sorted(r["window_ms"] for r in rows)[len(rows) // 2] if rows else None}, indent=1))

@@ -85,7 +85,8 @@ res = {"source": os.path.basename(out.rstrip("/")) + " (tools/profile.sh): rocpr
                  "--warmup 10 --no-cpu-baseline --no-extras --no-cold`; KiB units; FETCH_SIZE doubled (gfx950 note in MI355X_MICROARCH.md, calibrated on k_beaver_mask "
                  "in round 1); WRITE_SIZE checked on probes/write_calib (pure stores in the path's patterns, known byte counts): exact (ratio 1.0000) for plain stores, "
                  "+23..34 % REAL traffic for non-temporal 16-byte stores 32 B apart -- see write_calibration",
-       "workload": "bench.py --layout split, 2^20 gates per launch", "write_calibration": calib}
+       "workload": "bench.py --layout split, 2^20 gates per launch",
+       "write_calibration": calib if calib else "not re-run this round: profiles/r03/write_calib.json (probes/write_calib.hip)"}
 print("== HBM traffic per launch, split layout")
 for name, tag in (("k_beaver_finish_asm", "k_beaver_finish_asm"), ("k_beaver_mask", "k_beaver_mask")):
     fk = [k for k in fetch if tag in k]
