@@ -12,6 +12,8 @@ set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 if [ "${1:-}" = "--trace" ]; then
   O=$2; shift 3
+  case "$O" in /*) ;; *) O="$PWD/$O";; esac
+  CMD=(); for a in "$@"; do case "$a" in tools/*|probes/*|bench.py) CMD+=("$R/$a");; *) CMD+=("$a");; esac; done; set -- "${CMD[@]}"
   export TMPDIR=/tmp; mkdir -p "$O"; (cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d "$O" -o p -- "$@" > "$O/cmd.out" 2> "$O/cmd.err")
   python3 - "$O" <<'PY'
 import csv, glob, sys
