@@ -235,47 +235,207 @@ __global__ void __launch_bounds__(WIRE_TPB) k_wire_to_canonical(size_t n, const 
 }
 
 
-// ---- whitespace --------------------------------------------------------------------------------------------------
-// serde_json::from_slice accepts JSON whitespace (space, tab, LF, CR) between tokens; serde_json::to_vec -- what the reference's
-// transport sends (network/quic.rs:303) -- never emits any.  Frames without whitespace (every frame of a reference peer) take
-// the GPU path untouched; a frame that does contain whitespace is normalised ON THE HOST first: whitespace between tokens is
-// dropped, whitespace inside a string is kept (the literal comparison of the key then fails, as an unknown field would), and
-// whitespace between two digits -- two adjacent number tokens -- is a syntax error.
-__global__ void __launch_bounds__(WIRE_TPB) k_wire_has_ws(const unsigned char* frame, size_t frame_len, int* flag) {
-    const size_t v = (size_t)blockIdx.x * WIRE_TPB + threadIdx.x;
-    if (16 * v >= frame_len) return;
-    const uint4 q = load16_clamped(frame, 16 * v, frame_len);
-    const u32 w[4] = {q.x, q.y, q.z, q.w};
-    bool ws = false;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const u32 c = (w[k >> 2] >> (8 * (k & 3))) & 255u;
-        if (16 * v + k >= 8 && 16 * v + k < frame_len && (c == 0x20u || c == 0x09u || c == 0x0au || c == 0x0du)) ws = true;
+// ---- serde's object semantics -------------------------------------------------------------------------------------------
+// `NetworkOutbound` derives Deserialize (network.rs:33-60) and QuicTwoPartyNet reads it with serde_json::from_slice
+// (network/quic.rs:233-251): the two fields may come in ANY order, unknown fields are skipped (whatever JSON value they hold), a known
+// field given twice is an error ("duplicate field"), keys are compared after unescaping ("result_id" IS result_id), the payload is an
+// externally tagged enum -- an object with exactly ONE key naming the variant --, and only whitespace may follow the closing brace.
+// A frame the strict GPU parser rejects is therefore re-read here, on the host, by a small JSON scanner (RFC 8259: strings with escapes and
+// valid UTF-8, no raw control characters, no lone surrogates; nesting limited to 128 like serde_json's recursion limit); if it is a
+// NetworkOutbound message in any of those shapes it is rewritten into the canonical compact frame and handed to the GPU parser again.
+struct JsonScan {
+    const unsigned char* p; size_t n, i; std::string err;
+    bool fail(const char* what) { if (err.empty()) err = what; return false; }
+    void ws() { while (i < n && (p[i] == 0x20 || p[i] == 0x09 || p[i] == 0x0a || p[i] == 0x0d)) ++i; }
+    static int hexv(unsigned char c) { return c >= '0' && c <= '9' ? c - '0' : (c >= 'a' && c <= 'f' ? c - 'a' + 10 : (c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1)); }
+    bool hex4(u32* out) {
+        if (i + 4 > n) return fail("malformed message: truncated \\u escape");
+        u32 v = 0;
+        for (int k = 0; k < 4; ++k) { const int h = hexv(p[i + k]); if (h < 0) return fail("malformed message: bad \\u escape"); v = v * 16 + (u32)h; }
+        i += 4; *out = v; return true;
     }
-    if (__any(ws) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
-static bool host_has_ws(const unsigned char* p, size_t len) {
-    for (size_t i = 8; i < len; ++i) if (p[i] == 0x20 || p[i] == 0x09 || p[i] == 0x0a || p[i] == 0x0d) return true;
-    return false;
-}
-// in: a whole frame (8-byte prefix + JSON text).  out: the frame with inter-token whitespace removed and the prefix rewritten.
-static bool normalise_ws(const std::vector<unsigned char>& in, std::vector<unsigned char>& out) {
-    out.assign(in.begin(), in.begin() + 8);
+    static void put_utf8(std::string& o, u32 c) {
+        if (c < 0x80) o.push_back((char)c);
+        else if (c < 0x800) { o.push_back((char)(0xC0 | (c >> 6))); o.push_back((char)(0x80 | (c & 63))); }
+        else if (c < 0x10000) { o.push_back((char)(0xE0 | (c >> 12))); o.push_back((char)(0x80 | ((c >> 6) & 63))); o.push_back((char)(0x80 | (c & 63))); }
+        else { o.push_back((char)(0xF0 | (c >> 18))); o.push_back((char)(0x80 | ((c >> 12) & 63))); o.push_back((char)(0x80 | ((c >> 6) & 63))); o.push_back((char)(0x80 | (c & 63))); }
+    }
+    // at an opening quote: consumes the string, returns its unescaped value
+    bool string(std::string* out) {
+        if (i >= n || p[i] != '"') return fail("malformed message: expected a string");
+        ++i;
+        std::string o;
+        while (true) {
+            if (i >= n) return fail("malformed message: unterminated string");
+            const unsigned char c = p[i];
+            if (c == '"') { ++i; break; }
+            if (c < 0x20) return fail("malformed message: control character in a string");
+            if (c == '\\') {
+                if (i + 1 >= n) return fail("malformed message: truncated escape");
+                const unsigned char e = p[i + 1]; i += 2;
+                switch (e) {
+                    case '"': o.push_back('"'); break; case '\\': o.push_back('\\'); break; case '/': o.push_back('/'); break;
+                    case 'b': o.push_back('\b'); break; case 'f': o.push_back('\f'); break; case 'n': o.push_back('\n'); break;
+                    case 'r': o.push_back('\r'); break; case 't': o.push_back('\t'); break;
+                    case 'u': {
+                        u32 u; if (!hex4(&u)) return false;
+                        if (u >= 0xDC00 && u <= 0xDFFF) return fail("malformed message: lone trailing surrogate");
+                        if (u >= 0xD800 && u <= 0xDBFF) {
+                            u32 lo;
+                            if (i + 2 > n || p[i] != '\\' || p[i + 1] != 'u') return fail("malformed message: lone leading surrogate");
+                            i += 2; if (!hex4(&lo)) return false;
+                            if (lo < 0xDC00 || lo > 0xDFFF) return fail("malformed message: lone leading surrogate");
+                            u = 0x10000 + ((u - 0xD800) << 10) + (lo - 0xDC00);
+                        }
+                        put_utf8(o, u); break;
+                    }
+                    default: return fail("malformed message: bad escape");
+                }
+                continue;
+            }
+            if (c < 0x80) { o.push_back((char)c); ++i; continue; }
+            // raw multi-byte UTF-8: validate (from_slice rejects invalid UTF-8 inside strings)
+            int len = (c >= 0xC2 && c <= 0xDF) ? 2 : ((c >= 0xE0 && c <= 0xEF) ? 3 : ((c >= 0xF0 && c <= 0xF4) ? 4 : 0));
+            if (!len || i + len > n) return fail("malformed message: invalid UTF-8");
+            for (int k = 1; k < len; ++k) if ((p[i + k] & 0xC0) != 0x80) return fail("malformed message: invalid UTF-8");
+            if ((c == 0xE0 && p[i + 1] < 0xA0) || (c == 0xED && p[i + 1] > 0x9F) || (c == 0xF0 && p[i + 1] < 0x90) || (c == 0xF4 && p[i + 1] > 0x8F))
+                return fail("malformed message: invalid UTF-8");
+            o.append((const char*)p + i, len); i += len;
+        }
+        if (out) *out = std::move(o);
+        return true;
+    }
+    bool number() {                    // RFC 8259 number grammar
+        if (i < n && p[i] == '-') ++i;
+        if (i >= n) return fail("malformed message: number");
+        if (p[i] == '0') ++i;
+        else if (p[i] >= '1' && p[i] <= '9') { while (i < n && p[i] >= '0' && p[i] <= '9') ++i; }
+        else return fail("malformed message: number");
+        if (i < n && p[i] == '.') { ++i; size_t d = 0; while (i < n && p[i] >= '0' && p[i] <= '9') { ++i; ++d; } if (!d) return fail("malformed message: number"); }
+        if (i < n && (p[i] == 'e' || p[i] == 'E')) {
+            ++i; if (i < n && (p[i] == '+' || p[i] == '-')) ++i;
+            size_t d = 0; while (i < n && p[i] >= '0' && p[i] <= '9') { ++i; ++d; } if (!d) return fail("malformed message: number");
+        }
+        return true;
+    }
+    bool literal(const char* lit) { const size_t l = strlen(lit); if (i + l > n || memcmp(p + i, lit, l) != 0) return fail("malformed message: literal"); i += l; return true; }
+    // any JSON value, validated and skipped
+    bool value(int depth) {
+        if (depth > 128) return fail("malformed message: recursion limit exceeded");
+        ws();
+        if (i >= n) return fail("malformed message: unexpected end");
+        const unsigned char c = p[i];
+        if (c == '"') return string(nullptr);
+        if (c == '{') {
+            ++i; ws();
+            if (i < n && p[i] == '}') { ++i; return true; }
+            while (true) {
+                ws(); if (!string(nullptr)) return false;
+                ws(); if (i >= n || p[i] != ':') return fail("malformed message: expected ':'"); ++i;
+                if (!value(depth + 1)) return false;
+                ws(); if (i >= n) return fail("malformed message: unexpected end");
+                if (p[i] == ',') { ++i; continue; }
+                if (p[i] == '}') { ++i; return true; }
+                return fail("malformed message: expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            ++i; ws();
+            if (i < n && p[i] == ']') { ++i; return true; }
+            while (true) {
+                if (!value(depth + 1)) return false;
+                ws(); if (i >= n) return fail("malformed message: unexpected end");
+                if (p[i] == ',') { ++i; continue; }
+                if (p[i] == ']') { ++i; return true; }
+                return fail("malformed message: expected ',' or ']'");
+            }
+        }
+        if (c == 't') return literal("true");
+        if (c == 'f') return literal("false");
+        if (c == 'n') return literal("null");
+        return number();
+    }
+};
+// appends in[a, b) without inter-token whitespace (the span holds no strings that matter: the GPU parser rejects any in a batch body)
+static bool append_stripped(const unsigned char* in, size_t a, size_t b, std::vector<unsigned char>& out) {
     bool in_string = false;
-    const size_t n = in.size();
-    for (size_t i = 8; i < n; ++i) {
+    for (size_t i = a; i < b; ++i) {
         const unsigned char c = in[i];
         const bool ws = c == 0x20 || c == 0x09 || c == 0x0a || c == 0x0d;
-        if (in_string && c == '\\' && i + 1 < n) { out.push_back(c); out.push_back(in[++i]); continue; }     // an escape (\" does not close the string)
+        if (in_string && c == '\\' && i + 1 < b) { out.push_back(c); out.push_back(in[++i]); continue; }
         if (c == '"') in_string = !in_string;
         if (!ws || in_string) { out.push_back(c); continue; }
         size_t j = i;
-        while (j < n && (in[j] == 0x20 || in[j] == 0x09 || in[j] == 0x0a || in[j] == 0x0d)) ++j;
-        const bool digit_before = out.size() > 8 && out.back() >= '0' && out.back() <= '9';
-        const bool digit_after = j < n && in[j] >= '0' && in[j] <= '9';
-        if (digit_before && digit_after) return false;          // "1 2": two number tokens without a separator
+        while (j < b && (in[j] == 0x20 || in[j] == 0x09 || in[j] == 0x0a || in[j] == 0x0d)) ++j;
+        const bool digit_before = !out.empty() && out.back() >= '0' && out.back() <= '9';
+        const bool digit_after = j < b && in[j] >= '0' && in[j] <= '9';
+        if (digit_before && digit_after) return false;
         i = j - 1;
     }
+    return true;
+}
+// in: a whole frame (8-byte prefix + JSON text).  out: the canonical compact frame of the same message, or err set.
+static bool normalise_message(const std::vector<unsigned char>& in, std::vector<unsigned char>& out, std::string& err) {
+    JsonScan sc{in.data(), in.size(), 8, {}};
+    auto bad = [&](const char* what) { err = sc.err.empty() ? what : sc.err; return false; };
+    sc.ws();
+    if (sc.i >= sc.n || sc.p[sc.i] != '{') return bad("malformed message: expected an object");
+    ++sc.i;
+    size_t rid_a = 0, rid_b = 0, arr_a = 0, arr_b = 0;
+    bool have_rid = false, have_payload = false;
+    std::string variant;
+    sc.ws();
+    if (sc.i < sc.n && sc.p[sc.i] == '}') ++sc.i;
+    else while (true) {
+        sc.ws();
+        std::string key;
+        if (!sc.string(&key)) return bad("malformed message: field name");
+        sc.ws();
+        if (sc.i >= sc.n || sc.p[sc.i] != ':') return bad("malformed message: expected ':'");
+        ++sc.i;
+        if (key == "result_id") {
+            if (have_rid) return bad("malformed message: duplicate field `result_id`");
+            have_rid = true;
+            sc.ws(); rid_a = sc.i;
+            if (sc.i >= sc.n || !((sc.p[sc.i] >= '0' && sc.p[sc.i] <= '9') || sc.p[sc.i] == '-')) return bad("malformed message: result_id");
+            if (!sc.number()) return bad("malformed message: result_id");
+            rid_b = sc.i;
+        } else if (key == "payload") {
+            if (have_payload) return bad("malformed message: duplicate field `payload`");
+            have_payload = true;
+            sc.ws();
+            if (sc.i >= sc.n || sc.p[sc.i] != '{') return bad("malformed message: payload");
+            ++sc.i; sc.ws();
+            if (!sc.string(&variant)) return bad("malformed message: payload variant");
+            sc.ws();
+            if (sc.i >= sc.n || sc.p[sc.i] != ':') return bad("malformed message: payload");
+            ++sc.i; sc.ws(); arr_a = sc.i;
+            if (sc.i >= sc.n || sc.p[sc.i] != '[') return bad("malformed message: payload");
+            if (!sc.value(1)) return bad("malformed message: payload");
+            arr_b = sc.i; sc.ws();
+            if (sc.i >= sc.n || sc.p[sc.i] != '}') return bad("malformed message: payload is not a single-variant object");
+            ++sc.i;
+        } else if (!sc.value(1)) {
+            return bad("malformed message: value of an unknown field");
+        }
+        sc.ws();
+        if (sc.i >= sc.n) return bad("malformed message: unexpected end");
+        if (sc.p[sc.i] == ',') { ++sc.i; continue; }
+        if (sc.p[sc.i] == '}') { ++sc.i; break; }
+        return bad("malformed message: expected ',' or '}'");
+    }
+    sc.ws();
+    if (sc.i != sc.n) return bad("malformed message: trailing characters");
+    if (!have_rid) return bad("malformed message: missing field `result_id`");
+    if (!have_payload) return bad("malformed message: missing field `payload`");
+    if (variant != "ScalarBatch" && variant != "PointBatch") return bad("unsupported payload variant");
+    out.assign(8, 0);
+    auto lit = [&](const char* t) { out.insert(out.end(), (const unsigned char*)t, (const unsigned char*)t + strlen(t)); };
+    lit("{\"result_id\":");
+    out.insert(out.end(), in.begin() + rid_a, in.begin() + rid_b);
+    lit(",\"payload\":{\""); lit(variant.c_str()); lit("\":");
+    if (!append_stripped(in.data(), arr_a, arr_b, out)) return bad("malformed message: whitespace inside a number");
+    lit("}}");
     const u64 len = out.size() - 8;
     for (int k = 0; k < 8; ++k) out[k] = (unsigned char)(len >> (8 * k));
     return true;
@@ -363,7 +523,7 @@ int arkmpc_wire_encode_bytes32(arkmpc_ctx* ctx, int kind, uint64_t result_id, si
 
 static int decode_strict(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
                          size_t* out_n, uint64_t* out_result_id, int* out_kind);
-// Entry: the strict GPU parser; a frame it rejects that contains JSON whitespace is normalised (host, rare) and parsed again.
+// Entry: the strict GPU parser; a frame it rejects is re-read on the host (rare) with serde's object semantics and, if it is a message, parsed again.
 static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
                        size_t* out_n, uint64_t* out_result_id, int* out_kind) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
@@ -371,33 +531,24 @@ static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, 
     if (guard.rc) return guard.rc;
     if (!frame || !out_n) return ark_bad(ctx, "null frame / out_n");
     if (frame_len < 8 + 30) return ark_bad(ctx, "frame too short");
-    // The strict GPU parser runs FIRST: serde_json::to_vec -- what a reference peer sends -- never emits whitespace, so the common frame
-    // costs no whitespace scan, no extra launch and no extra synchronisation.  Only a frame the strict parser rejects is examined for
-    // JSON whitespace (which serde_json::from_slice accepts) and, if it has any, normalised on the host and parsed again.
+    // The strict GPU parser runs FIRST: serde_json::to_vec -- what a reference peer sends -- emits the compact form, so the common frame
+    // costs no extra scan, launch or synchronisation.
     if (!ctx->host_buffers && ((uintptr_t)frame & 15)) return ark_bad(ctx, "device pointer not 16-byte aligned");
     const int strict_rc = decode_strict(ctx, frame, frame_len, max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
     if (strict_rc != ARKMPC_ERR_BAD_ARG) return strict_rc;
     std::string strict_err;
     { std::lock_guard<std::mutex> lk(ctx->err_mu); strict_err = ctx->err; }
-    bool ws = false;
-    if (ctx->host_buffers) {
-        ws = host_has_ws(frame, frame_len);
-    } else {
-        ARK_HIP(ctx, hipMemsetAsync(ctx->d_flag + 4, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_wire_has_ws, dim3(blocks_for((frame_len + 15) / 16, WIRE_TPB)), dim3(WIRE_TPB), 0, ctx->stream, frame, frame_len, ctx->d_flag + 4);
-        ARK_HIP(ctx, hipMemcpyAsync(ctx->h_flag + 12, ctx->d_flag + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        ARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ws = ctx->h_flag[12] != 0;
-    }
-    if (!ws) { ark_set_err(ctx, strict_err); return strict_rc; }
-    // the declared length covers the text as sent, whitespace included
+    // the frame is not in serde_json::to_vec's compact form.  It may still be a NetworkOutbound message as serde_json::from_slice reads one
+    // (whitespace between tokens, fields in another order, unknown fields, escaped keys): re-read it on the host and, if so, canonicalise it.
     std::vector<unsigned char> raw(frame_len), norm;
     if (ctx->host_buffers) memcpy(raw.data(), frame, frame_len);
     else { ARK_HIP(ctx, hipMemcpyAsync(raw.data(), frame, frame_len, hipMemcpyDeviceToHost, ctx->stream)); ARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
     u64 declared = 0;
     for (int k = 0; k < 8; ++k) declared |= (u64)raw[k] << (8 * k);
     if (declared != frame_len - 8) return ark_bad(ctx, "length prefix does not match the frame");
-    if (!normalise_ws(raw, norm)) return ark_bad(ctx, "malformed message: whitespace inside a number");
+    std::string why;
+    if (!normalise_message(raw, norm, why)) { ark_set_err(ctx, why.empty() ? strict_err : why); return ARKMPC_ERR_BAD_ARG; }
+    if (norm.size() == raw.size() && memcmp(norm.data(), raw.data(), raw.size()) == 0) { ark_set_err(ctx, strict_err); return strict_rc; }   // already canonical: the strict verdict stands
     if (norm.size() < 8 + 30) return ark_bad(ctx, "frame too short");
     if (ctx->host_buffers) return decode_strict(ctx, norm.data(), norm.size(), max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
     void* dcopy = nullptr;

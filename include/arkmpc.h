@@ -420,9 +420,11 @@ int arkmpc_edshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64
  * Frame pointers follow the context's buffer mode like every other buffer.  Encoders and decoders block (the frame
  * length / element count is data dependent).  Decoders validate the whole grammar: a byte > 255, a scalar >= the modulus or
  * any syntax error returns ARKMPC_ERR_BAD_ARG (serde_json / deserialize_uncompressed would return an error to the caller,
- * scalar.rs:195-201).  JSON whitespace between tokens is accepted, as serde_json::from_slice accepts it (such a frame is
- * normalised on the host first; serde_json::to_vec, what a reference peer sends, never emits whitespace).  Still stricter than
- * serde's derive: the two fields must come in declaration order (result_id, payload) and no unknown fields are skipped.
+ * scalar.rs:195-201).  A frame that is not in serde_json::to_vec's compact form (what a reference peer sends and the GPU parser reads
+ * directly) is re-read on the host with the semantics serde_json::from_slice gives a derived struct (network/quic.rs:233-251): JSON
+ * whitespace between tokens, the two fields in any order, unknown fields skipped whatever value they hold, escaped keys compared after
+ * unescaping, a known field given twice = error, the payload an object with exactly one variant key, nothing but whitespace after the
+ * closing brace, nesting limited to 128 levels -- and, if it is a message, rewritten to the compact form and parsed on the GPU.
  * A device-mode frame buffer needs no padding: no byte at or beyond frame_len is read. */
 #define ARKMPC_WIRE_SCALAR_BATCH 0
 #define ARKMPC_WIRE_POINT_BATCH 1

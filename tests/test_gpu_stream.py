@@ -358,20 +358,23 @@ def test_host_buffer_mode_large_ops_vs_oracle(pkg, oracle, fid, n, pinned):
 
 
 @pytest.mark.parametrize("pinned", [True, False])
-def test_host_buffer_mode_in_place_and_repeated_operands(pkg, oracle, pinned):
-    """out aliases an input (ScalarResult ops are often written in place by callers), and one vector passed twice"""
+@pytest.mark.parametrize("stream_kind", ["own", "torch_default"])
+def test_host_buffer_mode_in_place_and_repeated_operands(pkg, oracle, pinned, stream_kind):
+    """out aliases an input (ScalarResult ops are often written in place by callers), and one vector passed twice; two rounds with different
+    values so that the second round's kernels would see the first round's data in the arena if they ran ahead of their uploads; with the context on
+    its own stream and on torch's default (NULL) stream"""
     fid, n = 0, 300000
-    e = pkg.Engine(fid, device=0, host_buffers=True)
+    e = pkg.Engine(fid, device=0, host_buffers=True, stream=None if stream_kind == "own" else torch.cuda.current_stream().cuda_stream)
     arena = _PinnedArena(pkg)
-    a0 = _tile(mont_array(fid, mixed_values(fid, 1000, 9)), 4, n)
-    want = oracle.scalar_mul(fid, a0, a0)
-    a = arena.copy(a0) if pinned else a0
-    out = arena.zeros(4 * n) if pinned else np.zeros(4 * n, dtype=np.uint64)
-    e.scalar_mul(n, a, a, out)
-    assert np.array_equal(out, want)
-    buf = arena.copy(a0) if pinned else a0.copy()
-    e.scalar_mul(n, buf, buf, buf)
-    assert np.array_equal(buf, want)
+    for seed in (9, 10):
+        a0 = _tile(mont_array(fid, mixed_values(fid, 1000, seed)[::-1 if seed & 1 else 1]), 4, n)
+        want = oracle.scalar_mul(fid, a0, a0)
+        a = arena.copy(a0) if pinned else a0
+        out = arena.zeros(4 * n) if pinned else np.zeros(4 * n, dtype=np.uint64)
+        e.scalar_mul(n, a, a, out)
+        assert np.array_equal(out, want)
+        buf = arena.copy(a0) if pinned else a0.copy()
+        e.scalar_mul(n, buf, buf, buf)
+        assert np.array_equal(buf, want)
     e.close()
-    del a, out, buf
     arena.free()

@@ -142,53 +142,91 @@ def test_large_round_trip_device_buffers(pkg):
     assert (cnt, rid) == (n, 99) and torch.equal(back, x)
 
 
+import json
 import re
 
-_NUM = r"(?:0|[1-9][0-9]?|1[0-9][0-9]|2[0-4][0-9]|25[0-5])"
-_ELEM = r"\[" + _NUM + r"(?:," + _NUM + r"){31}\]"
-_STRICT = re.compile(r'\{"result_id":(0|[1-9][0-9]{0,19}),"payload":\{"ScalarBatch":\[(?:' + _ELEM + r"(?:," + _ELEM + r")*)?\]\}\}\Z")
+_UINT = re.compile(r"(?:0|[1-9][0-9]*)\Z")
 
 
-def normalise_ws(body):
-    """JSON whitespace between tokens dropped (serde_json::from_slice skips it); None when a run of whitespace separates two digits
-    (two number tokens without a comma).  Whitespace inside a string stays: the key then no longer matches."""
-    out = bytearray()
-    in_string = False
-    i, n = 0, len(body)
-    while i < n:
-        c = body[i]
-        if c == 0x22:
-            in_string = not in_string
-        if c not in b" \t\n\r" or in_string:
-            out.append(c); i += 1
-            continue
-        j = i
-        while j < n and body[j] in b" \t\n\r":
-            j += 1
-        if out and chr(out[-1]).isdigit() and j < n and chr(body[j]).isdigit():
+class _Obj(list):
+    """a JSON object as its list of (key, value) pairs: duplicates and order stay visible"""
+
+
+def _no_const(_s):
+    raise ValueError("NaN / Infinity are not JSON")
+
+
+def _strings_and_depth(v, depth=1):
+    """(every string in v, deepest nesting) -- depth counts like the decoder: a field's value is level 1"""
+    if isinstance(v, _Obj):
+        out, deepest = [], depth
+        for k, x in v:
+            ss, d = _strings_and_depth(x, depth + 1)
+            out += [k] + ss; deepest = max(deepest, d)
+        return out, deepest
+    if isinstance(v, list):
+        out, deepest = [], depth
+        for x in v:
+            ss, d = _strings_and_depth(x, depth + 1)
+            out += ss; deepest = max(deepest, d)
+        return out, deepest
+    return ([v] if isinstance(v, str) else []), depth
+
+
+def serde_model(fid, body, variant="ScalarBatch"):
+    """What serde_json::from_slice::<NetworkOutbound> makes of `body` (network.rs:33-60, quic.rs:233-251), restated with Python's json: the
+    (result_id, [values]) of a `variant` message or None.  Fields in any order, unknown fields skipped, a known field twice = error, keys
+    compared after unescaping, exactly one variant key in the payload, integers only where integers are expected, scalars canonical."""
+    try:
+        text = body.decode("utf-8")
+        msg = json.loads(text, object_pairs_hook=_Obj, parse_int=lambda t: ("int", t), parse_float=lambda t: ("float", t), parse_constant=_no_const)
+    except (ValueError, RecursionError):
+        return None
+    if not isinstance(msg, _Obj):
+        return None
+    strings, depth = _strings_and_depth(msg, 0)
+    if depth > 128 or any(0xD800 <= ord(ch) <= 0xDFFF for st in strings for ch in st):       # serde_json: recursion limit, no lone surrogates
+        return None
+    rid = payload = None
+    for k, v in msg:
+        if k == "result_id":
+            if rid is not None:
+                return None
+            rid = v
+        elif k == "payload":
+            if payload is not None:
+                return None
+            payload = v
+    if rid is None or payload is None:
+        return None
+    if not (isinstance(rid, tuple) and rid[0] == "int" and _UINT.match(rid[1]) and int(rid[1]) < 1 << 64):
+        return None
+    if not (isinstance(payload, _Obj) and len(payload) == 1 and payload[0][0] == variant and isinstance(payload[0][1], list) and not isinstance(payload[0][1], _Obj)):
+        return None
+    vals = []
+    for e in payload[0][1]:
+        if not (isinstance(e, list) and not isinstance(e, _Obj) and len(e) == 32):
             return None
-        i = j
-    return bytes(out)
+        bs = []
+        for t in e:
+            if not (isinstance(t, tuple) and t[0] == "int" and _UINT.match(t[1]) and int(t[1]) <= 255):
+                return None
+            bs.append(int(t[1]))
+        v = int.from_bytes(bytes(bs), "little")
+        if v >= pyref.P[fid]:
+            return None
+        vals.append(v)
+    return int(rid[1]), vals
 
 
 def strict_accepts(fid, body):
-    """The serde_json text of a ScalarBatch message (whitespace between tokens allowed) and nothing else; scalars canonical; id fits a u64."""
-    body = normalise_ws(body)
-    if body is None:
-        return False
-    m = _STRICT.match(body.decode("latin-1"))
-    if not m or int(m.group(1)) >= 1 << 64:
-        return False
-    import json
-    return all(int.from_bytes(bytes(e), "little") < pyref.P[fid] for e in json.loads(body)["payload"]["ScalarBatch"])
+    return serde_model(fid, body) is not None
 
 
 @pytest.mark.gpu
 def test_decoder_agrees_with_strict_grammar_on_mutated_frames(hip, pkg):
-    """400 random byte edits of valid frames (replace / insert / delete, biased to structural characters): the GPU
-    decoder accepts exactly the frames a strict regular-expression model of the compact grammar accepts, and when it
-    accepts, the values are the ones Python's json reads."""
-    import json
+    """400 random byte edits of valid frames (replace / insert / delete, biased to structural characters): the decoder accepts exactly the
+    frames the serde model above accepts, and when it accepts, the values are the model's."""
     import random
     fid = 0
     rng = random.Random(20260928)
@@ -217,10 +255,95 @@ def test_decoder_agrees_with_strict_grammar_on_mutated_frames(hip, pkg):
         assert got == want, (trial, bytes(body)[:120])
         if got:
             accepted += 1
-            msg = json.loads(normalise_ws(bytes(body)))
-            assert rid == msg["result_id"] and cnt == len(msg["payload"]["ScalarBatch"])
-            assert np.array_equal(out[:4 * cnt], mont_array(fid, [int.from_bytes(bytes(e), "little") for e in msg["payload"]["ScalarBatch"]]))
+            want_rid, want_vals = serde_model(fid, bytes(body))
+            assert rid == want_rid and cnt == len(want_vals)
+            assert np.array_equal(out[:4 * cnt], mont_array(fid, want_vals))
     assert 40 < accepted < 360          # the mutation mix exercises both outcomes
+
+
+def _object_shapes(fid, vals, rid):
+    """(name, text, is a message) for frames serde_json::from_slice reads differently from a strict compact-form parser"""
+    compact = pyref.wire_frame("ScalarBatch", rid, pyref.wire_scalar_records(fid, vals))[8:]
+    arr = compact[compact.index(b":[") + 1:-2]                       # the [[..],[..]] text
+    R, P = b'"result_id":%d' % rid, b'"payload":{"ScalarBatch":' + arr + b"}"
+    deep = lambda k: b"[" * k + b"]" * k
+    yield "fields swapped", b"{" + P + b"," + R + b"}", True
+    yield "unknown field first", b'{"version":3,' + R + b"," + P + b"}", True
+    yield "unknown fields with nested values", b'{"a":{"b":[1,2,{"c":null}],"d":"x\\\"y\u00e9"},' + R + b',"z":[true,false,-1.5e-3],' + P + b',"tail":""}', True
+    yield "unknown field twice", b'{"x":1,"x":2,' + R + b"," + P + b"}", True
+    yield "escaped known key", b'{"result\u005fid":%d,' % rid + P + b"}", True
+    yield "escaped variant key", b"{" + R + b',"payload":{"Scalar\u0042atch":' + arr + b"}}", True
+    yield "whitespace everywhere + swapped", b" \n{ " + P.replace(b":", b" : ", 2) + b" ,\t" + R + b" }\r\n", True
+    yield "unknown value nested 100 deep", b'{"deep":' + deep(100) + b"," + R + b"," + P + b"}", True
+    yield "duplicate result_id", b"{" + R + b"," + R + b"," + P + b"}", False
+    yield "duplicate payload", b"{" + P + b"," + R + b"," + P + b"}", False
+    yield "duplicate via escape", b'{"result\u005fid":1,' + R + b"," + P + b"}", False
+    yield "missing payload", b"{" + R + b',"payloads":{}}', False
+    yield "missing result_id", b'{"result id":1,' + P + b"}", False
+    yield "two variants", b"{" + R + b',"payload":{"ScalarBatch":' + arr + b',"PointBatch":[]}}', False
+    yield "empty payload object", b"{" + R + b',"payload":{}}', False
+    yield "payload not an object", b"{" + R + b',"payload":' + arr + b"}", False
+    yield "unknown variant", b"{" + R + b',"payload":{"ScalarBatches":' + arr + b"}}", False
+    yield "trailing characters", b"{" + R + b"," + P + b"} x", False
+    yield "two messages", b"{" + R + b"," + P + b"}{}", False
+    yield "float result_id", b'{"result_id":%d.0,' % rid + P + b"}", False
+    yield "negative zero result_id", b'{"result_id":-0,' + P + b"}", False
+    yield "string result_id", b'{"result_id":"%d",' % rid + P + b"}", False
+    yield "lone surrogate in an unknown field", b'{"s":"\ud800",' + R + b"," + P + b"}", False
+    yield "surrogate pair in an unknown field", b'{"s":"\ud83d\ude00",' + R + b"," + P + b"}", True
+    yield "raw control character in a string", b'{"s":"a\x01b",' + R + b"," + P + b"}", False
+    yield "invalid utf-8 in a string", b'{"s":"\xff",' + R + b"," + P + b"}", False
+    yield "bad literal", b'{"s":nul,' + R + b"," + P + b"}", False
+    yield "leading zero in an unknown number", b'{"s":01,' + R + b"," + P + b"}", False
+    yield "unknown value nested 200 deep", b'{"deep":' + deep(200) + b"," + R + b"," + P + b"}", False
+    yield "byte order mark", b"\xef\xbb\xbf{" + R + b"," + P + b"}", False
+    yield "top-level array", b"[" + R[12:] + b"]", False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_frame", [False, True])
+def test_decoder_has_serde_object_semantics(hip, pkg, device_frame):
+    """network/quic.rs:233-251 reads a message with serde_json::from_slice into a derived struct: field order is free, unknown fields are skipped,
+    duplicates of known fields are errors, keys are unescaped before they are compared.  Every shape below is also run through the Python
+    model, so the test pins model and decoder against each other as well as against the expectation written next to the shape."""
+    fid, rid = 0, 41
+    vals = [0, 1, pyref.P[fid] - 1, 255, 256, 10 ** 30]
+    n = len(vals)
+    if device_frame:
+        import torch
+        e = pkg.Engine(fid, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    else:
+        e = hip.eng(fid)
+    for name, text, is_msg in _object_shapes(fid, vals, rid):
+        assert (serde_model(fid, text) is not None) == is_msg, name
+        frame = struct.pack("<Q", len(text)) + text
+        arr = np.frombuffer(frame, dtype=np.uint8).copy()
+        out = np.zeros(4 * n, dtype=np.uint64)
+        try:
+            if device_frame:
+                dfr = torch.from_numpy(arr).cuda(); dout = torch.zeros(4 * n, dtype=torch.int64, device="cuda")
+                cnt, got_rid = e.wire_decode_scalar_batch(dfr, len(frame), n, dout)
+                out = dout.cpu().numpy().view(np.uint64)
+            else:
+                cnt, got_rid = e.wire_decode_scalar_batch(arr, len(frame), n, out)
+            ok = True
+        except pkg.ArkMpcError:
+            ok = False
+        assert ok == is_msg, name
+        if ok:
+            assert (cnt, got_rid) == (n, rid) and np.array_equal(out, mont_array(fid, vals)), name
+    if device_frame:
+        e.close()
+
+
+def test_serde_model_reads_the_compact_form():
+    """the model itself against the literal known answer (CPU)"""
+    v = 1 + 255 * 256 + (10 << 248)
+    body = b'{"result_id":7,"payload":{"ScalarBatch":[[1,255' + b",0" * 29 + b",10]]}}"
+    assert serde_model(0, body) == (7, [v % (1 << 256)]) or v >= pyref.P[0]
+    assert serde_model(0, body.replace(b'"result_id":7,', b"") ) is None
+    assert serde_model(0, b'{"payload":{"ScalarBatch":[]},"result_id":18446744073709551615}') == ((1 << 64) - 1, [])
+    assert serde_model(0, b'{"payload":{"ScalarBatch":[]},"result_id":18446744073709551616}') is None
 
 
 # ---- round 2: JSON whitespace is accepted as serde_json::from_slice accepts it; exact-size device frames are never over-read ----
