@@ -1083,6 +1083,12 @@ def main():
     # parity on every rank (N = 1 runs the full-size comparison below instead)
     rank_exact = None
     if dist is not None and not args.no_check:
+        # the checker library is (re)built by `make` on first load: one rank of the node does that, the others load the finished file
+        if local_rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_api
+            oracle_api.load()
+        dist.barrier()
         exact_r, m_r = per_rank_oracle_check(parties, n, chunks, args.layout)
         ok = ok and exact_r == m_r
         rank_exact = {"gates_checked_per_rank": m_r, "ranks_all_exact": bool(reduce_over_ranks(1.0 if exact_r == m_r else 0.0, dist.ReduceOp.MIN) == 1.0)}
