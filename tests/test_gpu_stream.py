@@ -378,3 +378,52 @@ def test_host_buffer_mode_in_place_and_repeated_operands(pkg, oracle, pinned, st
         assert np.array_equal(buf, want)
     e.close()
     arena.free()
+
+
+def test_hostmul_soak_random_sizes_two_threads(pkg, oracle):
+    """300 sessions of random sizes (1 ... 40000 gates, so both the single-chunk and the chunked schedules, pinned and unpinned buffer sizes) from
+    two host threads with a context each, the parties' payloads crossing between the threads; every result against the oracle.  Leaks of
+    events, pins or device blocks would show as errors or as a growing pool; ordering bugs as wrong words."""
+    import random
+    fid = 0
+    rng = random.Random(4242)
+    base_n = 40000
+    _, keys, sh = _inputs(fid, base_n, seed=777, tile_from=2500)
+    ode_full, want_full = None, None
+    es = [pkg.Engine(fid, device=0) for _ in (0, 1)]
+    sizes = [rng.choice([1, 2, 63, 257, 1000, 4097, 16384, 16385, 33000, base_n]) for _ in range(150)]
+    offs = [rng.randrange(0, base_n - n + 1) for n in sizes]
+    bar = threading.Barrier(2)
+    errs = []
+    de = [[None] * len(sizes), [None] * len(sizes)]
+    out = [[None] * len(sizes), [None] * len(sizes)]
+
+    def party(p):
+        try:
+            torch.cuda.set_device(0)
+            for k, (n, o) in enumerate(zip(sizes, offs)):
+                sl = lambda a: a[8 * o: 8 * (o + n)]
+                de[p][k] = np.zeros(8 * n, dtype=np.uint64); out[p][k] = np.zeros(8 * n, dtype=np.uint64)
+                s = es[p].hostmul_begin(n, sl(sh["x"][p]), sl(sh["y"][p]), sl(sh["a"][p]), sl(sh["b"][p]), sl(sh["c"][p]), de[p][k])
+                es[p].hostmul_wait_de(s)
+                bar.wait(timeout=60)
+                es[p].hostmul_finish(s, p, keys[p], de[1 - p][k], out[p][k])
+                bar.wait(timeout=60)                       # the peer must have finished reading my payload before the buffers go away
+        except Exception as ex:      # noqa: BLE001
+            errs.append(repr(ex))
+            try:
+                bar.abort()
+            except Exception:        # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=party, args=(p,)) for p in (0, 1)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs[:2]
+    for k, (n, o) in enumerate(zip(sizes, offs)):
+        sub = {nm: (np.ascontiguousarray(sh[nm][0][8 * o: 8 * (o + n)]), np.ascontiguousarray(sh[nm][1][8 * o: 8 * (o + n)])) for nm in "xyabc"}
+        ode, want = _oracle_two_party(oracle, fid, n, keys, sub)
+        for p in (0, 1):
+            assert np.array_equal(de[p][k], ode[p]) and np.array_equal(out[p][k], want[p]), (k, n, o, p)
+    for e in es:
+        e.close()
