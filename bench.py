@@ -736,12 +736,29 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
         exact += int(good.sum())
     ok = ok and exact == 2 * m
     best = registered if registered["party_gates_per_s"] >= pageable["party_gates_per_s"] else pageable
+    # the reference's own bench shape, literally (benches/batch_ops.rs:19-39: share x, share y, batch_mul, open_authenticated_batch; both parties
+    # in-process, time = max over the parties), through the C++ host mirror: its own binary, run as a subprocess
+    ref_shape = {}
+    exe = os.path.join(ROOT, "ark-mpc_amd", "lib", "arkmpc_host_bench")
+    if os.path.exists(exe):
+        import subprocess
+        for link in ("host", "device"):
+            try:
+                r = subprocess.run([exe, "batch_ops", str(n), "2"], capture_output=True, text=True, timeout=180, env=dict(os.environ, ARKMPC_MOCK_LINK=link))
+                dd = json.loads(r.stdout.strip().splitlines()[-1])
+                ref_shape[link + "_link"] = {"ms": dd["seconds"] * 1e3, "elements_per_s": dd["elements_per_s"]}
+            except Exception as ex:      # noqa: BLE001
+                ref_shape[link + "_link"] = {"error": repr(ex)[:200]}
+        ref_shape["what"] = ("benches/batch_ops.rs:19-39 as written, n = 2^%d: batch_share_scalar x 2, batch_mul, open_authenticated_batch (two sequential SHA3-256 sponges over 32 n "
+                             "bytes per party: ~45 ms each at 2^20, the floor of this shape), dummy Beaver source, host mirror (host/bench_main.cpp); host_link = payloads cross "
+                             "as host vectors, device_link = as HBM buffers" % log2n)
     return {"what": "host arkworks records in -> host records out, 2^%d Beaver muls over BN254 Fr per party (benches/batch_ops.rs shape); NOT the metric's `value`, "
                     "which is quoted with inputs resident in HBM" % log2n,
             "bytes_per_party_gate": {"up": E2E_UP_BYTES, "down": E2E_DOWN_BYTES},
             "party_gates_per_s": best["party_gates_per_s"], "two_party_gates_per_s": two.get("two_party_gates_per_s") if two else None,
             "h2d_GBps": best["h2d_GBps"], "d2h_GBps": best["d2h_GBps"], "frac_of_measured_pcie": best["frac_of_measured_pcie"],
             "one_party": {"pageable": pageable, "registered": registered}, "two_party_one_gpu": two, "measured_pcie": cal,
+            "reference_bench_shape": ref_shape,
             "link_floor_note": "one PCIe gen5 x16 link: a party-gate needs 384 B up, so the link's measured %.1f GB/s allows at most %.3g party-gates/s "
                                "(and half of that per two-party gate when both parties share the link)" % (cal["h2d_GBps"], cal["h2d_GBps"] * 1e9 / E2E_UP_BYTES),
             "results_check": "all 2^%d gates of both parties == the device-resident pipeline's records, and the first 2^%d gates == oracle (%d of %d party-gates exact): %s"
