@@ -107,3 +107,25 @@ def test_batch_carrier_on_gpu(tmp_path):
     import subprocess
     r = subprocess.run([_build_c_smoke(tmp_path, "batch_carrier")], capture_output=True, text=True)
     assert r.returncode == 0 and "batch carrier ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_hostmul_c_caller_builds_and_fails_loudly_without_gpu(tmp_path):
+    """tests/c/hostmul_session.c (the streaming host-to-host sessions driven from C99) compiles with -Werror -pedantic and links; without a GPU it
+    reports ARKMPC_ERR_NO_DEVICE"""
+    import subprocess
+    import torch
+    exe = _build_c_smoke(tmp_path, "hostmul_session")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "hostmul sessions ok" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_hostmul_sessions_from_c_on_gpu(tmp_path):
+    """both parties' sessions from C, malloc'ed and pinned vectors at an odd alignment, sizes on both sides of the chunking threshold == the two-call
+    host-buffer entry points word for word; misuse is a status and ends the session (tests/c/hostmul_session.c)"""
+    import subprocess
+    r = subprocess.run([_build_c_smoke(tmp_path, "hostmul_session")], capture_output=True, text=True)
+    assert r.returncode == 0 and "hostmul sessions ok" in r.stdout, r.stdout + r.stderr
