@@ -637,44 +637,57 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
         s = eng.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p])
         eng.hostmul_finish(s, p, keys[p], peer_de, out[p])
 
-    def timed_one(label):
+    def timed_one(label, fresh):
         """back_to_back: `reps` sessions one after the other, as a circuit of many gates keeps the link busy (the throughput figure).  isolated: one
-        session after the link has idled for a few ms.  Output buffers are cleared before the timed runs."""
+        session after the link has idled for a few ms.  fresh = every session gets NEWLY ALLOCATED vectors (inputs copied, outputs zeroed,
+        before the clock starts): a caller whose Vecs are new for every gate, the worst case for pinning in place.  Consecutive sessions
+        alternate between the two parties' inputs: the device block is recycled from session to session, so a kernel that ran ahead of its upload
+        would compute on the OTHER party's stale records and the check would catch it."""
         nonlocal ok
         one_party(0, want_de[1])                       # warm: device block, streams, events
-        for p in (0, 1):
-            de[p].fill(0); out[p].fill(0)
 
-        def run(k):
-            # consecutive sessions alternate between the two parties' inputs: the device block is recycled from session to session, so a kernel
-            # that ran ahead of its upload would compute on the OTHER party's stale records and the check below would catch it
+        def vectors(k):
             p = k & 1
-            s = eng.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p])
-            eng.hostmul_finish(s, p, keys[p], want_de[1 - p], out[p])
+            if not fresh:
+                de[p].fill(0); out[p].fill(0)
+                return p, H[p], de[p], out[p], want_de[1 - p]
+            d_, o_ = np.empty(8 * n, dtype=np.uint64), np.empty(8 * n, dtype=np.uint64)
+            d_.fill(0); o_.fill(0)
+            return p, {k_: v.copy() for k_, v in H[p].items()}, d_, o_, want_de[1 - p].copy()
 
+        def run(v):
+            p, ins, d_, o_, peer = v
+            s = eng.hostmul_begin(n, ins["x"], ins["y"], ins["a"], ins["b"], ins["c"], d_)
+            eng.hostmul_finish(s, p, keys[p], peer, o_)
+
+        def good(v):
+            p, _, d_, o_, _ = v
+            return bool(np.array_equal(d_, want_de[p]) and np.array_equal(o_, want_out[p]))
+
+        sets_ = [vectors(k) for k in range(reps)]
         t0 = time.perf_counter()
-        for k in range(reps):
-            run(k)
+        for v in sets_:
+            run(v)
         t = (time.perf_counter() - t0) / reps
-        for p in (0, 1):
-            ok = ok and np.array_equal(de[p], want_de[p]) and np.array_equal(out[p], want_out[p])
+        ok = ok and all(good(v) for v in (sets_ if fresh else sets_[-2:]))
+        del sets_
         iso = []
         for k in range(4):
+            v = vectors(k)
             time.sleep(0.004)
             t1 = time.perf_counter()
-            run(k)
+            run(v)
             iso.append(time.perf_counter() - t1)
-        for p in (0, 1):
-            ok = ok and np.array_equal(de[p], want_de[p]) and np.array_equal(out[p], want_out[p])
+            ok = ok and good(v)
         return {"buffers": label, "ms": t * 1e3, "ms_isolated_call": float(np.median(iso)) * 1e3, "party_gates_per_s": n / t,
                 "party_gates_per_s_isolated_call": n / float(np.median(iso)), "h2d_GBps": n * E2E_UP_BYTES / t / 1e9,
                 "d2h_GBps": n * E2E_DOWN_BYTES / t / 1e9, "frac_of_measured_pcie": (n * E2E_UP_BYTES / t / 1e9) / cal["h2d_GBps"]}
 
-    pageable = timed_one("pageable (numpy / Vec memory); pinned in place inside each call, unpinned at its end")
+    pageable = timed_one("pageable, NEW vectors for every session (numpy / Vec memory); pinned in place inside each call, unpinned as their last DMA completes", True)
     regs = [a for p in (0, 1) for a in list(H[p].values())] + de + out + want_de
     for a in regs:
         lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))
-    registered = timed_one("registered once by the caller (arkmpc_host_register), as a caller that keeps its vectors across gates would")
+    registered = timed_one("registered once by the caller (arkmpc_host_register), as a caller that keeps its vectors across gates would", False)
     # two parties on this one GPU, a context and a host thread each, payloads handed over in host memory (network/mock.rs moves host payloads)
     es = [pkg.Engine(FID, device=dev) for _ in (0, 1)]
     bar = threading.Barrier(2)
