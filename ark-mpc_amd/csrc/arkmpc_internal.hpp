@@ -127,6 +127,10 @@ static inline bool runtime_knows(const void* p) {
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
     return attr.type != hipMemoryTypeUnregistered;
 }
+// a whole range: its first and its last byte (a range that only begins inside somebody's registration is not pinned memory)
+static inline bool runtime_knows_range(const void* p, size_t bytes) {
+    return bytes && runtime_knows(p) && runtime_knows((const char*)p + bytes - 1);
+}
 struct PinRegistry {
     std::mutex mu;
     struct Ent { size_t bytes; int refs; };
@@ -140,7 +144,7 @@ struct PinRegistry {
             --it;
             if (a >= it->first && a + bytes <= it->first + it->second.bytes) { it->second.refs++; return it->first; }
         }
-        if (runtime_knows(p)) return 0;                                        // pinned by the caller already (or not host memory)
+        if (runtime_knows_range(p, bytes)) return 0;                           // pinned by the caller already (or not host memory)
         if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
         ents[a] = Ent{bytes, 1};
         return a;
@@ -360,8 +364,8 @@ struct Stage {
         if (rc) return rc;
         if (ew && ctx->host_buffers && stream_enabled() && ew_n && total >= stream_min_bytes()) {
             bool go = true;                                  // every buffer: segs x n elements of a whole number of bytes, and pinned by the caller
-            for (auto& i : ins) go = go && i.bytes % ((size_t)i.segs * ew_n) == 0 && (i.bytes < ((size_t)1 << 20) || runtime_knows(i.host));
-            for (auto& o : oplan) go = go && o.bytes % ((size_t)o.segs * ew_n) == 0 && (o.bytes < ((size_t)1 << 20) || runtime_knows(o.host));
+            for (auto& i : ins) go = go && i.bytes % ((size_t)i.segs * ew_n) == 0 && (i.bytes < ((size_t)1 << 20) || runtime_knows_range(i.host, i.bytes));
+            for (auto& o : oplan) go = go && o.bytes % ((size_t)o.segs * ew_n) == 0 && (o.bytes < ((size_t)1 << 20) || runtime_knows_range(o.host, o.bytes));
             if (go) return commit_streamed();
         }
         if (scratch_total) {
