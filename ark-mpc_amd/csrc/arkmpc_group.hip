@@ -575,42 +575,57 @@ int arkmpc_group_commit_sha3(arkmpc_group* g, size_t n, const uint64_t* const* v
 // Variable-base MSM over sharded (point, scalar) pairs: every member folds its range with the bucket method (arkmpc_g1_msm), the G
 // partial results are added on member 0 (CurvePoint::msm, curve.rs:549-560; the cross-GPU point reduction of SURVEY.md section 8f-3).
 // The per-member calls block on their Horner tails, so they run on one host thread each.  BN254 contexts only.
-int arkmpc_group_g1_msm(arkmpc_group* g, size_t n, const uint64_t* const* points, const uint64_t* const* scalars, uint64_t out_point[12]) {
+}  // extern "C"
+namespace {
+typedef int (*MsmFn)(arkmpc_ctx*, size_t, const uint64_t*, const uint64_t*, uint64_t*);
+typedef int (*SumFn)(arkmpc_ctx*, size_t, const uint64_t*, uint64_t*);
+// one bucket MSM per member over its range, the G partial points pushed to member 0 and added there; pw = u64 words of a point
+int group_msm(arkmpc_group* g, size_t n, const uint64_t* const* points, const uint64_t* const* scalars, uint64_t* out_point, size_t pw, int field, MsmFn msm, SumFn sum_fn,
+              const char* what) {
     if (!g) return ARKMPC_ERR_BAD_ARG;
     if (!out_point) return gbad(g, "null output");
-    if (g->field_id != ARKMPC_BN254_FR) { gset_err(g, "group MSM needs a BN254 Fr group"); return ARKMPC_ERR_UNSUPPORTED; }
+    if (g->field_id != field) { gset_err(g, what); return ARKMPC_ERR_UNSUPPORTED; }
     int rc = shards_ok(g, n, (const void* const*)points, "null point shard");
     if (!rc) rc = shards_ok(g, n, (const void* const*)scalars, "null scalar shard");
     if (rc) return rc;
+    const size_t pb = pw * 8;
     std::lock_guard<std::mutex> lk(g->mu);
     std::vector<void*> part(g->G, nullptr);
     std::vector<int> rcs(g->G, ARKMPC_OK);
-    for (int m = 0; m < g->G; ++m) { rc = arkmpc_malloc(g->ctx[m], 96, &part[m]); if (rc) { gfail(g, m, rc, "arkmpc_malloc"); break; } }
+    for (int m = 0; m < g->G; ++m) { rc = arkmpc_malloc(g->ctx[m], pb, &part[m]); if (rc) { gfail(g, m, rc, "arkmpc_malloc"); break; } }
     if (!rc) {
         std::vector<std::thread> th;
         for (int m = 0; m < g->G; ++m)
             th.emplace_back([&, m] {
                 size_t lo, cnt; range(g, n, m, &lo, &cnt);
-                rcs[m] = arkmpc_g1_msm(g->ctx[m], cnt, points[m], scalars[m], (u64*)part[m]);
+                rcs[m] = msm(g->ctx[m], cnt, points[m], scalars[m], (u64*)part[m]);
                 if (rcs[m] == ARKMPC_OK) rcs[m] = arkmpc_sync(g->ctx[m]);
             });
         for (auto& t : th) t.join();
-        for (int m = 0; m < g->G && !rc; ++m) if (rcs[m]) rc = gfail(g, m, rcs[m], "arkmpc_g1_msm");
+        for (int m = 0; m < g->G && !rc; ++m) if (rcs[m]) rc = gfail(g, m, rcs[m], "member MSM");
     }
     void* all = nullptr; void* sum = nullptr;
-    if (!rc) { rc = arkmpc_malloc(g->ctx[0], (size_t)g->G * 96, &all); if (rc) gfail(g, 0, rc, "arkmpc_malloc"); }
-    if (!rc) { rc = arkmpc_malloc(g->ctx[0], 96, &sum); if (rc) gfail(g, 0, rc, "arkmpc_malloc"); }
-    for (int m = 0; m < g->G && !rc; ++m) rc = push(g, m, 0, (char*)all + (size_t)m * 96, part[m], 96);
+    if (!rc) { rc = arkmpc_malloc(g->ctx[0], (size_t)g->G * pb, &all); if (rc) gfail(g, 0, rc, "arkmpc_malloc"); }
+    if (!rc) { rc = arkmpc_malloc(g->ctx[0], pb, &sum); if (rc) gfail(g, 0, rc, "arkmpc_malloc"); }
+    for (int m = 0; m < g->G && !rc; ++m) rc = push(g, m, 0, (char*)all + (size_t)m * pb, part[m], pb);
     for (int m = 1; m < g->G && !rc; ++m) {
         if (hipSetDevice(g->dev[m]) != hipSuccess || hipEventRecord(g->ev[m], g->ctx[m]->stream) != hipSuccess ||
             hipSetDevice(g->dev[0]) != hipSuccess || hipStreamWaitEvent(g->ctx[0]->stream, g->ev[m], 0) != hipSuccess) { gset_err(g, "event ordering failed"); rc = ARKMPC_ERR_HIP; }
     }
-    if (!rc) { rc = arkmpc_g1_sum(g->ctx[0], (size_t)g->G, (const u64*)all, (u64*)sum); if (rc) gfail(g, 0, rc, "arkmpc_g1_sum"); }
-    if (!rc) { rc = arkmpc_memcpy_d2h(g->ctx[0], out_point, sum, 96); if (rc) gfail(g, 0, rc, "arkmpc_memcpy_d2h"); }
+    if (!rc) { rc = sum_fn(g->ctx[0], (size_t)g->G, (const u64*)all, (u64*)sum); if (rc) gfail(g, 0, rc, "point sum"); }
+    if (!rc) { rc = arkmpc_memcpy_d2h(g->ctx[0], out_point, sum, pb); if (rc) gfail(g, 0, rc, "arkmpc_memcpy_d2h"); }
     for (int m = 0; m < g->G; ++m) if (part[m]) (void)arkmpc_free(g->ctx[m], part[m]);
     if (all) (void)arkmpc_free(g->ctx[0], all);
     if (sum) (void)arkmpc_free(g->ctx[0], sum);
     return rc;
+}
+}  // namespace
+extern "C" {
+int arkmpc_group_g1_msm(arkmpc_group* g, size_t n, const uint64_t* const* points, const uint64_t* const* scalars, uint64_t out_point[12]) {
+    return group_msm(g, n, points, scalars, out_point, 12, ARKMPC_BN254_FR, arkmpc_g1_msm, arkmpc_g1_sum, "group MSM over G1 needs a BN254 Fr group");
+}
+int arkmpc_group_ed_msm(arkmpc_group* g, size_t n, const uint64_t* const* points, const uint64_t* const* scalars, uint64_t out_point[16]) {
+    return group_msm(g, n, points, scalars, out_point, 16, ARKMPC_CURVE25519_FR, arkmpc_ed_msm, arkmpc_ed_sum, "group MSM over Curve25519 needs a CURVE25519_FR group");
 }
 
 }  // extern "C"

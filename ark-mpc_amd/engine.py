@@ -493,6 +493,11 @@ class Group:
         self._ck(self.lib.arkmpc_group_g1_msm(self.h, ctypes.c_size_t(int(n)), self._sh(points), self._sh(scalars), ctypes.c_void_p(out.ctypes.data)))
         return out
 
+    def ed_msm(self, n, points, scalars):
+        out = np.zeros(16, dtype=np.uint64)
+        self._ck(self.lib.arkmpc_group_ed_msm(self.h, ctypes.c_size_t(int(n)), self._sh(points), self._sh(scalars), ctypes.c_void_p(out.ctypes.data)))
+        return out
+
 
 def sha3_256(data: bytes) -> bytes:
     lib = load_library()

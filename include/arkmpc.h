@@ -518,8 +518,10 @@ int arkmpc_group_mac_verify(arkmpc_group* grp, size_t n, const uint64_t* const* 
 int arkmpc_group_commit_sha3(arkmpc_group* grp, size_t n, const uint64_t* const* values, const uint64_t blinder[4],
                              uint64_t out_commitment[4]);
 /* CurvePoint::msm over sharded (point, scalar) pairs (curve.rs:549-560): one bucket MSM per member, the G partial points added on
- * member 0; out_point = HOST pointer to 12 x u64; blocks.  BN254 groups only. */
+ * member 0; out_point = HOST pointer to 12 x u64; blocks.  BN254 Fr groups. */
 int arkmpc_group_g1_msm(arkmpc_group* grp, size_t n, const uint64_t* const* points, const uint64_t* const* scalars, uint64_t out_point[12]);
+/* the same on a CURVE25519_FR group: 16-word extended points (curve.rs:549-560 is generic over C) */
+int arkmpc_group_ed_msm(arkmpc_group* grp, size_t n, const uint64_t* const* points, const uint64_t* const* scalars, uint64_t out_point[16]);
 
 #ifdef __cplusplus
 }
