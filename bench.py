@@ -729,9 +729,36 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
         two = {"ms": t * 1e3, "two_party_gates_per_s": n / t, "h2d_GBps": 2 * n * E2E_UP_BYTES / t / 1e9, "d2h_GBps": 2 * n * E2E_DOWN_BYTES / t / 1e9,
                "frac_of_measured_pcie": (2 * n * E2E_UP_BYTES / t / 1e9) / cal["h2d_GBps"],
                "marks_ms_last_round": {"what": "per party: begin returned, own d||e complete in host memory, peer's payload available, finish returned", "p0": marks[0][-1], "p1": marks[1][-1]},
-               "what": "both parties on this ONE GPU and its one PCIe link, one host thread + context each, d||e handed over in host memory; 768 B up per two-party gate"}
+               "what": "the same with one host thread + context PER PARTY (execute_mock_mpc's shape): the two parties' uploads race each other on the link and both lose"}
     for e_ in es:
         e_.close()
+    # the same two parties driven by ONE host thread on ONE context, both sessions open at once (how an in-process mock -- one process, both
+    # parties -- naturally drives one GPU): the two parties' uploads then queue on one stream instead of racing each other on the link
+    two_threads = two
+    eng1 = pkg.Engine(FID, device=dev)
+
+    def one_thread_round():
+        ss = [eng1.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p]) for p in (0, 1)]
+        for p in (0, 1):
+            eng1.hostmul_wait_de(ss[p])
+        for p in (0, 1):
+            eng1.hostmul_finish(ss[p], p, keys[p], de[1 - p], out[p])
+
+    one_thread_round()
+    for p in (0, 1):
+        de[p].fill(0); out[p].fill(0)
+    ts1 = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); one_thread_round(); ts1.append(time.perf_counter() - t0)
+    ok1 = all(np.array_equal(de[p], want_de[p]) and np.array_equal(out[p], want_out[p]) for p in (0, 1))
+    ok = ok and ok1
+    eng1.close()
+    t1 = float(np.median(ts1))
+    two = {"ms": t1 * 1e3, "two_party_gates_per_s": n / t1, "h2d_GBps": 2 * n * E2E_UP_BYTES / t1 / 1e9, "d2h_GBps": 2 * n * E2E_DOWN_BYTES / t1 / 1e9,
+           "frac_of_measured_pcie": (2 * n * E2E_UP_BYTES / t1 / 1e9) / cal["h2d_GBps"],
+           "what": "both parties on this ONE GPU and its one PCIe link, ONE host thread and context driving both parties' sessions (begin, begin, wait, wait, finish, finish), "
+                   "d||e handed over in host memory; 768 B up per two-party gate, so the link's floor is %.1f ms" % (2 * n * E2E_UP_BYTES / cal["h2d_GBps"] / 1e6),
+           "two_host_threads_two_contexts": two_threads}
     for a in regs:
         lib.arkmpc_host_unregister(ctypes.c_void_p(a.ctypes.data))
     # the oracle on a sample of the same host data (the device-resident buffers used as the expectation above are not an independent witness)
