@@ -106,6 +106,7 @@ static inline int arena_reserve(arkmpc_ctx* ctx, size_t bytes) {
 // the upload direction busy and hide the kernels and the downloads under it: three streams per context -- `up` (H2D DMA), the compute
 // stream, `down` (D2H DMA) -- ordered by events only, and the caller's buffers pinned in place so that the copies are true DMA.
 // ---------------------------------------------------------------------------------------------------------------------------------
+#include <atomic>
 #include <map>
 static inline int link_ensure(arkmpc_ctx* ctx) {
     if (ctx->up) return ARKMPC_OK;

@@ -427,3 +427,113 @@ def test_hostmul_soak_random_sizes_two_threads(pkg, oracle):
             assert np.array_equal(de[p][k], ode[p]) and np.array_equal(out[p][k], want[p]), (k, n, o, p)
     for e in es:
         e.close()
+
+
+# ---- zero-copy phases: vectors the caller pinned are read and written IN PLACE by k_hostmul_mask / k_hostmul_finish (no copy commands);
+# ---- each phase falls back to the DMA pipeline on its own.  The test hook counts the phases that ran zero-copy, so these tests also
+# ---- pin WHICH path produced the (identical) words.
+def _zc_count(pkg):
+    out = (ctypes.c_uint64 * 2)()
+    assert pkg.load_library().arkmpc_test_hostmul_zero_copy_phases(out) == 0
+    return int(out[0]), int(out[1])
+
+
+def _two_party_on(eng, n, keys, sh, place):
+    """_run_two_party with every vector put where `place(name, array)` says (pinned arena, pageable copy, shifted ...)"""
+    H = [{k: place(k, sh[k][p]) for k in "xyabc"} for p in (0, 1)]
+    de = [place("de", np.zeros(8 * n, dtype=np.uint64)) for _ in (0, 1)]
+    out = [place("out", np.zeros(8 * n, dtype=np.uint64)) for _ in (0, 1)]
+    ses = [eng.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p]) for p in (0, 1)]
+    for p in (0, 1):
+        eng.hostmul_wait_de(ses[p])
+        assert eng.hostmul_poll_de(ses[p]) == n
+    for p in (0, 1):
+        eng.hostmul_finish(ses[p], p, keys[p], de[1 - p], out[p])
+    return de, out
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2])
+@pytest.mark.parametrize("n", [4096, 4097, 70001])
+def test_hostmul_zero_copy_bitexact_vs_oracle(pkg, engs, oracle, fid, n):
+    """all eight vectors of both parties pinned: both phases run as kernels on the caller's memory; ragged last tile (n % 256 != 0)"""
+    arena = _PinnedArena(pkg)
+    _, keys, sh = _inputs(fid, n, seed=8100 + n, tile_from=3000)
+    before = _zc_count(pkg)
+    de, out = _two_party_on(engs[fid], n, keys, sh, lambda k, a: arena.copy(a))
+    after = _zc_count(pkg)
+    assert (after[0] - before[0], after[1] - before[1]) == (2, 2), "both phases of both parties must have run zero-copy"
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for party in (0, 1):
+        assert np.array_equal(de[party], ode[party]), "d||e of party %d" % party
+        assert np.array_equal(out[party], want[party]), "result of party %d" % party
+    arena.free()
+
+
+def test_hostmul_zero_copy_two_launches_per_phase(pkg, oracle):
+    """2^20 + 4173 gates: two launches per phase (one per 2^20 gates), the second one short and ragged; torch's default stream"""
+    fid, n = 0, (1 << 20) + 4173
+    arena = _PinnedArena(pkg)
+    e = pkg.Engine(fid, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    _, keys, sh = _inputs(fid, n, seed=8200, tile_from=4001)
+    before = _zc_count(pkg)
+    de, out = _two_party_on(e, n, keys, sh, lambda k, a: arena.copy(a))
+    after = _zc_count(pkg)
+    assert (after[0] - before[0], after[1] - before[1]) == (2, 2)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for party in (0, 1):
+        assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party]), "party %d" % party
+    e.close()
+    arena.free()
+
+
+@pytest.mark.parametrize("pageable", ["phase2", "phase1", "c_only", "x_only"])
+def test_hostmul_mixed_zero_copy_and_dma_phases(pkg, engs, oracle, pageable):
+    """one phase's vectors pageable, the other's pinned: the pinned phase runs zero-copy, the other through the copy pipeline, and they hand
+    a, b and d||e to each other in HBM.  c_only: c pageable -> it is uploaded, phase 2 still runs zero-copy on the peer's payload and the result."""
+    fid, n = 0, 70001
+    arena = _PinnedArena(pkg)
+    _, keys, sh = _inputs(fid, n, seed=8300, tile_from=3000)
+    loose = {"phase2": ("c", "out"), "phase1": ("x", "y", "a", "b", "de"), "c_only": ("c",), "x_only": ("x",)}[pageable]
+    # (de is both party p's phase-1 output and party 1-p's phase-2 input, so "phase1" makes the peer payloads pageable too: phase 2 then is DMA)
+    place = lambda k, a: (np.array(a) if k in loose else arena.copy(a))
+    before = _zc_count(pkg)
+    de, out = _two_party_on(engs[fid], n, keys, sh, place)
+    after = _zc_count(pkg)
+    got = (after[0] - before[0], after[1] - before[1])
+    # "phase1": party 0 finishes while party 1's session still holds its own d||e vector pinned (the library pinned it for the downloads), so
+    # party 0's phase 2 finds all of c, peer payload and result pinned and runs zero-copy; party 1's peer payload is pageable again by then
+    assert got == {"phase2": (2, 0), "phase1": (0, 1), "c_only": (2, 2), "x_only": (0, 2)}[pageable], got
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for party in (0, 1):
+        assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party]), "party %d" % party
+    arena.free()
+
+
+def test_hostmul_zero_copy_needs_16_byte_alignment_and_result_may_reuse_an_input(pkg, engs, oracle):
+    """pinned vectors at 8 mod 16 (a sub-slice of a pinned Vec) take the copy pipeline -- the kernels move 16-byte quarters --; and a result
+    vector that IS the x vector (dead after phase 1) or the c vector (same index, read before written within a tile) is fine in both modes"""
+    fid, n = 0, 20000
+    e = engs[fid]
+    arena = _PinnedArena(pkg)
+    _, keys, sh = _inputs(fid, n, seed=8400, tile_from=2000)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+
+    def shifted(k, a):
+        buf = arena.zeros(a.size + 2)
+        assert buf.ctypes.data % 16 == 0
+        v = buf[1:1 + a.size]; v[:] = a
+        return v
+    before = _zc_count(pkg)
+    de, out = _two_party_on(e, n, keys, sh, shifted)
+    assert _zc_count(pkg) == before
+    for party in (0, 1):
+        assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party])
+    for reuse, pin in (("x", True), ("c", True), ("c", False)):
+        for party in (0, 1):
+            put = (lambda a: arena.copy(a)) if pin else (lambda a: np.array(a))
+            H = {k: put(sh[k][party]) for k in "xyabc"}
+            my_de = put(np.zeros(8 * n, dtype=np.uint64)); peer = put(ode[1 - party])
+            s = e.hostmul_begin(n, H["x"], H["y"], H["a"], H["b"], H["c"], my_de)
+            e.hostmul_finish(s, party, keys[party], peer, H[reuse])
+            assert np.array_equal(my_de, ode[party]) and np.array_equal(H[reuse], want[party]), (reuse, pin, party)
+    arena.free()
