@@ -606,7 +606,7 @@ def pcie_calibration(mib=256):
     return out
 
 
-def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
+def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
     """SURVEY 8(d) "an end-to-end figure including H2D/D2H", in the shape of the reference's own bench (benches/batch_ops.rs:19-39: host values
     in, host values out, both parties in-process, time = max over the parties): every operand starts as arkworks ScalarShare records in HOST
     memory (what a Rust Vec<ScalarShare> is), the d||e payloads cross the host link in both directions as they would on a real network, the
@@ -637,6 +637,11 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
         s = eng.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p])
         eng.hostmul_finish(s, p, keys[p], peer_de, out[p])
 
+    def zero_copy_phases():
+        c_ = (ctypes.c_uint64 * 2)()
+        lib.arkmpc_test_hostmul_zero_copy_phases(c_)            # include/arkmpc_test_hooks.h: which path ran (a count, nothing timed depends on it)
+        return int(c_[0]), int(c_[1])
+
     def timed_one(label, fresh):
         """back_to_back: `reps` sessions one after the other, as a circuit of many gates keeps the link busy (the throughput figure).  isolated: one
         session after the link has idled for a few ms.  fresh = every session gets NEWLY ALLOCATED vectors (inputs copied, outputs zeroed,
@@ -645,6 +650,8 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
         would compute on the OTHER party's stale records and the check would catch it."""
         nonlocal ok
         one_party(0, want_de[1])                       # warm: device block, streams, events
+        t_ = time.perf_counter(); one_party(0, want_de[1]); est = time.perf_counter() - t_
+        reps = min(32, max(reps_min, int(np.ceil(0.04 / max(est, 1e-5)))))       # small batches: enough sessions for ~40 ms, so that one slow pin does not decide the mean
 
         def vectors(k):
             p = k & 1
@@ -665,10 +672,13 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
             return bool(np.array_equal(d_, want_de[p]) and np.array_equal(o_, want_out[p]))
 
         sets_ = [vectors(k) for k in range(reps)]
+        zc0 = zero_copy_phases()
+        each = []
         t0 = time.perf_counter()
         for v in sets_:
-            run(v)
+            t_ = time.perf_counter(); run(v); each.append((time.perf_counter() - t_) * 1e3)
         t = (time.perf_counter() - t0) / reps
+        zc1 = zero_copy_phases()
         ok = ok and all(good(v) for v in (sets_ if fresh else sets_[-2:]))
         del sets_
         iso = []
@@ -679,7 +689,10 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
             run(v)
             iso.append(time.perf_counter() - t1)
             ok = ok and good(v)
-        return {"buffers": label, "ms": t * 1e3, "ms_isolated_call": float(np.median(iso)) * 1e3, "party_gates_per_s": n / t,
+        zc = [(b - a) / reps for a, b in zip(zc0, zc1)]
+        return {"buffers": label, "path": {"phase1": "zero-copy kernel on the caller's vectors" if zc[0] == 1 else "copy pipeline" if zc[0] == 0 else "mixed",
+                                            "phase2": "zero-copy kernel on the caller's vectors" if zc[1] == 1 else "copy pipeline" if zc[1] == 0 else "mixed"},
+                "ms": t * 1e3, "sessions_timed": reps, "ms_median_session": float(np.median(each)), "ms_each_session": [round(x_, 3) for x_ in each[:12]], "ms_isolated_call": float(np.median(iso)) * 1e3, "party_gates_per_s": n / t,
                 "party_gates_per_s_isolated_call": n / float(np.median(iso)), "h2d_GBps": n * E2E_UP_BYTES / t / 1e9,
                 "d2h_GBps": n * E2E_DOWN_BYTES / t / 1e9, "frac_of_measured_pcie": (n * E2E_UP_BYTES / t / 1e9) / cal["h2d_GBps"]}
 
@@ -687,7 +700,8 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
     regs = [a for p in (0, 1) for a in list(H[p].values())] + de + out + want_de
     for a in regs:
         lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))
-    registered = timed_one("registered once by the caller (arkmpc_host_register), as a caller that keeps its vectors across gates would", False)
+    registered = timed_one("registered once by the caller (arkmpc_host_register), as a caller that keeps its vectors across gates would: both phases run as kernels that read and write "
+                           "the pinned vectors in place, no copy commands (ARKMPC_HOSTMUL_ZEROCOPY=0 puts them back on the copy pipeline: 8.0-8.1 ms at 2^20)", False)
     # two parties on this one GPU, a context and a host thread each, payloads handed over in host memory (network/mock.rs moves host payloads)
     es = [pkg.Engine(FID, device=dev) for _ in (0, 1)]
     bar = threading.Barrier(2)
@@ -715,6 +729,7 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps=6):
             errs.append(repr(ex))
             bar.abort()
 
+    reps = reps_min
     th = [threading.Thread(target=party, args=(p, reps + 1)) for p in (0, 1)]
     for t in th: t.start()
     for t in th: t.join()

@@ -245,7 +245,10 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
  * per party-gate), so these entry points run a three-stream pipeline (upload DMA | kernels | download DMA) that keeps the upload
  * direction busy from the first byte to the last and hides the kernels and the downloads under it.  They take HOST pointers whatever
  * the context's buffer mode, any alignment a Rust Vec has (8 bytes).  Buffers are pinned in place for the duration of the call
- * (hipHostRegister; skipped for buffers that are already pinned); a caller that keeps its vectors across calls pins them once: */
+ * (hipHostRegister; skipped for buffers that are already pinned).  A caller that keeps its vectors across calls pins them once, and
+ * gets the faster form for it: a phase whose vectors are all pinned (and 16-byte aligned) runs with NO copies -- one kernel reads the
+ * records where they lie in host memory and writes the payload / result vector in place (7.3 instead of 8.1 ms per 2^20 gates, 0.97 of
+ * the link).  Same words either way; sessions with several open on one context (both parties of an in-process run) are supported. */
 int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK */
 int arkmpc_host_unregister(void* ptr);
 int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc) */
@@ -257,8 +260,9 @@ int arkmpc_host_free(void* ptr);
  *            of a real link can start transmitting before the batch is complete.
  *   _finish  peer_de: the 2n Scalars received (:871-878); out: n ScalarShares.  Blocks until `out` is complete; ends the session (also
  *            when it returns an error).  _abort ends a session without phase 2.
- * The input vectors must stay valid and unmodified until _finish / _abort returns.  One session at a time per context is the intended
- * use; sessions of different contexts (the two parties of a mock run, rayon workers) are independent. */
+ * The input vectors must stay valid, unmodified and (if the caller pinned them) pinned until _finish / _abort returns; sessions must be
+ * ended before their context is destroyed.  Sessions of different contexts (rayon workers) are independent; two parties sharing one GPU
+ * do best as two sessions of ONE context driven by one thread (their uploads then queue instead of racing on the link). */
 typedef struct arkmpc_hostmul arkmpc_hostmul;
 int arkmpc_hostmul_begin(arkmpc_ctx* ctx, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a, const uint64_t* b,
                          const uint64_t* c, uint64_t* out_de, arkmpc_hostmul** out_session);
