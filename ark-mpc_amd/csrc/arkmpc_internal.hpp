@@ -150,6 +150,16 @@ struct PinRegistry {
         ents[a] = Ent{bytes, 1};
         return a;
     }
+    // the same for a range already known to be pinned (by the caller, or by an entry of this registry): a reference if it is ours, no runtime calls
+    uintptr_t acquire_if_ours(const void* p, size_t bytes) {
+        const uintptr_t a = (uintptr_t)p;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = ents.upper_bound(a);
+        if (it == ents.begin()) return 0;
+        --it;
+        if (a >= it->first && a + bytes <= it->first + it->second.bytes) { it->second.refs++; return it->first; }
+        return 0;
+    }
     void release(uintptr_t base) {
         std::lock_guard<std::mutex> lk(mu);
         auto it = ents.find(base);
@@ -173,6 +183,10 @@ struct HostPins {
         static const bool off = getenv("ARKMPC_NO_PIN") && getenv("ARKMPC_NO_PIN")[0] == '1';
         if (off || !p || bytes < min_bytes()) return;
         const uintptr_t base = pin_registry().acquire(p, bytes);
+        if (base) held.push_back(base);
+    }
+    void keep(const void* p, size_t bytes) {               // p is pinned already: only make sure it stays so if the pin is one of ours
+        const uintptr_t base = pin_registry().acquire_if_ours(p, bytes);
         if (base) held.push_back(base);
     }
     void release() {
