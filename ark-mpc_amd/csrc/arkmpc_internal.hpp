@@ -2,7 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <exception>
+#include <cstdlib>
 #include <mutex>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -78,13 +81,24 @@ static inline int ark_bad(arkmpc_ctx* ctx, const char* what) {
 }
 
 // RAII: serialise calls on the context and make its device current
+// Every entry point that takes a context holds one of these for its whole body (ENTER / ENTER_EC / ENTER_ED).  Besides the lock and the
+// device it is the library's "never unwinds across the ABI" guarantee (the callers are Rust gate closures, fabric.rs:841-854: unwinding
+// into them is undefined behaviour): errors are status codes, and a C++ exception the body did not foresee -- in practice std::bad_alloc
+// from a container -- reaches this destructor while the stack unwinds and ends the process there, as Rust's own allocation failures do.
 struct CtxGuard {
     arkmpc_ctx* c;
     std::unique_lock<std::mutex> lk;
     int rc = ARKMPC_OK;
-    explicit CtxGuard(arkmpc_ctx* ctx) : c(ctx), lk(ctx->mu) {
+    int exc_in_flight;
+    explicit CtxGuard(arkmpc_ctx* ctx) : c(ctx), lk(ctx->mu), exc_in_flight(std::uncaught_exceptions()) {
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess) { ark_set_err(ctx, std::string("hipSetDevice: ") + hipGetErrorString(e)); rc = ARKMPC_ERR_HIP; }
+    }
+    ~CtxGuard() {
+        if (std::uncaught_exceptions() > exc_in_flight) {
+            fputs("arkmpc: C++ exception inside the library (out of host memory?); aborting instead of unwinding into the caller\n", stderr);
+            std::abort();
+        }
     }
 };
 

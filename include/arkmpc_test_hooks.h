@@ -15,6 +15,9 @@ int arkmpc_test_f9(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t*
 /* process-wide count of streaming-session phases that ran as zero-copy kernels on the caller's pinned vectors (csrc/arkmpc_stream.inc):
  * out[0] = phase 1 (arkmpc_hostmul_begin), out[1] = phase 2 (arkmpc_hostmul_finish).  Lets the tests assert WHICH path produced a result. */
 int arkmpc_test_hostmul_zero_copy_phases(uint64_t out[2]);
+/* throws std::bad_alloc from inside an entry point's body: the process must end with the library's message on stderr (abort), never unwind
+ * into the caller (csrc/arkmpc_internal.hpp CtxGuard).  Run it in a child process. */
+int arkmpc_test_throw_inside(arkmpc_ctx* ctx);
 #ifdef __cplusplus
 }
 #endif

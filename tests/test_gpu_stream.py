@@ -537,3 +537,16 @@ def test_hostmul_zero_copy_needs_16_byte_alignment_and_result_may_reuse_an_input
             e.hostmul_finish(s, party, keys[party], peer, H[reuse])
             assert np.array_equal(my_de, ode[party]) and np.array_equal(H[reuse], want[party]), (reuse, pin, party)
     arena.free()
+
+
+def test_exception_inside_an_entry_point_aborts_instead_of_unwinding(pkg):
+    """The boundary's callers are Rust closures: nothing may unwind across the C ABI.  A C++ exception inside an entry point's body (std::bad_alloc
+    is the realistic one) must end the process at the guard every entry point holds, with the library's message -- run in a child process."""
+    import subprocess, sys, os, signal
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, sys; sys.path.insert(0, %r); pkg = importlib.import_module('ark-mpc_amd'); e = pkg.Engine(0, device=0); "
+            "print('before', flush=True); rc = pkg.load_library().arkmpc_test_throw_inside(e.h); print('after', rc, flush=True)" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "before" in r.stdout and "after" not in r.stdout
+    assert r.returncode == -signal.SIGABRT, r.returncode
+    assert "aborting instead of unwinding into the caller" in r.stderr
