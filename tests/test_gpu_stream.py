@@ -550,3 +550,46 @@ def test_exception_inside_an_entry_point_aborts_instead_of_unwinding(pkg):
     assert "before" in r.stdout and "after" not in r.stdout
     assert r.returncode == -signal.SIGABRT, r.returncode
     assert "aborting instead of unwinding into the caller" in r.stderr
+
+
+@pytest.mark.parametrize("how", ["host_alloc", "host_register"])
+def test_hostmul_zero_copy_sees_what_the_cpu_wrote_between_sessions(pkg, engs, oracle, how):
+    """a caller that keeps its pinned vectors across gates REWRITES them between sessions: the kernels read host memory directly, so any
+    line of a previous session still cached on the GPU side would come back stale.  Three sessions on the same eight pinned vectors per party,
+    new contents each time, results read by the CPU in between."""
+    fid, n = 0, 30000
+    e = engs[fid]
+    lib = pkg.load_library()
+    arena = _PinnedArena(pkg)
+    regs = []
+
+    def pinned(nwords):
+        if how == "host_alloc":
+            return arena.zeros(nwords)
+        a = np.zeros(nwords, dtype=np.uint64)
+        assert lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes)) == 0
+        regs.append(a)
+        return a
+    H = [{k: pinned(8 * n) for k in "xyabc"} for _ in (0, 1)]
+    de = [pinned(8 * n) for _ in (0, 1)]
+    out = [pinned(8 * n) for _ in (0, 1)]
+    before = _zc_count(pkg)
+    for seed in (1, 2, 3):
+        _, keys, sh = _inputs(fid, n, seed=8500 + seed, tile_from=1500 + seed)
+        for p in (0, 1):
+            for k in "xyabc":
+                H[p][k][:] = sh[k][p]
+            de[p].fill(seed); out[p].fill(seed)
+        ses = [e.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p]) for p in (0, 1)]
+        for p in (0, 1):
+            e.hostmul_wait_de(ses[p])
+        for p in (0, 1):
+            e.hostmul_finish(ses[p], p, keys[p], de[1 - p], out[p])
+        ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+        for p in (0, 1):
+            assert np.array_equal(de[p], ode[p]) and np.array_equal(out[p], want[p]), "seed %d party %d" % (seed, p)
+    after = _zc_count(pkg)
+    assert (after[0] - before[0], after[1] - before[1]) == (6, 6)
+    for a in regs:
+        assert lib.arkmpc_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0
+    arena.free()
