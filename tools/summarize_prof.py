@@ -196,14 +196,18 @@ for fn in ("bench_e2e_run.json",):
         d = json.loads(open(os.path.join(out, fn)).read().strip().splitlines()[-1])
         for k in ("pageable", "registered"):
             r = d["one_party"][k]
-            print("  one party, %-10s: %.2f ms per 2^20 gates = %.3e party-gates/s, up %.1f GB/s, down %.1f GB/s, %.2f of the measured link (%.1f GB/s)" %
-                  (k, r["ms"], r["party_gates_per_s"], r["h2d_GBps"], r["d2h_GBps"], r["frac_of_measured_pcie"], d["measured_pcie"]["h2d_GBps"]))
+            print("  one party, %-10s: %.2f ms per 2^20 gates = %.3e party-gates/s, up %.1f GB/s, down %.1f GB/s, %.2f of the measured link (%.1f GB/s); phases: %s | %s" %
+                  (k, r["ms"], r["party_gates_per_s"], r["h2d_GBps"], r["d2h_GBps"], r["frac_of_measured_pcie"], d["measured_pcie"]["h2d_GBps"],
+                   r.get("path", {}).get("phase1", "?"), r.get("path", {}).get("phase2", "?")))
         t = d["two_party_one_gpu"]
-        print("  two parties on one GPU / one link: %.2f ms = %.3e two-party gates/s" % (t["ms"], t["two_party_gates_per_s"]))
+        print("  two parties on one GPU / one link, one host thread driving both sessions: %.2f ms = %.3e two-party gates/s (a thread + context per party: %.2f ms)" %
+              (t["ms"], t["two_party_gates_per_s"], t.get("two_host_threads_two_contexts", {}).get("ms", float("nan"))))
         print("  " + d["results_check"])
     except Exception as ex:
         print("  (no e2e run: %r)" % ex)
 try:
-    print("  trace of one session under rocprofv3: " + json.dumps(json.load(open(os.path.join(out, "e2e_trace", "summary.json")))["last_one_party_session"]))
+    tr = json.load(open(os.path.join(out, "e2e_trace", "summary.json")))
+    print("  trace of one copy-pipeline session (pageable vectors) under rocprofv3: " + json.dumps(tr["last_one_party_session"]))
+    print("  zero-copy sessions (pinned vectors) under rocprofv3, medians: " + json.dumps(tr.get("zero_copy_one_party_sessions", {}).get("median")))
 except Exception as ex:
     print("  (no e2e trace summary: %r)" % ex)
