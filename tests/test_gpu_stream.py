@@ -380,8 +380,11 @@ def test_host_buffer_mode_in_place_and_repeated_operands(pkg, oracle, pinned, st
     arena.free()
 
 
-def test_hostmul_soak_random_sizes_two_threads(pkg, oracle):
-    """300 sessions of random sizes (1 ... 40000 gates, so both the single-chunk and the chunked schedules, pinned and unpinned buffer sizes) from
+@pytest.mark.parametrize("pinned", [False, True])
+def test_hostmul_soak_random_sizes_two_threads(pkg, oracle, pinned):
+    """(pinned: the same with every vector in memory the caller pinned -- sessions of 4096 gates and more then run as zero-copy kernels, the
+    smaller ones through the copy pipeline, in one interleaved stream of sessions on the same contexts.)
+    300 sessions of random sizes (1 ... 40000 gates, so both the single-chunk and the chunked schedules, pinned and unpinned buffer sizes) from
     two host threads with a context each, the parties' payloads crossing between the threads; every result against the oracle.  Leaks of
     events, pins or device blocks would show as errors or as a growing pool; ordering bugs as wrong words."""
     import random
@@ -389,9 +392,12 @@ def test_hostmul_soak_random_sizes_two_threads(pkg, oracle):
     rng = random.Random(4242)
     base_n = 40000
     _, keys, sh = _inputs(fid, base_n, seed=777, tile_from=2500)
-    ode_full, want_full = None, None
+    arena = _PinnedArena(pkg)
+    if pinned:
+        sh = {k: (arena.copy(v[0]), arena.copy(v[1])) for k, v in sh.items()}
+    zc_before = _zc_count(pkg)
     es = [pkg.Engine(fid, device=0) for _ in (0, 1)]
-    sizes = [rng.choice([1, 2, 63, 257, 1000, 4097, 16384, 16385, 33000, base_n]) for _ in range(150)]
+    sizes = [rng.choice([1, 2, 63, 255, 256, 257, 1000, 4095, 4096, 4097, 16384, 16385, 33000, base_n]) for _ in range(150)]
     offs = [rng.randrange(0, base_n - n + 1) for n in sizes]
     bar = threading.Barrier(2)
     errs = []
@@ -416,10 +422,42 @@ def test_hostmul_soak_random_sizes_two_threads(pkg, oracle):
             except Exception:        # noqa: BLE001
                 pass
 
+    # pinned: the payload / result vectors are slices of two pinned pools per party (checked session by session below, so each session's
+    # slice is copied out right after the run -- later sessions overwrite the pool)
+    pool = [[arena.zeros(8 * base_n), arena.zeros(8 * base_n)] for _ in (0, 1)] if pinned else None
+    if pinned:                                       # keep every session's words: run the sessions one by one per index, copying the slices out
+        keep_de = [[None] * len(sizes), [None] * len(sizes)]
+        keep_out = [[None] * len(sizes), [None] * len(sizes)]
+
+        def party(p):                                # noqa: F811
+            try:
+                torch.cuda.set_device(0)
+                for k, (n, o) in enumerate(zip(sizes, offs)):
+                    sl = lambda a: a[8 * o: 8 * (o + n)]
+                    d_, o_ = pool[p][0][8 * o: 8 * (o + n)], pool[p][1][8 * o: 8 * (o + n)]
+                    d_.fill(0); o_.fill(0)
+                    de[p][k] = d_
+                    s = es[p].hostmul_begin(n, sl(sh["x"][p]), sl(sh["y"][p]), sl(sh["a"][p]), sl(sh["b"][p]), sl(sh["c"][p]), d_)
+                    es[p].hostmul_wait_de(s)
+                    bar.wait(timeout=60)
+                    es[p].hostmul_finish(s, p, keys[p], de[1 - p][k], o_)
+                    keep_de[p][k] = d_.copy(); keep_out[p][k] = o_.copy()
+                    bar.wait(timeout=60)
+            except Exception as ex:      # noqa: BLE001
+                errs.append(repr(ex))
+                try:
+                    bar.abort()
+                except Exception:        # noqa: BLE001
+                    pass
     th = [threading.Thread(target=party, args=(p,)) for p in (0, 1)]
     for t in th: t.start()
     for t in th: t.join()
     assert not errs, errs[:2]
+    if pinned:
+        de, out = keep_de, keep_out
+        zc_after = _zc_count(pkg)
+        big = sum(1 for n in sizes if n >= 4096)
+        assert (zc_after[0] - zc_before[0], zc_after[1] - zc_before[1]) == (2 * big, 2 * big)
     for k, (n, o) in enumerate(zip(sizes, offs)):
         sub = {nm: (np.ascontiguousarray(sh[nm][0][8 * o: 8 * (o + n)]), np.ascontiguousarray(sh[nm][1][8 * o: 8 * (o + n)])) for nm in "xyabc"}
         ode, want = _oracle_two_party(oracle, fid, n, keys, sub)
@@ -427,6 +465,7 @@ def test_hostmul_soak_random_sizes_two_threads(pkg, oracle):
             assert np.array_equal(de[p][k], ode[p]) and np.array_equal(out[p][k], want[p]), (k, n, o, p)
     for e in es:
         e.close()
+    arena.free()
 
 
 # ---- zero-copy phases: vectors the caller pinned are read and written IN PLACE by k_hostmul_mask / k_hostmul_finish (no copy commands);
