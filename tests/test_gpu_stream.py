@@ -632,3 +632,30 @@ def test_hostmul_zero_copy_sees_what_the_cpu_wrote_between_sessions(pkg, engs, o
     for a in regs:
         assert lib.arkmpc_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0
     arena.free()
+
+
+def test_hostmul_zero_copy_on_slices_of_one_registered_region(pkg, engs, oracle):
+    """all eight vectors are sub-ranges of ONE region the caller registered (arkmpc_host_register on a slab it carves its Vecs from): the device-side
+    address of a vector is then the region's mapping plus an offset, not a mapping of its own"""
+    fid, n = 0, 9000
+    e = engs[fid]
+    lib = pkg.load_library()
+    _, keys, sh = _inputs(fid, n, seed=8600, tile_from=1500)
+    slab = np.zeros(2 * 8 * (8 * n + 8) + 64, dtype=np.uint64)
+    off0 = (-(slab.ctypes.data // 8)) % 2                        # first word on a 16-byte boundary
+    assert lib.arkmpc_host_register(ctypes.c_void_p(slab.ctypes.data), ctypes.c_size_t(slab.nbytes)) == 0
+    cur = [off0 + 2]                                             # (not the region's first byte)
+
+    def carve(a):
+        v = slab[cur[0]: cur[0] + a.size]; cur[0] += a.size + 8  # 64-byte gaps between the vectors
+        v[:] = a
+        assert v.ctypes.data % 16 == 0
+        return v
+    before = _zc_count(pkg)
+    de, out = _two_party_on(e, n, keys, sh, lambda k, a: carve(a))
+    after = _zc_count(pkg)
+    assert (after[0] - before[0], after[1] - before[1]) == (2, 2)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for party in (0, 1):
+        assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party]), "party %d" % party
+    assert lib.arkmpc_host_unregister(ctypes.c_void_p(slab.ctypes.data)) == 0
