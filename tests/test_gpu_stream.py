@@ -659,3 +659,25 @@ def test_hostmul_zero_copy_on_slices_of_one_registered_region(pkg, engs, oracle)
     for party in (0, 1):
         assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party]), "party %d" % party
     assert lib.arkmpc_host_unregister(ctypes.c_void_p(slab.ctypes.data)) == 0
+
+
+def test_hostmul_zero_copy_on_torch_pinned_tensors(pkg, engs, oracle):
+    """pinned memory that somebody else allocated (torch's caching host allocator): the library pins nothing, maps nothing of its own, and still
+    runs both phases in place"""
+    fid, n = 0, 12345
+    _, keys, sh = _inputs(fid, n, seed=8700, tile_from=1500)
+    keepalive = []
+
+    def place(k, a):
+        t = torch.empty(a.size, dtype=torch.int64).pin_memory()
+        keepalive.append(t)
+        v = t.numpy().view(np.uint64)
+        v[:] = a
+        return v
+    before = _zc_count(pkg)
+    de, out = _two_party_on(engs[fid], n, keys, sh, place)
+    after = _zc_count(pkg)
+    assert (after[0] - before[0], after[1] - before[1]) == (2, 2)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for party in (0, 1):
+        assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party]), "party %d" % party
