@@ -245,6 +245,10 @@ struct LinkEvents {
     }
 };
 
+// the wire codec on device buffers, for callers that hold the context lock (csrc/arkmpc_wire.hip)
+int ark_wire_encode_scalars_device(arkmpc_ctx* ctx, uint64_t result_id, size_t n, const uint64_t* d_scalars, uint8_t* d_frame, size_t cap, size_t* out_len);
+int ark_wire_decode_scalars_device(arkmpc_ctx* ctx, const uint8_t* d_frame, size_t frame_len, size_t max_n, uint64_t* d_scalars, size_t* out_n, uint64_t* out_result_id);
+
 // Chunk schedule of the chunked array of a phase: [lo, lo + cnt) ranges covering n.  Full chunks are 2^18 elements (16 MiB of 64-byte
 // records: the DMA engines reach 54 of their 56 GB/s at that size, 49 at 4 MiB); the tail tapers by halves down to 2^16 so that what is left
 // AFTER the last upload byte (one kernel + one download of the last chunk) is short; small batches run in about four chunks, never below 2^14.

@@ -461,11 +461,18 @@ WireHeader make_header(int kind, uint64_t result_id) {
     }
 
 // shared encoder: records are either given (recs32 != nullptr, caller layout mode) or produced from Montgomery scalars
+int encode_locked(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const unsigned char* recs32, const uint64_t* scalars, uint8_t* out_frame,
+                  size_t out_cap, size_t* out_len);
 int encode_impl(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const unsigned char* recs32, const uint64_t* scalars, uint8_t* out_frame,
                 size_t out_cap, size_t* out_len) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
     CtxGuard guard(ctx);
     if (guard.rc) return guard.rc;
+    return encode_locked(ctx, kind, result_id, n, recs32, scalars, out_frame, out_cap, out_len);
+}
+// (caller holds the context lock)
+int encode_locked(arkmpc_ctx* ctx, int kind, uint64_t result_id, size_t n, const unsigned char* recs32, const uint64_t* scalars, uint8_t* out_frame,
+                  size_t out_cap, size_t* out_len) {
     if (!kind_name(kind)) return ark_bad(ctx, "unknown payload kind");
     if (!out_len) return ark_bad(ctx, "null out_len");
     const WireHeader hdr = make_header(kind, result_id);
@@ -524,11 +531,18 @@ int arkmpc_wire_encode_bytes32(arkmpc_ctx* ctx, int kind, uint64_t result_id, si
 static int decode_strict(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
                          size_t* out_n, uint64_t* out_result_id, int* out_kind);
 // Entry: the strict GPU parser; a frame it rejects is re-read on the host (rare) with serde's object semantics and, if it is a message, parsed again.
+static int decode_locked(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
+                         size_t* out_n, uint64_t* out_result_id, int* out_kind);
 static int decode_impl(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
                        size_t* out_n, uint64_t* out_result_id, int* out_kind) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
     CtxGuard guard(ctx);
     if (guard.rc) return guard.rc;
+    return decode_locked(ctx, frame, frame_len, max_n, want_kind, out_records, out_scalars, out_n, out_result_id, out_kind);
+}
+// (caller holds the context lock)
+static int decode_locked(arkmpc_ctx* ctx, const uint8_t* frame, size_t frame_len, size_t max_n, int want_kind, uint8_t* out_records, uint64_t* out_scalars,
+                         size_t* out_n, uint64_t* out_result_id, int* out_kind) {
     if (!frame || !out_n) return ark_bad(ctx, "null frame / out_n");
     if (frame_len < 8 + 30) return ark_bad(ctx, "frame too short");
     // The strict GPU parser runs FIRST: serde_json::to_vec -- what a reference peer sends -- emits the compact form, so the common frame
@@ -670,3 +684,22 @@ int arkmpc_wire_decode_bytes32(arkmpc_ctx* ctx, const uint8_t* frame, size_t fra
 }
 
 }  // extern "C"
+
+// The codec on DEVICE buffers whatever the context's buffer mode, for callers inside the library that hold the context lock (the wire form of the
+// streaming sessions, csrc/arkmpc_stream.inc): scalars / frame are device pointers, *out_len / *out_n come back after a synchronisation.
+__attribute__((visibility("hidden"))) int ark_wire_encode_scalars_device(arkmpc_ctx* ctx, uint64_t result_id, size_t n, const uint64_t* d_scalars, uint8_t* d_frame,
+                                                                         size_t cap, size_t* out_len) {
+    const bool mode = ctx->host_buffers;
+    ctx->host_buffers = false;
+    const int rc = encode_locked(ctx, ARKMPC_WIRE_SCALAR_BATCH, result_id, n, nullptr, n ? d_scalars : nullptr, d_frame, cap, out_len);
+    ctx->host_buffers = mode;
+    return rc;
+}
+__attribute__((visibility("hidden"))) int ark_wire_decode_scalars_device(arkmpc_ctx* ctx, const uint8_t* d_frame, size_t frame_len, size_t max_n, uint64_t* d_scalars,
+                                                                         size_t* out_n, uint64_t* out_result_id) {
+    const bool mode = ctx->host_buffers;
+    ctx->host_buffers = false;
+    const int rc = decode_locked(ctx, d_frame, frame_len, max_n, ARKMPC_WIRE_SCALAR_BATCH, nullptr, d_scalars, out_n, out_result_id, nullptr);
+    ctx->host_buffers = mode;
+    return rc;
+}

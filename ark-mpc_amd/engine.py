@@ -245,6 +245,19 @@ class Engine:
         arr, pk = _key(key)
         self._ck(self.lib.arkmpc_hostmul_finish(s, ctypes.c_int(int(party)), pk, _ptr(peer_de), _ptr(out)))
     def hostmul_abort(self, s): self._ck(self.lib.arkmpc_hostmul_abort(s))
+    def hostmul_begin_wire(self, n, x, y, a, b, c, result_id, out_frame):
+        """Phase 1 with the payload as a wire frame (uint8 host array of capacity >= wire_frame_bound(2 n)); returns (session, frame length)."""
+        s = ctypes.c_void_p()
+        ln = ctypes.c_size_t(0)
+        self._ck(self.lib.arkmpc_hostmul_begin_wire(self.h, ctypes.c_size_t(n), _ptr(x), _ptr(y), _ptr(a), _ptr(b), _ptr(c), ctypes.c_uint64(int(result_id)),
+                                                    _ptr(out_frame), ctypes.c_size_t(out_frame.nbytes), ctypes.byref(ln), ctypes.byref(s)))
+        return s, int(ln.value)
+    def hostmul_finish_wire(self, s, party, key, peer_frame, peer_len, out):
+        """Phase 2 from the peer's wire frame; returns the frame's result_id."""
+        arr, pk = _key(key)
+        rid = ctypes.c_uint64(0)
+        self._ck(self.lib.arkmpc_hostmul_finish_wire(s, ctypes.c_int(int(party)), pk, _ptr(peer_frame), ctypes.c_size_t(int(peer_len)), _ptr(out), ctypes.byref(rid)))
+        return int(rid.value)
 
     # ---- batch open + MAC check
     def mac_check_shares(self, n, key, opened, shares, out): self.call("mac_check_shares", ("size", n), ("key", key), opened, shares, out)

@@ -270,6 +270,18 @@ int arkmpc_hostmul_poll_de(arkmpc_hostmul* session, size_t* out_gates);
 int arkmpc_hostmul_wait_de(arkmpc_hostmul* session);
 int arkmpc_hostmul_finish(arkmpc_hostmul* session, int party_id, const uint64_t mac_key[4], const uint64_t* peer_de, uint64_t* out);
 int arkmpc_hostmul_abort(arkmpc_hostmul* session);
+/* The same session with the payloads in their WIRE form -- the frames QuicTwoPartyNet writes and reads (network/quic.rs:226-251, :303-306;
+ * format below under "Wire format"), ~115 text bytes per scalar, rendered and parsed on the GPU so that the host never runs serde_json over
+ * 2n scalars (where the QUIC path's time goes):
+ *   _begin_wire   phase 1, then NetworkOutbound{result_id, ScalarBatch(d||e)} as a frame into out_frame (capacity >= arkmpc_wire_frame_bound(2 n));
+ *                 *out_len = its length.  Blocks until the frame is complete.
+ *   _finish_wire  peer_frame = the frame received; it must be a ScalarBatch of exactly 2n canonical scalars (anything else: ARKMPC_ERR_BAD_ARG, as
+ *                 serde_json / deserialize_uncompressed would fail); *out_result_id (may be NULL) = its result_id.  Then phase 2 as _finish. */
+int arkmpc_hostmul_begin_wire(arkmpc_ctx* ctx, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a, const uint64_t* b,
+                              const uint64_t* c, uint64_t result_id, uint8_t* out_frame, size_t out_cap, size_t* out_len,
+                              arkmpc_hostmul** out_session);
+int arkmpc_hostmul_finish_wire(arkmpc_hostmul* session, int party_id, const uint64_t mac_key[4], const uint8_t* peer_frame, size_t peer_len,
+                               uint64_t* out, uint64_t* out_result_id);
 
 /* ---- batch open + MAC check, authenticated_scalar.rs:278-354 ------------------------------- */
 /* the `.share()` projection sent by open_batch (:141-145): n ScalarShares -> n Scalars */

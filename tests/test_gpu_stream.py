@@ -681,3 +681,77 @@ def test_hostmul_zero_copy_on_torch_pinned_tensors(pkg, engs, oracle):
     ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
     for party in (0, 1):
         assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party]), "party %d" % party
+
+
+# ---- sessions with the payloads in their wire form (arkmpc_hostmul_begin_wire / _finish_wire): the frame each party would put on a QUIC stream
+# ---- (network/quic.rs:303-306) checked byte for byte against the serde_json model (pyref.wire_frame), the results against the oracle
+def _wire_two_party(eng, fid, n, keys, sh, place, rids=(100, 2 ** 63 + 5)):
+    H = [{k: place(sh[k][p]) for k in "xyabc"} for p in (0, 1)]
+    cap = eng.wire_frame_bound(2 * n)
+    frames = [place(np.zeros(cap, dtype=np.uint8)) for _ in (0, 1)]
+    out = [place(np.zeros(8 * n, dtype=np.uint64)) for _ in (0, 1)]
+    ses, lens = [], []
+    for p in (0, 1):
+        s, ln = eng.hostmul_begin_wire(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], rids[p], frames[p])
+        ses.append(s); lens.append(ln)
+    got_rids = [eng.hostmul_finish_wire(ses[p], p, keys[p], frames[1 - p], lens[1 - p], out[p]) for p in (0, 1)]
+    return [frames[p][:lens[p]].tobytes() for p in (0, 1)], out, got_rids
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("fid,n", [(0, 1), (0, 777), (0, 16389), (1, 5000), (2, 4097)])
+def test_hostmul_wire_sessions_vs_model_and_oracle(pkg, engs, oracle, fid, n, pinned):
+    e = engs[fid]
+    arena = _PinnedArena(pkg)
+    _, keys, sh = _inputs(fid, n, seed=9000 + n, tile_from=2000)
+    rids = (100, 2 ** 63 + 5)
+    before = _zc_count(pkg)
+    frames, out, got_rids = _wire_two_party(e, fid, n, keys, sh, (lambda a: arena.copy(a)) if pinned else (lambda a: np.array(a)), rids)
+    after = _zc_count(pkg)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    for p in (0, 1):
+        model = pyref.wire_frame("ScalarBatch", rids[p], pyref.wire_scalar_records(fid, from_mont_array(fid, ode[p])))
+        assert frames[p] == model, "frame of party %d" % p
+        assert np.array_equal(out[p], want[p]), "result of party %d" % p
+        assert got_rids[p] == rids[1 - p]
+    if pinned and n >= 4096:
+        assert (after[0] - before[0], after[1] - before[1]) == (2, 2)           # the phases themselves still run in place on the pinned vectors
+    arena.free()
+
+
+def test_hostmul_wire_session_rejects_bad_peer_frames(pkg, engs, oracle):
+    """a peer frame with one scalar too few, with a scalar >= the modulus, with a syntax error, of the wrong variant: ARKMPC_ERR_BAD_ARG, the session
+    ends, and the context runs the next session normally"""
+    fid, n = 0, 300
+    e = engs[fid]
+    p_mod = pyref.P[fid]
+    _, keys, sh = _inputs(fid, n, seed=9100)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    good_vals = from_mont_array(fid, ode[1])
+    recs = pyref.wire_scalar_records(fid, good_vals)
+    bad = {
+        "one scalar too few": pyref.wire_frame("ScalarBatch", 1, recs[:-1]),
+        "one scalar too many": pyref.wire_frame("ScalarBatch", 1, recs + recs[:1]),
+        "scalar >= modulus": pyref.wire_frame("ScalarBatch", 1, recs[:5] + [int(p_mod).to_bytes(32, "little")] + recs[6:]),
+        "syntax": pyref.wire_frame("ScalarBatch", 1, recs).replace(b"],[", b"],,[", 1),
+        "variant": pyref.wire_frame("PointBatch", 1, recs),
+    }
+    bad["syntax"] = bad["syntax"][8:]
+    import struct
+    bad["syntax"] = struct.pack("<Q", len(bad["syntax"])) + bad["syntax"]
+    cap = e.wire_frame_bound(2 * n)
+    for why, fr in bad.items():
+        frame = np.zeros(cap, dtype=np.uint8); out = np.zeros(8 * n, dtype=np.uint64)
+        s, ln = e.hostmul_begin_wire(n, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], 7, frame)
+        peer = np.frombuffer(fr, dtype=np.uint8).copy()
+        with pytest.raises(pkg.ArkMpcError):
+            e.hostmul_finish_wire(s, 0, keys[0], peer, len(peer), out)
+        assert not out.any(), why
+    # too small a frame buffer is refused before anything is enqueued
+    with pytest.raises(pkg.ArkMpcError):
+        e.hostmul_begin_wire(n, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], 7, np.zeros(cap - 1, dtype=np.uint8))
+    frame = np.zeros(cap, dtype=np.uint8); out = np.zeros(8 * n, dtype=np.uint64)
+    s, ln = e.hostmul_begin_wire(n, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], 7, frame)
+    peer = np.frombuffer(pyref.wire_frame("ScalarBatch", 9, recs), dtype=np.uint8).copy()
+    assert e.hostmul_finish_wire(s, 0, keys[0], peer, len(peer), out) == 9
+    assert np.array_equal(out, want[0])
