@@ -806,6 +806,66 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
            "what": "both parties on this ONE GPU and its one PCIe link, ONE host thread and context driving both parties' sessions (begin, begin, wait, wait, finish, finish), "
                    "d||e handed over in host memory; 768 B up per two-party gate, so the link's floor is %.1f ms" % (2 * n * E2E_UP_BYTES / cal["h2d_GBps"] / 1e6),
            "two_host_threads_two_contexts": two_threads}
+    # the same sessions with the payloads in their WIRE form (the frames QuicTwoPartyNet puts on the stream: serde_json text, ~115 bytes per scalar):
+    # host records in -> frame out; peer's frame in -> host records out.  The text is rendered and parsed on the GPU; it crosses the link instead of
+    # the raw scalars (about 3.6x their bytes each way).
+    wire = None
+    try:
+        cap = eng.wire_frame_bound(2 * n)
+        fbuf = []
+        for _ in range(3):
+            q = ctypes.c_void_p()
+            if lib.arkmpc_host_alloc(ctypes.c_size_t(cap), ctypes.byref(q)) != 0:
+                raise RuntimeError("arkmpc_host_alloc(frame)")
+            fbuf.append((q, np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ctypes.c_uint8)), shape=(cap,))))
+        peer_frames, peer_lens = [], []
+        for p in (0, 1):                                   # each party's own frame once, kept as the other party's inbound message
+            s_, ln = eng.hostmul_begin_wire(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], 1000 + p, fbuf[2][1])
+            eng.hostmul_abort(s_)
+            peer_frames.append(fbuf[2][1][:ln].copy()); peer_lens.append(ln)
+        for a in peer_frames:
+            lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))
+    except Exception as ex:      # noqa: BLE001
+        wire = {"error": repr(ex)[:200]}
+    if wire is None:
+        try:
+            def wire_session(k):
+                p = k & 1
+                out[p].fill(0)
+                s_, ln = eng.hostmul_begin_wire(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], 1000 + p, fbuf[p][1])
+                rid = eng.hostmul_finish_wire(s_, p, keys[p], peer_frames[1 - p], peer_lens[1 - p], out[p])
+                return p, ln, rid
+            wire_session(0)
+            tw = []
+            okw = True
+            for k in range(reps):
+                t0 = time.perf_counter(); p, ln, rid = wire_session(k); tw.append(time.perf_counter() - t0)
+                okw = okw and ln == peer_lens[p] and rid == 1000 + (1 - p) and bool(np.array_equal(fbuf[p][1][:ln], peer_frames[p])) and bool(np.array_equal(out[p], want_out[p]))
+            # the frame text itself against the serde_json model, on its head (header + the first 512 scalars of d) and its tail
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import pyref
+            from helpers import from_mont_array
+            for p in (0, 1):
+                head_vals = from_mont_array(FID, want_de[p][:4 * 512])
+                tail_vals = from_mont_array(FID, want_de[p][-4 * 512:])
+                model_h = pyref.wire_frame("ScalarBatch", 1000 + p, pyref.wire_scalar_records(FID, head_vals))[8:-3]
+                model_t = pyref.wire_frame("ScalarBatch", 0, pyref.wire_scalar_records(FID, tail_vals))[8:]
+                fr = peer_frames[p].tobytes()
+                t_text = model_t[model_t.index(b"[[") + 1:]
+                okw = okw and fr[8:8 + len(model_h)] == model_h and fr.endswith(t_text) and int.from_bytes(fr[:8], "little") == len(fr) - 8
+            tm = float(np.median(tw))
+            wire = {"ms": tm * 1e3, "party_gates_per_s": n / tm, "frame_bytes": int(peer_lens[0]), "text_bytes_per_scalar": peer_lens[0] / (2.0 * n),
+                    "link_bytes_per_party_gate": {"up": 320 + peer_lens[0] / n, "down": 64 + peer_lens[0] / n},
+                    "what": "arkmpc_hostmul_begin_wire + _finish_wire, one party, pinned vectors and frame buffers, sessions back to back: records in, this party's "
+                            "NetworkOutbound{ScalarBatch(d||e)} frame out; the peer's frame in, result records out.  The frames are rendered / validated and parsed on the GPU "
+                            "(csrc/arkmpc_wire.hip); not overlapped with the phases (a frame's length is data dependent)",
+                    "check": "frames == the serde_json model on head and tail and identical from session to session, result_id round-trips, results == the plain sessions': %s" % ("ok" if okw else "FAILED")}
+            ok = ok and okw
+        except Exception as ex:      # noqa: BLE001
+            wire = {"error": repr(ex)[:300]}
+            ok = False
+        for a in peer_frames:
+            lib.arkmpc_host_unregister(ctypes.c_void_p(a.ctypes.data))
     for a in regs:
         lib.arkmpc_host_unregister(ctypes.c_void_p(a.ctypes.data))
     # the oracle on a sample of the same host data (the device-resident buffers used as the expectation above are not an independent witness)
@@ -846,7 +906,7 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
             "party_gates_per_s": best["party_gates_per_s"], "two_party_gates_per_s": two.get("two_party_gates_per_s") if two else None,
             "h2d_GBps": best["h2d_GBps"], "d2h_GBps": best["d2h_GBps"], "frac_of_measured_pcie": best["frac_of_measured_pcie"],
             "one_party": {"pageable": pageable, "registered": registered}, "two_party_one_gpu": two, "measured_pcie": cal,
-            "reference_bench_shape": ref_shape,
+            "wire_form": wire, "reference_bench_shape": ref_shape,
             "link_floor_note": "one PCIe gen5 x16 link: a party-gate needs 384 B up, so the link's measured %.1f GB/s allows at most %.3g party-gates/s "
                                "(and half of that per two-party gate when both parties share the link)" % (cal["h2d_GBps"], cal["h2d_GBps"] * 1e9 / E2E_UP_BYTES),
             "results_check": "all 2^%d gates of both parties == the device-resident pipeline's records, and %s == oracle, every word of d||e and result (%d of %d party-gates exact): %s"
