@@ -831,7 +831,6 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
         try:
             def wire_session(k):
                 p = k & 1
-                out[p].fill(0)
                 s_, ln = eng.hostmul_begin_wire(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], 1000 + p, fbuf[p][1])
                 rid = eng.hostmul_finish_wire(s_, p, keys[p], peer_frames[1 - p], peer_lens[1 - p], out[p])
                 return p, ln, rid
@@ -839,6 +838,7 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
             tw = []
             okw = True
             for k in range(reps):
+                out[k & 1].fill(0); fbuf[k & 1][1][:4096].fill(0)
                 t0 = time.perf_counter(); p, ln, rid = wire_session(k); tw.append(time.perf_counter() - t0)
                 okw = okw and ln == peer_lens[p] and rid == 1000 + (1 - p) and bool(np.array_equal(fbuf[p][1][:ln], peer_frames[p])) and bool(np.array_equal(out[p], want_out[p]))
             # the frame text itself against the serde_json model, on its head (header + the first 512 scalars of d) and its tail
