@@ -36,3 +36,23 @@ for k in range(6):
     t2 = time.perf_counter()
     rows.append([round((t1 - t0) * 1e3, 3), round((t2 - t1) * 1e3, 3)])
 print(json.dumps({"log2n": L, "frame_bytes": ln, "begin_wire_ms, finish_wire_ms": rows}))
+# two workers (a context and a thread each, own buffers): does one's frame download hide under the other's uploads?
+import threading
+def mk():
+    v = [shares() for _ in range(5)]
+    return v, pinned(64 * n, np.uint64), pinned(cap, np.uint8), pkg.Engine(0, device=0)
+workers = [mk() for _ in range(2)]
+reps = 8
+def work(w):
+    v, o, fr, e = workers[w]
+    for _ in range(reps):
+        s_, _l = e.hostmul_begin_wire(n, v[0], v[1], v[2], v[3], v[4], 1, fr)
+        e.hostmul_finish_wire(s_, 0, key, peer, ln, o)
+for w in (0, 1):
+    work(w)
+t0 = time.perf_counter()
+th = [threading.Thread(target=work, args=(w,)) for w in (0, 1)]
+for t in th: t.start()
+for t in th: t.join()
+t = time.perf_counter() - t0
+print(json.dumps({"two_workers": {"sessions": 2 * reps, "ms_per_session_aggregate": t / (2 * reps) * 1e3, "party_gates_per_s": 2 * reps * n / t}}))
