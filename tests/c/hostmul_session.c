@@ -43,6 +43,29 @@ static int run(arkmpc_ctx* ctx, arkmpc_ctx* hctx, size_t n, int pinned) {
         CHECK(arkmpc_hostmul_finish(s[p], p, key[p], buf[1 - p][5], buf[p][6]) == ARKMPC_OK);
         CHECK(memcmp(buf[p][6], buf[p][8], n * 64) == 0);
     }
+    /* the same gate with the payloads in their wire form: each party's frame must be the codec's own frame of its d||e (arkmpc_wire_encode_scalar_batch
+     * on the host-buffer context), and the results the same words again */
+    {
+        size_t cap = 0, len[2] = {0, 0}, want_len = 0;
+        CHECK(arkmpc_wire_frame_bound(2 * n, &cap) == ARKMPC_OK);
+        uint8_t* fr[3];
+        for (int k = 0; k < 3; ++k) { fr[k] = (uint8_t*)malloc(cap); CHECK(fr[k] != NULL); }
+        for (int p = 0; p < 2; ++p) {
+            memset(buf[p][6], 0x5A, n * 64);
+            CHECK(arkmpc_hostmul_begin_wire(ctx, n, buf[p][0], buf[p][1], buf[p][2], buf[p][3], buf[p][4], 40 + (uint64_t)p, fr[p], cap, &len[p], &s[p]) == ARKMPC_OK && s[p]);
+            CHECK(arkmpc_wire_encode_scalar_batch(hctx, 40 + (uint64_t)p, 2 * n, buf[p][7], fr[2], cap, &want_len) == ARKMPC_OK);
+            CHECK(want_len == len[p] && memcmp(fr[p], fr[2], want_len) == 0);
+        }
+        for (int p = 0; p < 2; ++p) {
+            uint64_t rid = 0;
+            CHECK(arkmpc_hostmul_finish_wire(s[p], p, key[p], fr[1 - p], len[1 - p], buf[p][6], &rid) == ARKMPC_OK && rid == 40 + (uint64_t)(1 - p));
+            CHECK(memcmp(buf[p][6], buf[p][8], n * 64) == 0);
+        }
+        /* a truncated peer frame is a status and ends the session */
+        CHECK(arkmpc_hostmul_begin_wire(ctx, n, buf[0][0], buf[0][1], buf[0][2], buf[0][3], buf[0][4], 1, fr[2], cap, &want_len, &s[0]) == ARKMPC_OK);
+        CHECK(arkmpc_hostmul_finish_wire(s[0], 0, key[0], fr[1], len[1] - 1, buf[0][6], NULL) == ARKMPC_ERR_BAD_ARG);
+        for (int k = 0; k < 3; ++k) free(fr[k]);
+    }
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < 9; ++k) { void* q = buf[p][k] - 1; if (pinned && k < 7) CHECK(arkmpc_host_free(q) == ARKMPC_OK); else free(q); }
     return 0;
