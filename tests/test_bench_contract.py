@@ -56,7 +56,11 @@ def test_single_process_default_shape():
     for k in ("party_gates_per_s", "two_party_gates_per_s", "h2d_GBps", "d2h_GBps", "frac_of_measured_pcie"):
         assert k in e2e and e2e[k] is not None and e2e[k] > 0, k
     assert e2e["results_check"].endswith("ok")
+    assert e2e["one_party"]["registered"]["path"] == {"phase1": "zero-copy kernel on the caller's vectors", "phase2": "zero-copy kernel on the caller's vectors"}
+    assert e2e["one_party"]["pageable"]["path"] == {"phase1": "copy pipeline", "phase2": "copy pipeline"}
+    assert e2e["wire_form"]["ms"] > 0 and e2e["wire_form"]["check"].endswith("ok")
     c4 = d["config4"]
+    assert c4["host_vectors"]["check"].endswith("ok") and c4["host_vectors"]["pageable_ms"] > c4["ms"]
     assert 0 < c4["frac_of_nominal_valu_rate"] < c4["frac_of_int_alu_peak"] < 1
 
 
