@@ -755,3 +755,27 @@ def test_hostmul_wire_session_rejects_bad_peer_frames(pkg, engs, oracle):
     peer = np.frombuffer(pyref.wire_frame("ScalarBatch", 9, recs), dtype=np.uint8).copy()
     assert e.hostmul_finish_wire(s, 0, keys[0], peer, len(peer), out) == 9
     assert np.array_equal(out, want[0])
+
+
+def test_hostmul_wire_session_reads_what_serde_would(pkg, engs, oracle):
+    """the peer's frame need not be in serde_json::to_vec's compact form: anything serde_json::from_slice reads as the same NetworkOutbound -- whitespace
+    between tokens, the two fields in the other order, an unknown field -- finishes the session with the same words"""
+    import json, struct
+    fid, n = 0, 200
+    e = engs[fid]
+    _, keys, sh = _inputs(fid, n, seed=9300)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    recs = [list(r) for r in pyref.wire_scalar_records(fid, from_mont_array(fid, ode[1]))]
+    shapes = {
+        "whitespace": json.dumps({"result_id": 3, "payload": {"ScalarBatch": recs}}, indent=1),
+        "fields swapped": json.dumps({"payload": {"ScalarBatch": recs}, "result_id": 3}, separators=(",", ":")),
+        "unknown field": json.dumps({"result_id": 3, "note": {"a": [1, 2, {"b": None}]}, "payload": {"ScalarBatch": recs}}, separators=(",", ":")),
+    }
+    cap = e.wire_frame_bound(2 * n)
+    for why, body in shapes.items():
+        frame = np.zeros(cap, dtype=np.uint8); out = np.zeros(8 * n, dtype=np.uint64)
+        s, ln = e.hostmul_begin_wire(n, sh["x"][0], sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], 7, frame)
+        b = body.encode()
+        peer = np.frombuffer(struct.pack("<Q", len(b)) + b, dtype=np.uint8).copy()
+        assert e.hostmul_finish_wire(s, 0, keys[0], peer, len(peer), out) == 3, why
+        assert np.array_equal(out, want[0]), why
