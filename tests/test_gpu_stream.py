@@ -779,3 +779,29 @@ def test_hostmul_wire_session_reads_what_serde_would(pkg, engs, oracle):
         peer = np.frombuffer(struct.pack("<Q", len(b)) + b, dtype=np.uint8).copy()
         assert e.hostmul_finish_wire(s, 0, keys[0], peer, len(peer), out) == 3, why
         assert np.array_equal(out, want[0]), why
+
+
+def test_host_register_of_a_vector_a_session_has_pinned(pkg, engs, oracle):
+    """the caller registers a vector WHILE a session of the library has it pinned in place: the registration becomes a reference on that pin, survives
+    the session's end, and arkmpc_host_unregister gives it back (ROCm itself would take the second registration and drop both at the first unregister)"""
+    fid, n = 0, 40000
+    e = engs[fid]
+    lib = pkg.load_library()
+    _, keys, sh = _inputs(fid, n, seed=9400, tile_from=2000)
+    ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
+    x = np.array(sh["x"][0])
+    reg = lambda a: lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))
+    unreg = lambda a: lib.arkmpc_host_unregister(ctypes.c_void_p(a.ctypes.data))
+    for rnd in range(2):
+        de = np.zeros(8 * n, dtype=np.uint64); out = np.zeros(8 * n, dtype=np.uint64)
+        s = e.hostmul_begin(n, x, sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], de)
+        if rnd == 0:
+            assert reg(x) == 0 and reg(x) == 0                     # while the session holds the pin; twice = still one reference
+        e.hostmul_finish(s, 0, keys[0], ode[1], out)
+        assert np.array_equal(de, ode[0]) and np.array_equal(out, want[0])
+    assert unreg(x) == 0
+    assert unreg(x) != 0                                           # no longer registered: a status, not a crash
+    de = np.zeros(8 * n, dtype=np.uint64); out = np.zeros(8 * n, dtype=np.uint64)
+    s = e.hostmul_begin(n, x, sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], de)
+    e.hostmul_finish(s, 0, keys[0], ode[1], out)
+    assert np.array_equal(out, want[0])
