@@ -245,6 +245,9 @@ class Engine:
         arr, pk = _key(key)
         self._ck(self.lib.arkmpc_hostmul_finish(s, ctypes.c_int(int(party)), pk, _ptr(peer_de), _ptr(out)))
     def hostmul_abort(self, s): self._ck(self.lib.arkmpc_hostmul_abort(s))
+    @staticmethod
+    def host_trim():
+        return load_library().arkmpc_host_trim()
     def hostmul_begin_wire(self, n, x, y, a, b, c, result_id, out_frame):
         """Phase 1 with the payload as a wire frame (uint8 host array of capacity >= wire_frame_bound(2 n)); returns (session, frame length)."""
         s = ctypes.c_void_p()

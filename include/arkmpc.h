@@ -251,8 +251,9 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
  * the link).  Same words either way; sessions with several open on one context (both parties of an in-process run) are supported. */
 int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK */
 int arkmpc_host_unregister(void* ptr);
-int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc) */
-int arkmpc_host_free(void* ptr);
+int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc), RECYCLED: a freed block comes back from a free list by size */
+int arkmpc_host_free(void* ptr);                        /* class in microseconds (the runtime's own alloc + free of 64 MiB cost 16 ms); contents are not cleared */
+int arkmpc_host_trim(void);                             /* returns the free list (at most ARKMPC_HOST_POOL_MB, default 4096 MiB) to the runtime */
 /* AuthenticatedScalarResult::batch_mul (authenticated_scalar.rs:848-879) as a two-phase session around the d||e exchange:
  *   _begin   x, y, a, b, c: n ScalarShares each (arkworks records); out_de: 2n Scalars, d then e -- the ScalarBatch this party sends
  *            (:863-868, :141-145).  Enqueues the uploads, K1 chunk by chunk and the payload downloads, and returns.

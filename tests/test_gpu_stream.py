@@ -805,3 +805,32 @@ def test_host_register_of_a_vector_a_session_has_pinned(pkg, engs, oracle):
     s = e.hostmul_begin(n, x, sh["y"][0], sh["a"][0], sh["b"][0], sh["c"][0], de)
     e.hostmul_finish(s, 0, keys[0], ode[1], out)
     assert np.array_equal(out, want[0])
+
+
+def test_host_alloc_recycles_blocks(pkg):
+    """arkmpc_host_alloc / _free keep freed pinned blocks on a free list by size class (the runtime's own alloc + free of 64 MiB cost 16 ms): the same
+    block comes back for the same class, another class gets another block, double frees and foreign pointers are a status, trim empties the list"""
+    lib = pkg.load_library()
+    assert lib.arkmpc_host_trim() == 0
+    def alloc(nbytes):
+        q = ctypes.c_void_p()
+        assert lib.arkmpc_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(q)) == 0 and q.value
+        return q
+    a = alloc(3 << 20)
+    ctypes.memset(a, 0x5A, 3 << 20)
+    assert lib.arkmpc_host_free(a) == 0
+    b = alloc((3 << 20) - 4097)                                   # same 1 MiB class
+    assert b.value == a.value
+    c = alloc(3 << 20)                                            # the list is empty again: a new block
+    assert c.value != b.value
+    d = alloc(5 << 20)
+    assert d.value not in (b.value, c.value)
+    assert lib.arkmpc_host_free(b) == 0 and lib.arkmpc_host_free(b) != 0          # double free
+    assert lib.arkmpc_host_free(ctypes.c_void_p(b.value + 64)) != 0              # not a block
+    buf = np.zeros(16, dtype=np.uint64)
+    assert lib.arkmpc_host_free(ctypes.c_void_p(buf.ctypes.data)) != 0
+    assert lib.arkmpc_host_free(c) == 0 and lib.arkmpc_host_free(d) == 0
+    assert lib.arkmpc_host_trim() == 0
+    assert lib.arkmpc_host_free(c) != 0                                           # gone with the trim
+    small = alloc(1000)
+    assert lib.arkmpc_host_free(small) == 0 and alloc(65536).value == small.value     # 64 KiB classes below 1 MiB
