@@ -628,7 +628,7 @@ def pcie_calibration(mib=256):
     for name, fn, vol in (("h2d", lambda: dev.copy_(h, non_blocking=True), m), ("d2h", lambda: h2.copy_(dev2, non_blocking=True), m), ("both", both, 2 * m)):
         fn(); torch.cuda.synchronize()
         best = 0.0
-        for _ in range(3):                               # best of three batches of four copies
+        for _ in range(6):                               # best of six batches of four copies (the denominator of frac_of_measured_pcie: a low reading would flatter the path)
             t0 = time.perf_counter()
             for _ in range(4):
                 fn()
