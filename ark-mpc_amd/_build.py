@@ -64,6 +64,10 @@ def build_engine(force=False, verbose=False):
     so = os.path.join(LIB, "libarkmpc_hip.so")
     if force or jobs or _newer(so, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs)
+    # test-only entry points (include/arkmpc_test_hooks.h) that must not ship in the product library: their own small shared object
+    hooks_src, hooks_so = os.path.join(CSRC, "arkmpc_testhooks.hip"), os.path.join(LIB, "libarkmpc_testhooks.so")
+    if force or _newer(hooks_so, [hooks_src] + deps):
+        _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", hooks_so, hooks_src])
     return so
 
 

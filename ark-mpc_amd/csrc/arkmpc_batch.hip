@@ -11,6 +11,7 @@
 #include "arkmpc_internal.hpp"
 #include <atomic>
 #include <cstdlib>
+#include <initializer_list>
 
 struct arkmpc_batch {
     std::atomic<int> refs{1};
@@ -22,7 +23,33 @@ struct arkmpc_batch {
     u64* share = nullptr;                // element i: share + stride * i   (the whole record for AoS kinds)
     u64* mac = nullptr;                  // ScalarShare batches only: MAC half of element i at mac + stride * i
     u32 stride = 0;                      // u64 units
+    // asynchronous import (arkmpc_batch_from_host_async): the upload's completion, the pin on the caller's vector, a staging block
+    hipEvent_t ready = nullptr;
+    HostPins* pins = nullptr;
+    void* staging = nullptr;
 };
+
+// ---- imports at link speed ------------------------------------------------------------------------------------------------------------
+// n arkworks ScalarShare records where they lie (pinned host memory addressed over the link, or HBM) -> share column + MAC column, ONE
+// pass: lane t moves quarter t of the records (a wave reads 1 KiB of contiguous source per access, fully coalesced 16-byte loads) and drops
+// it at its place in the column.  Replaces upload-to-staging + split pass (64 B up, 64 B written, 128 B re-read / re-written per record).
+// Few workgroups, as for the session kernels: the link, not the chip, is what the kernel waits for.
+__global__ void __launch_bounds__(256) k_import_split(size_t n, const uint4* __restrict__ rec, uint4* __restrict__ share_col, uint4* __restrict__ mac_col) {
+    const size_t total = 4 * n, step = (size_t)gridDim.x * 256;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += step) {
+        const uint4 v = rec[q];
+        const size_t i = q >> 2;
+        const unsigned k = (unsigned)(q & 3);
+        (k < 2 ? share_col : mac_col)[2 * i + (k & 1)] = v;
+    }
+}
+int ark_import_split(hipStream_t st, size_t n, const void* rec_dev, u64* share_col, u64* mac_col) {
+    if (!n) return ARKMPC_OK;
+    static const unsigned env = getenv("ARKMPC_IMPORT_BLOCKS") ? (unsigned)atoi(getenv("ARKMPC_IMPORT_BLOCKS")) : 0u;
+    const size_t tiles = (4 * n + 255) / 256, want = env ? env : 128;
+    hipLaunchKernelGGL(k_import_split, dim3((unsigned)(tiles < want ? tiles : want)), dim3(256), 0, st, n, (const uint4*)rec_dev, (uint4*)share_col, (uint4*)mac_col);
+    return hipGetLastError() == hipSuccess ? ARKMPC_OK : ARKMPC_ERR_HIP;
+}
 
 static u32 elem_words(int kind, int field_id) {
     const bool ed = field_id == ARKMPC_CURVE25519_FR;
@@ -87,6 +114,7 @@ int arkmpc_batch_destroy(arkmpc_ctx* ctx, arkmpc_batch* b) {
     int rc = ARKMPC_OK;
     while (b && b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         arkmpc_batch* parent = b->parent;
+        if (b->ready || b->pins || b->staging) { int r = arkmpc_batch_host_release(ctx, b); if (r) rc = r; }      // an import nobody released: wait for it, drop the pin
         if (b->base) { int r = arkmpc_free(ctx, b->base); if (r) rc = r; }
         delete b;
         b = parent;
@@ -162,11 +190,107 @@ int arkmpc_batch_from_host(arkmpc_ctx* ctx, int kind, int layout, size_t n, cons
     return rc;
 }
 
+// The same without blocking: the records go up on the context's `up` stream -- read IN PLACE over the link by k_import_split when the batch
+// is split columns, plain DMA otherwise -- behind whatever the compute stream is doing (the previous gate's kernels, the network round).
+// The caller's vector is pinned in place if it is not pinned already.  Small or unpinnable vectors take the blocking path above.
+int arkmpc_batch_from_host_async(arkmpc_ctx* ctx, int kind, int layout, size_t n, const void* host_records, arkmpc_batch** out) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (n && !host_records) return ark_bad(ctx, "null host records");
+    int rc = arkmpc_batch_create(ctx, kind, layout, n, out);
+    if (rc) return rc;
+    arkmpc_batch* b = *out;
+    if (!n) return ARKMPC_OK;
+    const size_t bytes = n * (size_t)b->words * 8;
+    const bool split = layout == ARKMPC_LAYOUT_SPLIT;
+    HostPins* pins = new HostPins();
+    Place src = classify_and_hold(ctx, *pins, host_records, bytes);
+    if (src.kind == Mem::Pageable) { pins->pin(host_records, bytes); src = classify(ctx, host_records, bytes); }
+    if (src.kind == Mem::Foreign || (src.kind == Mem::Device && ((uintptr_t)host_records & 15))) {
+        delete pins; arkmpc_batch_destroy(ctx, b); *out = nullptr;
+        return ark_bad(ctx, "records in device memory must be 16-byte aligned and on the context's GPU");
+    }
+    void* staging = nullptr;
+    if (src.kind != Mem::Pageable && split && !src.zc()) rc = arkmpc_malloc(ctx, bytes, &staging);      // pinned but only 8-byte aligned: DMA, then the columns from HBM
+    if (src.kind == Mem::Pageable || rc) {               // not pinnable (below ARKMPC_PIN_MIN_KB, a read-only mapping ...): the blocking import
+        delete pins;
+        arkmpc_batch_destroy(ctx, b); *out = nullptr;
+        if (rc) return rc;
+        rc = arkmpc_batch_from_host(ctx, kind, layout, n, host_records, out);
+        if (!rc) { CtxGuard g(ctx); ctx->stats.batch_blocking_imports++; }
+        return rc;
+    }
+    {
+        CtxGuard guard(ctx);
+        rc = guard.rc;
+        if (!rc) rc = link_ensure(ctx);
+        LinkEvents evs(ctx);
+        if (!rc) rc = evs.edge(ctx->stream, ctx->up);        // the batch's block (and the staging block) were last used on the compute stream
+        if (!rc) {
+            hipError_t e = hipSuccess;
+            if (split && src.zc()) rc = ark_import_split(ctx->up, n, src.dev, b->share, b->mac);
+            else if (split) {
+                e = hipMemcpyAsync(staging, host_records, bytes, hipMemcpyDefault, ctx->up);
+                if (e == hipSuccess) rc = ark_import_split(ctx->up, n, staging, b->share, b->mac);
+            } else e = hipMemcpyAsync(b->base, host_records, bytes, hipMemcpyDefault, ctx->up);
+            if (e != hipSuccess) { ark_set_err(ctx, std::string("asynchronous import: ") + hipGetErrorString(e)); rc = ARKMPC_ERR_HIP; }
+            else if (rc) ark_set_err(ctx, "import kernel launch failed");
+        }
+        hipEvent_t ready = nullptr;
+        if (!rc) rc = evs.mark(ctx->up, &ready);
+        if (!rc) {
+            evs.used.pop_back();                             // `ready` stays with the batch; the edge's event goes back to the free list now (its wait is enqueued)
+            b->ready = ready; b->pins = pins; b->staging = staging;
+            ctx->stats.batch_async_imports++;
+        }
+        evs.give_back();
+    }
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->up);
+        delete pins;
+        if (staging) (void)arkmpc_free(ctx, staging);
+        arkmpc_batch_destroy(ctx, b); *out = nullptr;
+    }
+    return rc;
+}
+static arkmpc_batch* owner_of(arkmpc_batch* b) { return b->parent ? b->parent : b; }
+// the context's compute stream waits -- on the device -- for the batch's import; returns at once.  Call it before the first use of the batch
+// on this context (the batch-level entry points below do it themselves).  A batch that was not imported asynchronously: nothing to do.
+int arkmpc_batch_acquire(arkmpc_ctx* ctx, arkmpc_batch* batch) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    int rc = batch_check(ctx, batch);
+    if (rc) return rc;
+    arkmpc_batch* o = owner_of(batch);
+    if (!o->ready) return ARKMPC_OK;
+    CtxGuard guard(ctx);
+    if (guard.rc) return guard.rc;
+    ARK_HIP(ctx, hipStreamWaitEvent(ctx->stream, o->ready, 0));
+    return ARKMPC_OK;
+}
+// blocks until the import has read the caller's vector to its end, then drops the pin: the vector may be freed or overwritten.  (Consumers
+// enqueued after arkmpc_batch_acquire stay ordered by the stream.)  Idempotent.
+int arkmpc_batch_host_release(arkmpc_ctx* ctx, arkmpc_batch* batch) {
+    if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    int rc = batch_check(ctx, batch);
+    if (rc) return rc;
+    arkmpc_batch* o = owner_of(batch);
+    if (o->ready) {
+        if (hipEventSynchronize(o->ready) != hipSuccess) { ark_set_err(ctx, "hipEventSynchronize(import) failed"); rc = ARKMPC_ERR_HIP; }
+        CtxGuard guard(ctx);
+        // consumers that did not call arkmpc_batch_acquire are still ordered from here on: the import is complete
+        ctx->link_ev.push_back(o->ready);
+        o->ready = nullptr;
+    }
+    if (o->pins) { delete o->pins; o->pins = nullptr; }
+    if (o->staging) { const int r = arkmpc_free(ctx, o->staging); if (r && !rc) rc = r; o->staging = nullptr; }
+    return rc;
+}
+
 // the batch as the arkworks Vec<T> the awaiting caller expects (always AoS records); blocks until the data has landed
 int arkmpc_batch_to_host(arkmpc_ctx* ctx, const arkmpc_batch* b, void* host_records_out) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
     int rc = batch_check(ctx, b);
     if (rc) return rc;
+    if ((rc = arkmpc_batch_acquire(ctx, const_cast<arkmpc_batch*>(b)))) return rc;
     if (b->n && !host_records_out) return ark_bad(ctx, "null host buffer");
     if (!b->n) return arkmpc_sync(ctx);
     const size_t bytes = b->n * (size_t)b->words * 8;
@@ -198,6 +322,7 @@ int arkmpc_batch_beaver_mask(arkmpc_ctx* ctx, const arkmpc_batch* x, const arkmp
     const size_t n = x->n;
     int rc;
     if ((rc = share_batch_check(ctx, x, n)) || (rc = share_batch_check(ctx, y, n)) || (rc = share_batch_check(ctx, a, n)) || (rc = share_batch_check(ctx, b, n))) return rc;
+    for (const arkmpc_batch* q : {x, y, a, b}) if ((rc = arkmpc_batch_acquire(ctx, const_cast<arkmpc_batch*>(q)))) return rc;
     if ((rc = arkmpc_batch_create(ctx, ARKMPC_KIND_SCALAR, ARKMPC_LAYOUT_AOS, 2 * n, out_de))) return rc;
     rc = arkmpc_beaver_mask_v(ctx, n, x->share, x->stride, y->share, y->stride, a->share, a->stride, b->share, b->stride, (*out_de)->share);
     if (rc) { arkmpc_batch_destroy(ctx, *out_de); *out_de = nullptr; }
@@ -216,6 +341,7 @@ int arkmpc_batch_beaver_finish(arkmpc_ctx* ctx, int party_id, const uint64_t mac
     if ((rc = batch_check(ctx, my_de)) || (rc = batch_check(ctx, peer_de))) return rc;
     if (my_de->kind != ARKMPC_KIND_SCALAR || peer_de->kind != ARKMPC_KIND_SCALAR || my_de->n != 2 * n || peer_de->n != 2 * n)
         return ark_bad(ctx, "d||e batches must hold 2n Scalars");          // a short peer payload is an error, never an out-of-bounds read
+    for (const arkmpc_batch* q : {my_de, peer_de, a, b, c}) if ((rc = arkmpc_batch_acquire(ctx, const_cast<arkmpc_batch*>(q)))) return rc;
     if ((rc = arkmpc_batch_create(ctx, ARKMPC_KIND_SCALAR_SHARE, out_layout, n, out))) return rc;
     arkmpc_batch* r = *out;
     rc = arkmpc_beaver_finish_fused_v(ctx, n, party_id, mac_key, my_de->share, peer_de->share, a->share, a->mac, a->stride, b->share, b->mac, b->stride,

@@ -231,8 +231,12 @@ int arkmpc_group_free(arkmpc_group* g, uint64_t* const* shards) {
     return rc;
 }
 
-// host vector of `segs` segments x n elements  <->  shards.  Every member's DMA runs on its own stream (its own PCIe link); the call
-// returns when all of them have landed.
+// host vector of `segs` segments x n elements  <->  shards.  The host vector is pinned ONCE, whole (HostPins: nothing to do for a vector
+// the caller registered or allocated pinned), so that every member's copy is a true asynchronous DMA: the G copies are all enqueued -- each
+// on its member's stream, i.e. on its own GPU's PCIe link -- before the first one is waited for.  (Until round 5 the copies were issued from
+// pageable memory: the runtime stages such a copy through its own bounce buffers on the calling thread, so the members' uploads could
+// serialise behind one another.)  Vectors below ARKMPC_PIN_MIN_KB are not worth a registration and travel as pageable copies.  Returns when all
+// copies have landed.
 static int host_xfer(arkmpc_group* g, bool to_device, size_t n, size_t segs, size_t ew, const u64* host_c, u64* host_m, u64* const* shards) {
     if (!g) return ARKMPC_ERR_BAD_ARG;
     if (!segs || !ew) return gbad(g, "bad segment / element size");
@@ -240,6 +244,8 @@ static int host_xfer(arkmpc_group* g, bool to_device, size_t n, size_t segs, siz
     int rc = shards_ok(g, n, (const void* const*)shards, "null shard pointer");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
+    HostPins pins;
+    if (n) pins.pin(to_device ? (const void*)host_c : (const void*)host_m, segs * n * ew * 8);
     for (int m = 0; m < g->G; ++m) {
         size_t lo, cnt; range(g, n, m, &lo, &cnt);
         if (!cnt) continue;
@@ -252,7 +258,7 @@ static int host_xfer(arkmpc_group* g, bool to_device, size_t n, size_t segs, siz
         }
     }
     for (int m = 0; m < g->G; ++m) { GHIP(g, hipSetDevice(g->dev[m])); GHIP(g, hipStreamSynchronize(g->ctx[m]->stream)); }
-    return ARKMPC_OK;
+    return ARKMPC_OK;                                      // (the pin ends here: every copy has completed)
 }
 int arkmpc_group_scatter_h2d(arkmpc_group* g, size_t n, size_t segs, size_t elem_words, const uint64_t* host, uint64_t* const* shards) {
     return host_xfer(g, true, n, segs, elem_words, host, nullptr, shards);
@@ -261,7 +267,10 @@ int arkmpc_group_gather_d2h(arkmpc_group* g, size_t n, size_t segs, size_t elem_
     return host_xfer(g, false, n, segs, elem_words, nullptr, host, (u64* const*)shards);
 }
 
-// Vec<ScalarShare> (arkworks records on the host) <-> sharded ScalarShare vector in `layout`
+// Vec<ScalarShare> (arkworks records on the host) <-> sharded ScalarShare vector in `layout`.  Split columns: the vector is pinned once and
+// every member's import kernel reads ITS range of the records in place over its own link and writes the two columns (ark_import_split):
+// no staging block, no split pass, all members in flight together.  A vector that cannot be addressed in place (not pinnable, or only
+// 8-byte aligned) goes the old way per member: staging block, copy, split.
 int arkmpc_group_shares_from_host(arkmpc_group* g, int layout, size_t n, const uint64_t* host_records, uint64_t* const* shards) {
     if (!g) return ARKMPC_ERR_BAD_ARG;
     if (!layout_ok(layout)) return gbad(g, "bad layout");
@@ -270,14 +279,27 @@ int arkmpc_group_shares_from_host(arkmpc_group* g, int layout, size_t n, const u
     int rc = shards_ok(g, n, (const void* const*)shards, "null shard pointer");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
+    HostPins pins;
+    Place src;
+    if (n) {
+        src = classify_and_hold(g->ctx[0], pins, host_records, n * 64);
+        if (src.kind == Mem::Pageable) { pins.pin(host_records, n * 64); src = classify(g->ctx[0], host_records, n * 64); }
+    }
+    const bool in_place = src.kind == Mem::Pinned && src.zc();
     std::vector<void*> tmp(g->G, nullptr);
     for (int m = 0; m < g->G && rc == ARKMPC_OK; ++m) {
         size_t lo, cnt; range(g, n, m, &lo, &cnt);
         if (!cnt) continue;
+        if (hipSetDevice(g->dev[m]) != hipSuccess) { gset_err(g, "hipSetDevice failed"); rc = ARKMPC_ERR_HIP; break; }
+        if (in_place) {
+            // the mapped alias of a pinned range is valid on every device of the node (one registration, portable across the GPUs of the process)
+            rc = ark_import_split(g->ctx[m]->stream, cnt, (const char*)src.dev + 64 * lo, shards[m], shards[m] + 4 * cnt);
+            if (rc) gset_err(g, "import kernel launch failed");
+            continue;
+        }
         rc = arkmpc_malloc(g->ctx[m], cnt * 64, &tmp[m]);
         if (rc) { gfail(g, m, rc, "arkmpc_malloc"); break; }
-        if (hipSetDevice(g->dev[m]) != hipSuccess ||
-            hipMemcpyAsync(tmp[m], host_records + 8 * lo, cnt * 64, hipMemcpyHostToDevice, g->ctx[m]->stream) != hipSuccess) { gset_err(g, "H2D failed"); rc = ARKMPC_ERR_HIP; break; }
+        if (hipMemcpyAsync(tmp[m], host_records + 8 * lo, cnt * 64, hipMemcpyHostToDevice, g->ctx[m]->stream) != hipSuccess) { gset_err(g, "H2D failed"); rc = ARKMPC_ERR_HIP; break; }
         rc = arkmpc_share_split(g->ctx[m], cnt, (const u64*)tmp[m], shards[m], shards[m] + 4 * cnt);
         if (rc) gfail(g, m, rc, "arkmpc_share_split");
     }
@@ -296,6 +318,8 @@ int arkmpc_group_shares_to_host(arkmpc_group* g, int layout, size_t n, const uin
     int rc = shards_ok(g, n, (const void* const*)shards, "null shard pointer");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
+    HostPins pins;
+    if (n) pins.pin(host_records, n * 64);
     std::vector<void*> tmp(g->G, nullptr);
     for (int m = 0; m < g->G && rc == ARKMPC_OK; ++m) {
         size_t lo, cnt; range(g, n, m, &lo, &cnt);
@@ -313,6 +337,107 @@ int arkmpc_group_shares_to_host(arkmpc_group* g, int layout, size_t n, const uin
         if (tmp[m]) (void)arkmpc_free(g->ctx[m], tmp[m]);
     }
     return rc;
+}
+
+// ---- streaming sessions over the group: host vectors in, host vectors out, one PCIe link per member ----------------------------------
+// AuthenticatedScalarResult::batch_mul (authenticated_scalar.rs:848-879) for a party whose operands ARE host memory (what
+// benches/batch_ops.rs:19-39 times) and that owns several GPUs.  Host-fed, the path is bound by the host link, 20x below the kernels'
+// rate, so the links -- one per GPU -- are what more GPUs add.  A group session is one range session per member
+// (arkmpc_hostmul_begin_range on [g n/G, (g+1) n/G) of the SAME host vectors: x + 8 lo, ..., d at out_de + 4 lo, e at out_de + 4 (n + lo)),
+// each on its member's context, device and link.  The caller's vectors are pinned once per call, whole (nothing to do for vectors it
+// registered or allocated pinned); the member sessions then run their phases as kernels that address their ranges in place, and because
+// every member call only ENQUEUES (begin_range, finish_async), one host thread keeps all G links busy at once; _finish ends the members
+// after all of them have been started.  Vectors that cannot be pinned travel as the runtime's pageable copies, member after member.
+struct arkmpc_group_hostmul {
+    arkmpc_group* g = nullptr;
+    size_t n = 0;
+    std::vector<arkmpc_hostmul*> ses;                     // one per member (null: empty range)
+    HostPins pins_in, pins_de, pins_c, pins_peer, pins_out;
+};
+namespace {
+// ends every member session that is still open (their streams drain); keeps the first error
+int ghm_end_all(arkmpc_group_hostmul* s, int rc) {
+    arkmpc_group* g = s->g;
+    for (int m = 0; m < g->G; ++m) {
+        if (!s->ses[m]) continue;
+        const int r = arkmpc_hostmul_end(s->ses[m]);
+        s->ses[m] = nullptr;
+        if (r && !rc) rc = gfail(g, m, r, "arkmpc_hostmul_end");
+    }
+    delete s;                                             // (the whole-vector pins end with it: nothing is in flight any more)
+    return rc;
+}
+}  // namespace
+int arkmpc_group_hostmul_begin(arkmpc_group* g, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                               uint64_t* out_de, arkmpc_group_hostmul** out_session) {
+    if (!g) return ARKMPC_ERR_BAD_ARG;
+    if (!out_session) return gbad(g, "null out_session");
+    *out_session = nullptr;
+    if (n && (!x || !y || !a || !b || !c || !out_de)) return gbad(g, "null pointer");
+    if (n > ((size_t)1 << 40)) return gbad(g, "batch too large");
+    std::lock_guard<std::mutex> lk(g->mu);
+    arkmpc_group_hostmul* s = new arkmpc_group_hostmul();
+    s->g = g; s->n = n;
+    s->ses.assign(g->G, nullptr);
+    const size_t rec = n * 64;
+    if (n) { s->pins_in.pin(x, rec); s->pins_in.pin(y, rec); s->pins_in.pin(a, rec); s->pins_in.pin(b, rec); s->pins_de.pin(out_de, rec); }
+    for (int m = 0; m < g->G; ++m) {
+        size_t lo, cnt; range(g, n, m, &lo, &cnt);
+        if (!cnt) continue;
+        const int rc = arkmpc_hostmul_begin_range(g->ctx[m], cnt, x + 8 * lo, y + 8 * lo, a + 8 * lo, b + 8 * lo, c + 8 * lo, out_de + 4 * lo, out_de + 4 * (n + lo),
+                                                  ARKMPC_HOSTMUL_NO_PIN, &s->ses[m]);
+        if (rc) return ghm_end_all(s, gfail(g, m, rc, "arkmpc_hostmul_begin_range"));
+    }
+    if (n) s->pins_c.pin(c, rec);                          // under the members' phase 1: c is not looked at before _wait_de / _finish
+    *out_session = s;
+    return ARKMPC_OK;
+}
+// leading gates of d AND e that have landed in out_de: the members' ranges in order, up to and including the first incomplete one's progress
+int arkmpc_group_hostmul_poll_de(arkmpc_group_hostmul* s, size_t* out_gates) {
+    if (!s || !out_gates) return ARKMPC_ERR_BAD_ARG;
+    arkmpc_group* g = s->g;
+    size_t done = 0;
+    for (int m = 0; m < g->G; ++m) {
+        size_t lo, cnt; range(g, s->n, m, &lo, &cnt);
+        if (!cnt) continue;
+        size_t k = 0;
+        if (arkmpc_hostmul_poll_de(s->ses[m], &k) != ARKMPC_OK) break;
+        done = lo + k;
+        if (k < cnt) break;
+    }
+    *out_gates = done;
+    return ARKMPC_OK;
+}
+int arkmpc_group_hostmul_wait_de(arkmpc_group_hostmul* s) {
+    if (!s) return ARKMPC_ERR_BAD_ARG;
+    arkmpc_group* g = s->g;
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (int m = 0; m < g->G; ++m) if (s->ses[m]) GCALL(g, m, arkmpc_hostmul_wait_de(s->ses[m]));
+    s->pins_de.release();                                  // the payload has been produced: the vector is the caller's again
+    return ARKMPC_OK;
+}
+int arkmpc_group_hostmul_finish(arkmpc_group_hostmul* s, int party_id, const uint64_t mac_key[4], const uint64_t* peer_de, uint64_t* out) {
+    if (!s) return ARKMPC_ERR_BAD_ARG;
+    arkmpc_group* g = s->g;
+    std::lock_guard<std::mutex> lk(g->mu);
+    const size_t n = s->n;
+    int rc = ARKMPC_OK;
+    if (party_id != 0 && party_id != 1) rc = gbad(g, "party_id must be 0 or 1");
+    else if (!mac_key) rc = gbad(g, "null mac_key");
+    else if (n && (!peer_de || !out)) rc = gbad(g, "null pointer");
+    if (!rc && n) { s->pins_peer.pin(peer_de, n * 64); s->pins_out.pin(out, n * 64); }
+    for (int m = 0; m < g->G && !rc; ++m) {                // phase 2 of every member enqueued before any of them is waited for
+        size_t lo, cnt; range(g, n, m, &lo, &cnt);
+        if (!cnt) continue;
+        const int r = arkmpc_hostmul_finish_async(s->ses[m], party_id, mac_key, peer_de + 4 * lo, peer_de + 4 * (n + lo), out + 8 * lo);
+        if (r) rc = gfail(g, m, r, "arkmpc_hostmul_finish_async");
+    }
+    return ghm_end_all(s, rc);
+}
+int arkmpc_group_hostmul_abort(arkmpc_group_hostmul* s) {
+    if (!s) return ARKMPC_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(s->g->mu);
+    return ghm_end_all(s, ARKMPC_OK);
 }
 
 // ---- device-to-device movement: direct peer writes -------------------------------------------------------------------------------

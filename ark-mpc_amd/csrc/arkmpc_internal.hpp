@@ -57,6 +57,7 @@ struct arkmpc_ctx {
     static constexpr int kTimerSlots = 64;
     hipEvent_t tev[2 * kTimerSlots] = {};
     int timer_slot = -1;
+    arkmpc_ctx_stats stats = {};      // arkmpc_ctx_get_stats: written under `mu` only
 };
 
 struct arkmpc_ctx;
@@ -210,6 +211,42 @@ struct HostPins {
     ~HostPins() { release(); }
 };
 
+// Where a caller's vector lives (streaming sessions, group transfers, asynchronous batch imports).  Every vector is looked at on its own: a circuit keeps x, y (the previous gates' outputs) and its result in
+// HBM while the triples come from a preprocessing source in host memory and the payloads cross a host link (fabric.rs:894-915).
+enum class Mem { Pageable, Pinned, Device, Foreign };
+struct Place {
+    Mem kind = Mem::Pageable;
+    void* dev = nullptr;                                   // what a kernel dereferences: the pointer itself (Device), its mapped alias (Pinned)
+    bool zc() const { return dev && !((uintptr_t)dev & 15) && (kind == Mem::Device || kind == Mem::Pinned); }    // (the zero-copy kernels move 16-byte quarters; a Rust Vec only promises 8)
+    bool device() const { return kind == Mem::Device; }
+};
+static inline Place classify(const arkmpc_ctx* ctx, const void* p, size_t bytes) {
+    Place pl;
+    if (!p || !bytes) return pl;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return pl; }       // plain malloc memory on older runtimes
+    if (attr.type == hipMemoryTypeDevice) {
+        pl.kind = attr.device == ctx->device ? Mem::Device : Mem::Foreign;
+        pl.dev = const_cast<void*>(p);
+        return pl;
+    }
+    if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return pl;                               // hipMemoryTypeUnregistered, managed
+    if (!runtime_knows((const char*)p + bytes - 1)) return pl;                                          // a range that only begins inside somebody's registration
+    pl.kind = Mem::Pinned;
+    pl.dev = attr.devicePointer;
+    return pl;
+}
+// The same for a vector a kernel is going to address in place: the registry reference is taken FIRST (HostPins::keep), the pointer is looked
+// at afterwards.  The other order left a window -- round-4 advisor finding: a vector that is pinned only because ANOTHER session of this library
+// registered it (an in-process peer's out_de passed as this party's peer_de) could be unregistered by that session between the look and the
+// reference, and the kernel would then fault on an unmapped address.  If the look says "not pinned after all" the reference is dropped again.
+static inline Place classify_and_hold(const arkmpc_ctx* ctx, HostPins& pins, const void* p, size_t bytes) {
+    const size_t before = pins.held.size();
+    pins.keep(p, bytes);
+    const Place pl = classify(ctx, p, bytes);
+    if (pl.kind != Mem::Pinned && pins.held.size() > before) { pin_registry().release(pins.held.back()); pins.held.pop_back(); }
+    return pl;
+}
 // the events of one streamed call: taken from the context's free list, returned when the call has drained
 struct LinkEvents {
     arkmpc_ctx* ctx;
@@ -245,6 +282,9 @@ struct LinkEvents {
     }
 };
 
+// n arkworks ScalarShare records at rec_dev (a device-side address: HBM, or the mapped alias of pinned host memory) -> split columns, one pass,
+// enqueued on `st` (csrc/arkmpc_batch.hip)
+int ark_import_split(hipStream_t st, size_t n, const void* rec_dev, uint64_t* share_col, uint64_t* mac_col);
 // the wire codec on device buffers, for callers that hold the context lock (csrc/arkmpc_wire.hip)
 int ark_wire_encode_scalars_device(arkmpc_ctx* ctx, uint64_t result_id, size_t n, const uint64_t* d_scalars, uint8_t* d_frame, size_t cap, size_t* out_len);
 int ark_wire_decode_scalars_device(arkmpc_ctx* ctx, const uint8_t* d_frame, size_t frame_len, size_t max_n, uint64_t* d_scalars, size_t* out_n, uint64_t* out_result_id);

@@ -245,6 +245,43 @@ class Engine:
         arr, pk = _key(key)
         self._ck(self.lib.arkmpc_hostmul_finish(s, ctypes.c_int(int(party)), pk, _ptr(peer_de), _ptr(out)))
     def hostmul_abort(self, s): self._ck(self.lib.arkmpc_hostmul_abort(s))
+    NO_PIN = 1
+    def hostmul_begin_range(self, n, x, y, a, b, c, out_d, out_e, flags=0):
+        """Phase 1 of a session over a RANGE of a larger batch (d and e halves addressed separately); every vector may be a numpy array
+        (pageable / pinned host memory), a torch tensor or an int device pointer on this engine's GPU."""
+        s = ctypes.c_void_p()
+        self._ck(self.lib.arkmpc_hostmul_begin_range(self.h, ctypes.c_size_t(int(n)), _ptr(x), _ptr(y), _ptr(a), _ptr(b), _ptr(c), _ptr(out_d), _ptr(out_e),
+                                                     ctypes.c_uint(int(flags)), ctypes.byref(s)))
+        return s
+    def hostmul_finish_async(self, s, party, key, peer_d, peer_e, out):
+        arr, pk = _key(key)
+        self._ck(self.lib.arkmpc_hostmul_finish_async(s, ctypes.c_int(int(party)), pk, _ptr(peer_d), _ptr(peer_e), _ptr(out)))
+    def hostmul_end(self, s): self._ck(self.lib.arkmpc_hostmul_end(s))
+    def stats(self):
+        """arkmpc_ctx_get_stats as a dict"""
+        st = (ctypes.c_uint64 * 8)()
+        self._ck(self.lib.arkmpc_ctx_get_stats(self.h, st))
+        return {"hostmul_zero_copy_phases": (int(st[0]), int(st[1])), "hostmul_copy_phases": (int(st[2]), int(st[3])),
+                "hostmul_device_bytes_last": int(st[4]), "hostmul_device_bytes_peak": int(st[5]),
+                "batch_async_imports": int(st[6]), "batch_blocking_imports": int(st[7])}
+    # ---- device-batch handles (arkmpc_batch_*): the subset the asynchronous import needs
+    SCALAR, SCALAR_SHARE = 0, 1
+    AOS, SPLIT = 0, 1
+    def batch_from_host(self, kind, layout, n, host_records, asynchronous=False):
+        b = ctypes.c_void_p()
+        fn = self.lib.arkmpc_batch_from_host_async if asynchronous else self.lib.arkmpc_batch_from_host
+        self._ck(fn(self.h, ctypes.c_int(int(kind)), ctypes.c_int(int(layout)), ctypes.c_size_t(int(n)), _ptr(host_records), ctypes.byref(b)))
+        return b
+    def batch_acquire(self, b): self._ck(self.lib.arkmpc_batch_acquire(self.h, b))
+    def batch_host_release(self, b): self._ck(self.lib.arkmpc_batch_host_release(self.h, b))
+    def batch_destroy(self, b): self._ck(self.lib.arkmpc_batch_destroy(self.h, b))
+    def batch_to_host(self, b, out): self._ck(self.lib.arkmpc_batch_to_host(self.h, b, _ptr(out)))
+    def batch_ptrs(self, b):
+        """(share / record pointer, MAC pointer or 0, stride in u64) of a batch"""
+        self.lib.arkmpc_batch_data.restype = ctypes.c_void_p
+        self.lib.arkmpc_batch_mac_data.restype = ctypes.c_void_p
+        self.lib.arkmpc_batch_stride.restype = ctypes.c_size_t
+        return int(self.lib.arkmpc_batch_data(b) or 0), int(self.lib.arkmpc_batch_mac_data(b) or 0), int(self.lib.arkmpc_batch_stride(b))
     @staticmethod
     def host_trim():
         return load_library().arkmpc_host_trim()
@@ -465,6 +502,33 @@ class Group:
         arr, kp = _key(key)
         self._ck(self.lib.arkmpc_group_beaver_finish_fused(self.h, int(layout), ctypes.c_size_t(int(n)), int(party), kp, self._sh(my_de), self._sh(peer_de), self._sh(a),
                                                            self._sh(b), self._sh(c), self._sh(out)))
+
+    # ---- streaming sessions over the group (arkmpc_group_hostmul_*): host numpy vectors in, host vectors out, one link per member
+    def hostmul_begin(self, n, x, y, a, b, c, out_de):
+        s = ctypes.c_void_p()
+        self._ck(self.lib.arkmpc_group_hostmul_begin(self.h, ctypes.c_size_t(int(n)), _ptr(x), _ptr(y), _ptr(a), _ptr(b), _ptr(c), _ptr(out_de), ctypes.byref(s)))
+        return s
+
+    def hostmul_poll_de(self, s):
+        g = ctypes.c_size_t(0)
+        self._ck(self.lib.arkmpc_group_hostmul_poll_de(s, ctypes.byref(g)))
+        return int(g.value)
+
+    def hostmul_wait_de(self, s):
+        self._ck(self.lib.arkmpc_group_hostmul_wait_de(s))
+
+    def hostmul_finish(self, s, party, key, peer_de, out):
+        arr, kp = _key(key)
+        self._ck(self.lib.arkmpc_group_hostmul_finish(s, ctypes.c_int(int(party)), kp, _ptr(peer_de), _ptr(out)))
+
+    def hostmul_abort(self, s):
+        self._ck(self.lib.arkmpc_group_hostmul_abort(s))
+
+    def member_stats(self, member):
+        st = (ctypes.c_uint64 * 8)()
+        self.lib.arkmpc_ctx_get_stats(self.member_ctx(member), st)
+        return {"hostmul_zero_copy_phases": (int(st[0]), int(st[1])), "hostmul_copy_phases": (int(st[2]), int(st[3])),
+                "hostmul_device_bytes_last": int(st[4]), "hostmul_device_bytes_peak": int(st[5])}
 
     def prepare_beaver(self, layout, n, party, key, x, y, a, b, c, my_de, peer_de, out):
         """Pre-marshalled K1 and K2+K3 group calls (replayed in timing loops)."""

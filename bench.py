@@ -670,9 +670,7 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
         eng.hostmul_finish(s, p, keys[p], peer_de, out[p])
 
     def zero_copy_phases():
-        c_ = (ctypes.c_uint64 * 2)()
-        lib.arkmpc_test_hostmul_zero_copy_phases(c_)            # include/arkmpc_test_hooks.h: which path ran (a count, nothing timed depends on it)
-        return int(c_[0]), int(c_[1])
+        return eng.stats()["hostmul_zero_copy_phases"]          # arkmpc_ctx_get_stats: which path ran (a count, nothing timed depends on it)
 
     def timed_one(label, fresh):
         """back_to_back: `reps` sessions one after the other, as a circuit of many gates keeps the link busy (the throughput figure).  isolated: one

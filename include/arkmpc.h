@@ -68,6 +68,17 @@ int arkmpc_ctx_set_stream(arkmpc_ctx* ctx, void* hip_stream);
 int arkmpc_ctx_set_host_buffers(arkmpc_ctx* ctx, int enabled);
 int arkmpc_sync(arkmpc_ctx* ctx);
 const char* arkmpc_last_error(arkmpc_ctx* ctx);
+/* Counters of one context since its creation (diagnostics: which path the streaming sessions below took, what they held).  A session phase
+ * counts once, under the path that ran it; *_bytes_* = device memory one session held (the last one to take a block / the largest so far). */
+typedef struct {
+    uint64_t hostmul_zero_copy_phases[2];   /* [0] phase 1 (_begin), [1] phase 2 (_finish): ran as ONE kernel on the caller's vectors in place */
+    uint64_t hostmul_copy_phases[2];        /* ... ran through the three-stream copy pipeline */
+    uint64_t hostmul_device_bytes_last;
+    uint64_t hostmul_device_bytes_peak;
+    uint64_t batch_async_imports;           /* arkmpc_batch_from_host_async calls that went up asynchronously (in-place kernel or DMA) */
+    uint64_t batch_blocking_imports;        /* ... that fell back to the blocking copy (small or unpinnable vectors) */
+} arkmpc_ctx_stats;
+int arkmpc_ctx_get_stats(arkmpc_ctx* ctx, arkmpc_ctx_stats* out_stats);
 /* Kernel timer: arm slot s (0..63) and the NEXT K1 / K2+K3 / K5 launch on this context gets HIP events bound to
  * its dispatch (hipExtLaunchKernelGGL start/stop events): arkmpc_kernel_timer_ms then returns that kernel's own duration
  * (it blocks until the kernel has finished).  Unlike marker events recorded between launches this excludes the dispatch gap. */
@@ -112,6 +123,19 @@ typedef enum {
 int arkmpc_batch_create(arkmpc_ctx* ctx, int kind, int layout, size_t n, arkmpc_batch** out_batch);   /* uninitialised storage */
 /* upload a host Vec<T> (n arkworks records); with ARKMPC_LAYOUT_SPLIT the columns are separated on the device */
 int arkmpc_batch_from_host(arkmpc_ctx* ctx, int kind, int layout, size_t n, const void* host_records, arkmpc_batch** out_batch);
+/* The same WITHOUT blocking, at link speed -- for the triples a PreprocessingPhase hands over as host vectors gate after gate
+ * (fabric.rs:894-915 next_triple_batch, offline_prep.rs:65-81; 192 B per party-gate, what bounds a circuit whose operands are resident):
+ * the records go up on the context's upload stream behind whatever its compute stream is doing.  ScalarShare batches in
+ * ARKMPC_LAYOUT_SPLIT are read IN PLACE over the link by one kernel that writes the two columns (no staging copy, no split pass); everything
+ * else is one DMA.  The caller's vector is pinned in place unless it already is (arkmpc_host_alloc / arkmpc_host_register).
+ *   _acquire        the context's compute stream waits, on the device, for the import (returns at once).  The batch-level entry points do
+ *                   it themselves; call it before handing arkmpc_batch_data() pointers to the pointer-level ones.
+ *   _host_release   blocks until the import has read host_records to its end and drops the pin; only then may the vector be freed or
+ *                   overwritten (arkmpc_batch_destroy does the same if it was never called).
+ * Vectors that cannot be pinned (below 1 MiB, read-only mappings) take the blocking path of arkmpc_batch_from_host. */
+int arkmpc_batch_from_host_async(arkmpc_ctx* ctx, int kind, int layout, size_t n, const void* host_records, arkmpc_batch** out_batch);
+int arkmpc_batch_acquire(arkmpc_ctx* ctx, arkmpc_batch* batch);
+int arkmpc_batch_host_release(arkmpc_ctx* ctx, arkmpc_batch* batch);
 /* the batch as n arkworks records in host memory, whatever its device layout; blocks */
 int arkmpc_batch_to_host(arkmpc_ctx* ctx, const arkmpc_batch* batch, void* host_records_out);
 /* &v[lo .. lo+count] as a new handle that SHARES the storage (and keeps it alive): index-range sharding, sub-batches */
@@ -261,6 +285,7 @@ int arkmpc_host_trim(void);                             /* returns the free list
  *            of a real link can start transmitting before the batch is complete.
  *   _finish  peer_de: the 2n Scalars received (:871-878); out: n ScalarShares.  Blocks until `out` is complete; ends the session (also
  *            when it returns an error).  _abort ends a session without phase 2.
+ * out_de is the caller's again once _wait_de has returned (it has been sent; it may be freed or reused before _finish).
  * The input vectors must stay valid, unmodified and (if the caller pinned them) pinned until _finish / _abort returns; sessions must be
  * ended before their context is destroyed.  Sessions of different contexts (rayon workers) are independent; two parties sharing one GPU
  * do best as two sessions of ONE context driven by one thread (their uploads then queue instead of racing on the link). */
@@ -271,6 +296,24 @@ int arkmpc_hostmul_poll_de(arkmpc_hostmul* session, size_t* out_gates);
 int arkmpc_hostmul_wait_de(arkmpc_hostmul* session);
 int arkmpc_hostmul_finish(arkmpc_hostmul* session, int party_id, const uint64_t mac_key[4], const uint64_t* peer_de, uint64_t* out);
 int arkmpc_hostmul_abort(arkmpc_hostmul* session);
+/* Placement and range forms of the same session.
+ * PLACEMENT: every vector of a session is looked at on its own and may be pageable host memory, pinned host memory or DEVICE memory of the
+ *   context's GPU (16-byte aligned; memory of another GPU is ARKMPC_ERR_BAD_ARG).  A circuit keeps x, y -- the previous gates' outputs -- and
+ *   its result resident in HBM while the triples a, b, c lie in the preprocessing source's host memory (fabric.rs:894-915,
+ *   offline_prep.rs:65-81) and the payloads cross a host link: resident vectors are read / written where they are, nothing is staged for them.
+ * RANGE: _begin_range / _finish_async address the two halves of a d||e vector separately, so a session can be gates [lo, lo + n) of a batch
+ *   of N: pass x + 8 lo ... c + 8 lo, out_d = de + 4 lo, out_e = de + 4 (N + lo) (same for peer_d / peer_e, out + 8 lo).  This is what the
+ *   multi-device group's sessions below are made of.  flags: ARKMPC_HOSTMUL_NO_PIN = the session registers no host memory itself (the caller
+ *   pins whole vectors once for all of its range sessions; unpinned vectors then travel as the runtime's pageable copies).
+ * _finish_async enqueues phase 2 and returns; _end blocks until `out` is complete and ends the session (arkmpc_hostmul_finish = the two
+ *   together).  After a failed _finish_async the session is still open: end it with _end or _abort.  Several sessions -- one per GPU of a
+ *   group -- therefore run their phases concurrently from one host thread. */
+#define ARKMPC_HOSTMUL_NO_PIN 1u
+int arkmpc_hostmul_begin_range(arkmpc_ctx* ctx, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a, const uint64_t* b,
+                               const uint64_t* c, uint64_t* out_d, uint64_t* out_e, unsigned flags, arkmpc_hostmul** out_session);
+int arkmpc_hostmul_finish_async(arkmpc_hostmul* session, int party_id, const uint64_t mac_key[4], const uint64_t* peer_d,
+                                const uint64_t* peer_e, uint64_t* out);
+int arkmpc_hostmul_end(arkmpc_hostmul* session);
 /* The same session with the payloads in their WIRE form -- the frames QuicTwoPartyNet writes and reads (network/quic.rs:226-251, :303-306;
  * format below under "Wire format"), ~115 text bytes per scalar, rendered and parsed on the GPU so that the host never runs serde_json over
  * 2n scalars (where the QUIC path's time goes):
@@ -496,12 +539,30 @@ const char* arkmpc_group_last_error(arkmpc_group* grp);
 /* sharded storage: out_shards / shards = arrays of G pointers */
 int arkmpc_group_malloc(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, uint64_t** out_shards);
 int arkmpc_group_free(arkmpc_group* grp, uint64_t* const* shards);
-/* host full vector <-> shards; every member's DMA runs on its own stream / PCIe link; blocks */
+/* host full vector <-> shards: the host vector is pinned once (unless the caller already did), every member's DMA is enqueued on its own
+ * stream / PCIe link before any is waited for; blocks until all have landed */
 int arkmpc_group_scatter_h2d(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, const uint64_t* host, uint64_t* const* shards);
 int arkmpc_group_gather_d2h(arkmpc_group* grp, size_t n, size_t segs, size_t elem_words, const uint64_t* const* shards, uint64_t* host);
-/* host Vec<ScalarShare> (n arkworks records) <-> sharded ScalarShare vector in `layout`; blocks */
+/* host Vec<ScalarShare> (n arkworks records) <-> sharded ScalarShare vector in `layout`; blocks.  _from_host into ARKMPC_LAYOUT_SPLIT reads the
+ * pinned records in place, one kernel per member over its own link writing both columns (no staging, no split pass) */
 int arkmpc_group_shares_from_host(arkmpc_group* grp, int layout, size_t n, const uint64_t* host_records, uint64_t* const* shards);
 int arkmpc_group_shares_to_host(arkmpc_group* grp, int layout, size_t n, const uint64_t* const* shards, uint64_t* host_records);
+/* AuthenticatedScalarResult::batch_mul (authenticated_scalar.rs:848-879) as a streaming session over the GROUP: the arkmpc_hostmul_* session
+ * above for a party that owns several GPUs and whose operands are host vectors (benches/batch_ops.rs:19-39).  Same arguments, same words: x, y,
+ * a, b, c = n ScalarShare records each in HOST memory, out_de / peer_de = 2n Scalars (d then e), out = n records.  Member g runs gates
+ * [g n/G, (g+1) n/G) of the same vectors as a range session on its own device and PCIe link; the vectors are pinned once per call, whole
+ * (nothing to do for vectors from arkmpc_host_alloc / arkmpc_host_register -- the form that reaches the links' rate), and because the member
+ * calls only enqueue, all G links are busy together from one host thread.  Host-fed, a party is link-bound 20x below the kernels' rate, so the
+ * links are what more GPUs add.  _begin returns once phase 1 is enqueued on every member; _poll_de = leading gates of d AND e complete in out_de
+ * (members in range order); _wait_de blocks until all of out_de is (it is the caller's again afterwards); _finish blocks until `out` is
+ * complete and ends the session (also on error); _abort ends it without phase 2. */
+typedef struct arkmpc_group_hostmul arkmpc_group_hostmul;
+int arkmpc_group_hostmul_begin(arkmpc_group* grp, size_t n, const uint64_t* x, const uint64_t* y, const uint64_t* a, const uint64_t* b,
+                               const uint64_t* c, uint64_t* out_de, arkmpc_group_hostmul** out_session);
+int arkmpc_group_hostmul_poll_de(arkmpc_group_hostmul* session, size_t* out_gates);
+int arkmpc_group_hostmul_wait_de(arkmpc_group_hostmul* session);
+int arkmpc_group_hostmul_finish(arkmpc_group_hostmul* session, int party_id, const uint64_t mac_key[4], const uint64_t* peer_de, uint64_t* out);
+int arkmpc_group_hostmul_abort(arkmpc_group_hostmul* session);
 /* device <-> device over xGMI as DIRECT PEER WRITES (no ring): gather = every member pushes its range into the full buffer on
  * member `root`; allgather = every member pushes its range into every member's full buffer (G*(G-1) point-to-point copies, all
  * links busy at once); scatter = root pushes each member its range of a full buffer.  The consumers' streams wait on the device. */

@@ -1,7 +1,8 @@
 /* C99 caller of the multi-device group (include/arkmpc.h, arkmpc_group_*): ONE process, G members.  Run with repeated device ids
  * ({0,0,...}: members share the GPU, each with its own stream) the whole sharded path -- range kernels, peer pushes, gathers, the
  * pipelined commitment, the AND-reduced verify flag -- must equal, word for word, what ONE context computes on the unsharded batch:
- *   config-3 shape: two parties' Beaver batch_mul over n gates of BN254 Fr, in both layouts, d||e handed over member by member;
+ *   config-3 shape: two parties' Beaver batch_mul over n gates of BN254 Fr, in both layouts, d||e handed over member by member; the same as
+ *                   streaming sessions over the group (arkmpc_group_hostmul_*: host vectors in and out, one range session per member);
  *   config-5 shape: open_authenticated_batch over n shares of BLS12-381 Fr incl. commitments, and a corrupted last share;
  *   MSM: group bucket MSM == single-context MSM (as affine points).
  * usage: group_oversub [n [G [device ids...]]]     (default n = 100003, G = 4 on device 0; device ids default to 0)
@@ -120,6 +121,53 @@ static int beaver(size_t n, int G, const int* devs) {
                   arkmpc_group_free(grp[p], sc[p]) == 0 && arkmpc_group_free(grp[p], sout[p]) == 0 && arkmpc_group_free(grp[p], sde[p]) == 0);
         }
     }
+    /* streaming sessions over the group: the same host vectors in, host vectors out, each member on its range and link.  Once with the
+     * vectors as malloc gave them (pinned by the call), once in memory the caller pinned (arkmpc_host_alloc: the phases run in place). */
+    for (int pinned = 0; pinned < 2; ++pinned) {
+        uint64_t *hx[2], *hy[2], *ha[2], *hb[2], *hc[2], *hde[2], *hout[2];
+        arkmpc_group_hostmul* ses[2] = {NULL, NULL};
+        for (int p = 0; p < 2; ++p) {
+            uint64_t** dst[7] = {&hx[p], &hy[p], &ha[p], &hb[p], &hc[p], &hde[p], &hout[p]};
+            const uint64_t* src[7] = {x[p], y[p], a[p], b[p], c[p], NULL, NULL};
+            for (int k = 0; k < 7; ++k) {
+                if (pinned) { void* q = NULL; CHECK(arkmpc_host_alloc(n * 64 + 16, &q) == ARKMPC_OK); *dst[k] = (uint64_t*)q; }
+                else *dst[k] = zeros(8 * n + 2);
+                if (src[k]) memcpy(*dst[k], src[k], n * 64); else memset(*dst[k], 0, n * 64);
+            }
+        }
+        for (int p = 0; p < 2; ++p) CHECK(arkmpc_group_hostmul_begin(grp[p], n, hx[p], hy[p], ha[p], hb[p], hc[p], hde[p], &ses[p]) == ARKMPC_OK);
+        for (int p = 0; p < 2; ++p) {
+            size_t done = 0;
+            CHECK(arkmpc_group_hostmul_poll_de(ses[p], &done) == ARKMPC_OK && done <= n);
+            CHECK(arkmpc_group_hostmul_wait_de(ses[p]) == ARKMPC_OK);
+            CHECK(arkmpc_group_hostmul_poll_de(ses[p], &done) == ARKMPC_OK && done == n);
+            CHECK(memcmp(hde[p], want_de[p], n * 64) == 0);
+        }
+        for (int p = 0; p < 2; ++p) {
+            CHECK(arkmpc_group_hostmul_finish(ses[p], p, key[p], hde[1 - p], hout[p]) == ARKMPC_OK);
+            CHECK(memcmp(hout[p], want[p], n * 64) == 0);
+        }
+        if (n >= (size_t)4096 * (size_t)G && pinned) {        /* every member's range reaches the in-place threshold: both phases of both parties ran as kernels on the vectors */
+            for (int m = 0; m < G; ++m) {
+                arkmpc_ctx_stats st;
+                CHECK(arkmpc_ctx_get_stats(arkmpc_group_ctx(grp[0], m), &st) == ARKMPC_OK);
+                CHECK(st.hostmul_zero_copy_phases[0] >= 1 && st.hostmul_zero_copy_phases[1] >= 1 && st.hostmul_device_bytes_peak <= 512 * (n / (size_t)G + 1));
+            }
+        }
+        /* misuse: a null vector, a bad party; an aborted session leaves the group usable */
+        {
+            arkmpc_group_hostmul* s2 = NULL;
+            if (n) CHECK(arkmpc_group_hostmul_begin(grp[0], n, hx[0], NULL, ha[0], hb[0], hc[0], hde[0], &s2) == ARKMPC_ERR_BAD_ARG && s2 == NULL);
+            CHECK(arkmpc_group_hostmul_begin(grp[0], n, hx[0], hy[0], ha[0], hb[0], hc[0], hde[0], &s2) == ARKMPC_OK);
+            CHECK(arkmpc_group_hostmul_finish(s2, 7, key[0], hde[1], hout[0]) == ARKMPC_ERR_BAD_ARG);       /* ends the session */
+            CHECK(arkmpc_group_hostmul_begin(grp[0], n, hx[0], hy[0], ha[0], hb[0], hc[0], hde[0], &s2) == ARKMPC_OK);
+            CHECK(arkmpc_group_hostmul_abort(s2) == ARKMPC_OK);
+        }
+        for (int p = 0; p < 2; ++p) {
+            uint64_t* all[7] = {hx[p], hy[p], ha[p], hb[p], hc[p], hde[p], hout[p]};
+            for (int k = 0; k < 7; ++k) { if (pinned) CHECK(arkmpc_host_free(all[k]) == ARKMPC_OK); else free(all[k]); }
+        }
+    }
     /* misuse is a status code */
     {
         shards_t bad;
@@ -136,7 +184,7 @@ static int beaver(size_t n, int G, const int* devs) {
     for (int p = 0; p < 2; ++p) { free(x[p]); free(y[p]); free(a[p]); free(b[p]); free(c[p]); free(key[p]); free(want_de[p]); free(want[p]); CHECK(arkmpc_group_destroy(grp[p]) == 0); grp[p] = NULL; }
     free(got);
     CHECK(arkmpc_ctx_destroy(ctx) == 0);
-    printf("  beaver batch_mul over %zu gates on %d members: AoS + split, host / member hand-over, gather / gathered K1 / all-gather / scatter: bit-equal\n", n, G);
+    printf("  beaver batch_mul over %zu gates on %d members: AoS + split, host / member hand-over, gather / gathered K1 / all-gather / scatter, group sessions (pageable + pinned): bit-equal\n", n, G);
     return 0;
 }
 

@@ -76,7 +76,9 @@ def _run_two_party(eng, n, keys, sh, poll=False):
 
 @pytest.fixture(scope="module")
 def engs(pkg):
-    return {fid: pkg.Engine(fid, device=0) for fid in (0, 1, 2)}
+    d = {fid: pkg.Engine(fid, device=0) for fid in (0, 1, 2)}
+    _TRACKED.extend(d.values())
+    return d
 
 
 @pytest.mark.parametrize("fid", [0, 1, 2])
@@ -395,8 +397,8 @@ def test_hostmul_soak_random_sizes_two_threads(pkg, oracle, pinned):
     arena = _PinnedArena(pkg)
     if pinned:
         sh = {k: (arena.copy(v[0]), arena.copy(v[1])) for k, v in sh.items()}
-    zc_before = _zc_count(pkg)
     es = [pkg.Engine(fid, device=0) for _ in (0, 1)]
+    zc_before = _zc_count(pkg, *es)
     sizes = [rng.choice([1, 2, 63, 255, 256, 257, 1000, 4095, 4096, 4097, 16384, 16385, 33000, base_n]) for _ in range(150)]
     offs = [rng.randrange(0, base_n - n + 1) for n in sizes]
     bar = threading.Barrier(2)
@@ -455,7 +457,7 @@ def test_hostmul_soak_random_sizes_two_threads(pkg, oracle, pinned):
     assert not errs, errs[:2]
     if pinned:
         de, out = keep_de, keep_out
-        zc_after = _zc_count(pkg)
+        zc_after = _zc_count(pkg, *es)
         big = sum(1 for n in sizes if n >= 4096)
         assert (zc_after[0] - zc_before[0], zc_after[1] - zc_before[1]) == (2 * big, 2 * big)
     for k, (n, o) in enumerate(zip(sizes, offs)):
@@ -471,10 +473,16 @@ def test_hostmul_soak_random_sizes_two_threads(pkg, oracle, pinned):
 # ---- zero-copy phases: vectors the caller pinned are read and written IN PLACE by k_hostmul_mask / k_hostmul_finish (no copy commands);
 # ---- each phase falls back to the DMA pipeline on its own.  The test hook counts the phases that ran zero-copy, so these tests also
 # ---- pin WHICH path produced the (identical) words.
-def _zc_count(pkg):
-    out = (ctypes.c_uint64 * 2)()
-    assert pkg.load_library().arkmpc_test_hostmul_zero_copy_phases(out) == 0
-    return int(out[0]), int(out[1])
+_TRACKED = []           # the module's shared engines (fixture `engs`): their per-context counters are what the path assertions read
+
+
+def _zc_count(pkg, *extra):
+    """phases that ran as zero-copy kernels so far (arkmpc_ctx_get_stats), summed over the module's shared engines and `extra`"""
+    tot = [0, 0]
+    for e in list(_TRACKED) + list(extra):
+        z = e.stats()["hostmul_zero_copy_phases"]
+        tot[0] += z[0]; tot[1] += z[1]
+    return tot[0], tot[1]
 
 
 def _two_party_on(eng, n, keys, sh, place):
@@ -514,9 +522,9 @@ def test_hostmul_zero_copy_two_launches_per_phase(pkg, oracle):
     arena = _PinnedArena(pkg)
     e = pkg.Engine(fid, device=0, stream=torch.cuda.current_stream().cuda_stream)
     _, keys, sh = _inputs(fid, n, seed=8200, tile_from=4001)
-    before = _zc_count(pkg)
+    before = _zc_count(pkg, e)
     de, out = _two_party_on(e, n, keys, sh, lambda k, a: arena.copy(a))
-    after = _zc_count(pkg)
+    after = _zc_count(pkg, e)
     assert (after[0] - before[0], after[1] - before[1]) == (2, 2)
     ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
     for party in (0, 1):
@@ -539,9 +547,9 @@ def test_hostmul_mixed_zero_copy_and_dma_phases(pkg, engs, oracle, pageable):
     de, out = _two_party_on(engs[fid], n, keys, sh, place)
     after = _zc_count(pkg)
     got = (after[0] - before[0], after[1] - before[1])
-    # "phase1": party 0 finishes while party 1's session still holds its own d||e vector pinned (the library pinned it for the downloads), so
-    # party 0's phase 2 finds all of c, peer payload and result pinned and runs zero-copy; party 1's peer payload is pageable again by then
-    assert got == {"phase2": (2, 0), "phase1": (0, 1), "c_only": (2, 2), "x_only": (0, 2)}[pageable], got
+    # "phase1": the payload vectors are pageable; each party's pin on its own d||e ends at _wait_de (the vector is the caller's again), so both
+    # parties' phase 2 find a pageable peer payload and go through the copy pipeline
+    assert got == {"phase2": (2, 0), "phase1": (0, 0), "c_only": (2, 2), "x_only": (0, 2)}[pageable], got
     ode, want = _oracle_two_party(oracle, fid, n, keys, sh)
     for party in (0, 1):
         assert np.array_equal(de[party], ode[party]) and np.array_equal(out[party], want[party]), "party %d" % party
@@ -584,7 +592,8 @@ def test_exception_inside_an_entry_point_aborts_instead_of_unwinding(pkg):
     import subprocess, sys, os, signal
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import importlib, sys; sys.path.insert(0, %r); pkg = importlib.import_module('ark-mpc_amd'); e = pkg.Engine(0, device=0); "
-            "print('before', flush=True); rc = pkg.load_library().arkmpc_test_throw_inside(e.h); print('after', rc, flush=True)" % root)
+            "import ctypes, os; hooks = ctypes.CDLL(os.path.join(os.path.dirname(pkg.lib_path()), 'libarkmpc_testhooks.so')); "
+            "print('before', flush=True); rc = hooks.arkmpc_test_throw_inside(e.h); print('after', rc, flush=True)" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "before" in r.stdout and "after" not in r.stdout
     assert r.returncode == -signal.SIGABRT, r.returncode
