@@ -222,6 +222,11 @@ class PreprocessingPhase {
     // Optional: a source whose batches are n copies of one value (the dummy source below) may describe them by that value;
     // the fabric then fills the batch on the GPU (arkmpc_fill) instead of building and uploading n-element host vectors.
     virtual bool constant_triplet(ScalarShare&, ScalarShare&, ScalarShare&) { return false; }
+    // Optional: a source that keeps its triples in memory of its own (LowGearPrep holds Vecs it split_off()s from, offline-phase
+    // lowgear/mod.rs) may LEND the next n instead of copying them out: the three pointers address n consecutive ScalarShare records each, valid
+    // and unmodified until the next call on this source.  The fabric then imports them straight from there (asynchronously, in place over
+    // the link when the storage is pinned) -- no intermediate Vec, no pin / unpin per gate.  Consumes the triples like next_triplet_batch.
+    virtual bool borrow_triplet_batch(size_t /*n*/, const ScalarShare** /*a*/, const ScalarShare** /*b*/, const ScalarShare** /*c*/) { return false; }
     virtual bool constant_input_masks(Scalar& /*local value*/, ScalarShare& /*local share*/, ScalarShare& /*counterparty share*/) { return false; }
 };
 // offline_prep.rs:88-170: a = 2, b = 3, c = 6 statically split; MAC key share = party id
@@ -342,6 +347,51 @@ class DealerBeaverSource : public PreprocessingPhase {
     const Engine& e_;
     uint64_t state_;
     Scalar key_share_[2], key_;
+};
+
+// A source that holds its triples in PINNED host memory, the way a real offline phase would leave them for this engine: `capacity` triples are
+// drawn from an inner source once (here: at construction) into three arkmpc_host_alloc blocks and then handed out in order -- copied into Vecs
+// through the PreprocessingPhase interface (next_triplet_batch), or lent in place (borrow_triplet_batch).  Everything else -- MAC key share,
+// masks, bits, inverse pairs -- is the inner source's.  Running out is what LowGearPrep does (assert, offline-phase/src/structs.rs:189): throws.
+class VectorBeaverSource : public PreprocessingPhase {
+  public:
+    VectorBeaverSource(std::unique_ptr<PreprocessingPhase> inner, size_t capacity) : inner_(std::move(inner)), cap_(capacity) {
+        std::vector<ScalarShare> a, b, c;
+        inner_->next_triplet_batch(cap_, a, b, c);
+        if (a.size() != cap_ || b.size() != cap_ || c.size() != cap_) throw std::runtime_error("VectorBeaverSource: the inner source is short of triples");
+        const std::vector<ScalarShare>* src[3] = {&a, &b, &c};
+        for (int k = 0; k < 3; ++k) {
+            void* q = nullptr;
+            if (arkmpc_host_alloc((cap_ ? cap_ : 1) * sizeof(ScalarShare), &q) != ARKMPC_OK) throw std::runtime_error("arkmpc_host_alloc failed: no GPU runtime, or out of pinnable memory");
+            store_[k] = static_cast<ScalarShare*>(q);
+            if (cap_) std::memcpy(store_[k], src[k]->data(), cap_ * sizeof(ScalarShare));
+        }
+    }
+    ~VectorBeaverSource() override { for (auto* q : store_) if (q) arkmpc_host_free(q); }
+    VectorBeaverSource(const VectorBeaverSource&) = delete;
+    Scalar get_mac_key_share() override { return inner_->get_mac_key_share(); }
+    std::pair<std::vector<Scalar>, std::vector<ScalarShare>> next_local_input_mask_batch(size_t n) override { return inner_->next_local_input_mask_batch(n); }
+    std::vector<ScalarShare> next_counterparty_input_mask_batch(size_t n) override { return inner_->next_counterparty_input_mask_batch(n); }
+    std::vector<ScalarShare> next_shared_bit_batch(size_t n) override { return inner_->next_shared_bit_batch(n); }
+    std::vector<ScalarShare> next_shared_value_batch(size_t n) override { return inner_->next_shared_value_batch(n); }
+    void next_shared_inverse_pair_batch(size_t n, std::vector<ScalarShare>& l, std::vector<ScalarShare>& r) override { inner_->next_shared_inverse_pair_batch(n, l, r); }
+    void next_triplet_batch(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) override {
+        const ScalarShare *pa, *pb, *pc;
+        borrow_triplet_batch(n, &pa, &pb, &pc);
+        a.assign(pa, pa + n); b.assign(pb, pb + n); c.assign(pc, pc + n);
+    }
+    bool borrow_triplet_batch(size_t n, const ScalarShare** a, const ScalarShare** b, const ScalarShare** c) override {
+        if (n > cap_ - used_) throw std::runtime_error("preprocessing exhausted: " + std::to_string(cap_ - used_) + " triples left, " + std::to_string(n) + " requested");
+        *a = store_[0] + used_; *b = store_[1] + used_; *c = store_[2] + used_;
+        used_ += n;
+        return true;
+    }
+    size_t remaining() const { return cap_ - used_; }
+
+  private:
+    std::unique_ptr<PreprocessingPhase> inner_;
+    size_t cap_ = 0, used_ = 0;
+    ScalarShare* store_[3] = {nullptr, nullptr, nullptr};
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -568,6 +618,7 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     }
     // the next n triples as host vectors (PreprocessingPhase::next_triplet_batch, offline_prep.rs:65-81), ids advanced as next_triple_batch
     void next_triple_host(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) {
+        if (pending_) throw std::logic_error("next_triple_host after triples were read ahead into HBM: turn the prefetch off on a fabric that is driven through host-vector triples");
         prep_->next_triplet_batch(n, a, b, c);
         if (a.size() != n || b.size() != n || c.size() != n) throw std::runtime_error("preprocessing exhausted");
         next_id_ += 3 * n;
@@ -662,6 +713,16 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // fabric.rs:894-915.  broadcast_ok: the caller consumes the triples through column views only (the scalar Beaver kernels), so a source
     // whose batch is n copies of one value may hand out ONE record read with element stride 0 instead of n materialised copies
     void next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c, bool broadcast_ok = false);
+    // Triples of a real source are host vectors, 192 B per party-gate: over a 56 GB/s link that -- not the kernels -- bounds a circuit whose
+    // operands are resident.  They therefore go up asynchronously (arkmpc_batch_from_host_async: in place over the link for split columns), and
+    // with prefetch on the triples of the NEXT gate are requested from the source and started on their way as soon as this gate's K1 is enqueued,
+    // i.e. under this gate's network round and K2+K3.  The source is a FIFO of triples, so reading ahead changes nothing a party can observe,
+    // as long as both parties do it (they run the same program); a request of another size is served from what was read ahead, in order.
+    // ARKMPC_TRIPLE_PREFETCH=0 turns it off (execute_mock_mpc).  prefetch_triples is called by batch_mul; a source that throws when asked ahead
+    // of need (exhausted) is asked again when the triples are really requested.
+    void set_triple_prefetch(bool on) { if (!on && pending_) throw std::logic_error("triples have been read ahead already"); prefetch_ = on; }
+    bool triple_prefetch() const { return prefetch_; }
+    void prefetch_triples(size_t n);
     AuthenticatedScalarBatch random_shared_scalars(size_t n);                                    // fabric.rs:917-928
     AuthenticatedScalarBatch random_shared_bits(size_t n);                                       // fabric.rs:961-984
     void random_inverse_pairs(size_t n, AuthenticatedScalarBatch& l, AuthenticatedScalarBatch& r);  // fabric.rs:942-958
@@ -682,6 +743,11 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     Scalar mac_key_;
     bool wire_ = false;
     std::vector<AuthenticatedScalarBatch> const_triple_;     // the constant source's (a, b, c) records, shared by every broadcast triple batch
+    struct TripleFetch;                                       // n triples on their way to the GPU (or there already)
+    std::shared_ptr<TripleFetch> fetch_triples(size_t n);
+    void land(TripleFetch& t);
+    std::shared_ptr<TripleFetch> pending_;                    // read ahead of need by prefetch_triples
+    bool prefetch_ = true;
     int share_layout_ = ARKMPC_LAYOUT_SPLIT;
     LinkMode link_ = LinkMode::Host;
     uint64_t next_id_ = 6;   // N_CONSTANT_RESULTS (fabric.rs:55-70)
@@ -797,9 +863,11 @@ class AuthenticatedScalarBatch {
             // in the round's dependent chain); ids and ordering as exchange_values
             auto msg = std::make_shared<DeviceBuf>(f->engine(), ARKMPC_KIND_SCALAR, 2 * n);
             check(f->ctx(), arkmpc_beaver_mask_dup(f->ctx(), n, a.s(), a.st(), b.s(), b.st(), ta.s(), ta.st(), tb.s(), tb.st(), my_de.buf.ptr(), msg->ptr()), "beaver_mask");
+            f->prefetch_triples(n);                                                           // the next gate's triples start on their way under this gate's round
             peer_de = f->exchange_device_owned(std::move(msg), 8 * n, 2 * n);
         } else {
             check(f->ctx(), arkmpc_beaver_mask_v(f->ctx(), n, a.s(), a.st(), b.s(), b.st(), ta.s(), ta.st(), tb.s(), tb.st(), my_de.buf.ptr()), "beaver_mask");
+            f->prefetch_triples(n);
             peer_de = f->exchange_values(my_de);                                              // the one network round (length-checked: 2n)
         }
         auto r = alloc(f, n);                                                                 // combine (:161-171) + de + d[b] + e[a] + [c] (:871-878)
@@ -1176,6 +1244,12 @@ inline AuthenticatedScalarBatch MpcFabric::fill_scalar_shares(const ScalarShare&
 }
 inline AuthenticatedScalarBatch MpcFabric::zeros_authenticated(size_t n) { return fill_scalar_shares(ScalarShare{Scalar{{0, 0, 0, 0}}, Scalar{{0, 0, 0, 0}}}, n); }
 inline AuthenticatedScalarBatch MpcFabric::ones_authenticated(size_t n) { return fill_scalar_shares(ScalarShare{eng_->from_u64(party_), mac_key_}, n); }
+struct MpcFabric::TripleFetch {
+    size_t n = 0;
+    std::vector<ScalarShare> h[3];                           // the source's Vecs, alive until the import has read them (empty: lent in place)
+    AuthenticatedScalarBatch t[3];
+    bool landed = false;
+};
 inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c, bool broadcast_ok) {
     ScalarShare ca, cb, cc;
     if (prep_->constant_triplet(ca, cb, cc)) {
@@ -1196,11 +1270,81 @@ inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, 
         a = fill_scalar_shares(ca, n); b = fill_scalar_shares(cb, n); c = fill_scalar_shares(cc, n);
         return;
     }
-    std::vector<ScalarShare> ha, hb, hc;
-    prep_->next_triplet_batch(n, ha, hb, hc);
-    if (ha.size() != n || hb.size() != n || hc.size() != n) throw std::runtime_error("preprocessing exhausted");   // structs.rs:189 asserts
+    AuthenticatedScalarBatch* out[3] = {&a, &b, &c};
+    if (pending_ && pending_->n != n) {
+        // a request of another size than what was read ahead: the source is a FIFO, so serve from the read-ahead triples first, in order
+        std::shared_ptr<TripleFetch> p = std::move(pending_);
+        pending_.reset();
+        land(*p);
+        if (n < p->n) {
+            auto rest = std::make_shared<TripleFetch>();
+            rest->n = p->n - n;
+            for (int k = 0; k < 3; ++k) { *out[k] = p->t[k].slice(0, n); rest->t[k] = p->t[k].slice(n, p->n - n); rest->t[k].fabric.reset(); }
+            pending_ = std::move(rest);
+        } else {
+            std::shared_ptr<TripleFetch> more = fetch_triples(n - p->n);
+            land(*more);
+            for (int k = 0; k < 3; ++k) {
+                AuthenticatedScalarBatch r = AuthenticatedScalarBatch::alloc(shared_from_this(), n);
+                const AuthenticatedScalarBatch* part[2] = {&p->t[k], &more->t[k]};
+                size_t lo = 0;
+                for (const AuthenticatedScalarBatch* q : part) {
+                    if (!q->n) continue;
+                    if (r.split()) {
+                        check(ctx(), arkmpc_memcpy_d2d(ctx(), r.s() + 4 * lo, q->s(), q->n * 32), "d2d");
+                        check(ctx(), arkmpc_memcpy_d2d(ctx(), r.m() + 4 * lo, q->m(), q->n * 32), "d2d");
+                    } else check(ctx(), arkmpc_memcpy_d2d(ctx(), r.s() + 8 * lo, q->s(), q->n * 64), "d2d");
+                    lo += q->n;
+                }
+                *out[k] = std::move(r);
+            }
+        }
+        next_id_ += 3 * n;
+        return;
+    }
+    std::shared_ptr<TripleFetch> t = pending_ ? std::move(pending_) : fetch_triples(n);
+    pending_.reset();
+    land(*t);
     next_id_ += 3 * n;
-    a = allocate_scalar_shares(ha); b = allocate_scalar_shares(hb); c = allocate_scalar_shares(hc);
+    for (int k = 0; k < 3; ++k) *out[k] = std::move(t->t[k]);
+}
+// n triples from the source, started on their way to the GPU; returns at once for vectors that can go up asynchronously
+inline std::shared_ptr<MpcFabric::TripleFetch> MpcFabric::fetch_triples(size_t n) {
+    auto f = std::make_shared<TripleFetch>();
+    f->n = n;
+    const ScalarShare* p[3] = {nullptr, nullptr, nullptr};
+    if (!prep_->borrow_triplet_batch(n, &p[0], &p[1], &p[2])) {
+        prep_->next_triplet_batch(n, f->h[0], f->h[1], f->h[2]);
+        for (int k = 0; k < 3; ++k) {
+            if (f->h[k].size() != n) throw std::runtime_error("preprocessing exhausted");   // structs.rs:189 asserts
+            p[k] = f->h[k].data();
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        arkmpc_batch* b = nullptr;
+        check(ctx(), arkmpc_batch_from_host_async(ctx(), ARKMPC_KIND_SCALAR_SHARE, share_layout_, n, p[k], &b), "batch_from_host_async");
+        f->t[k].n = n;
+        f->t[k].buf = DeviceBuf::adopt(eng_, b);             // (no fabric pointer while the fetch may be parked in pending_: no cycle fabric -> batch -> fabric)
+    }
+    return f;
+}
+// the compute stream waits for the imports; the source's memory is released (blocks until the uploads have read it -- long done for triples
+// that were read ahead a gate ago)
+inline void MpcFabric::land(TripleFetch& t) {
+    if (t.landed) return;
+    for (int k = 0; k < 3; ++k) {
+        check(ctx(), arkmpc_batch_acquire(ctx(), t.t[k].buf.handle()), "batch_acquire");
+        check(ctx(), arkmpc_batch_host_release(ctx(), t.t[k].buf.handle()), "batch_host_release");
+        t.t[k].fabric = shared_from_this();
+        std::vector<ScalarShare>().swap(t.h[k]);
+    }
+    t.landed = true;
+}
+inline void MpcFabric::prefetch_triples(size_t n) {
+    if (!prefetch_ || pending_ || !n) return;
+    ScalarShare ca, cb, cc;
+    if (prep_->constant_triplet(ca, cb, cc)) return;         // constant sources are one record on the GPU already
+    try { pending_ = fetch_triples(n); } catch (const std::exception&) { pending_.reset(); }
 }
 inline void MpcFabric::random_inverse_pairs(size_t n, AuthenticatedScalarBatch& l, AuthenticatedScalarBatch& r) {
     std::vector<ScalarShare> hl, hr;
@@ -1296,6 +1440,7 @@ struct ShardedShares {              // Vec<AuthenticatedScalarResult<C>> range-s
 class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
   public:
     GroupFabric(std::shared_ptr<MpcFabric> fabric, const std::vector<int>& device_ids) : f_(std::move(fabric)) {
+        f_->set_triple_prefetch(false);                      // this fabric's triples are taken as host vectors (next_triple_host): no reading ahead into ONE device's HBM
         if (arkmpc_group_create(f_->engine()->field_id(), (int)device_ids.size(), device_ids.data(), &g_) != ARKMPC_OK)
             throw std::runtime_error("arkmpc_group_create failed: the engine needs GPUs, there is no CPU fallback");
     }
@@ -1344,6 +1489,29 @@ class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
         gcheck(arkmpc_group_beaver_finish_fused(g_, layout(), n, (int)f_->party_id(), f_->mac_key().l, my_de.cptrs(), peer_de.cptrs(), ta.buf.cptrs(),
                                                 tb.buf.cptrs(), tc.buf.cptrs(), r.buf.ptrs()), "group_beaver_finish_fused");
         return r;                                             // the temporaries' frees are stream-ordered per member (arkmpc_free): no synchronisation
+    }
+    // Beaver multiplication of HOST vectors over the group (authenticated_scalar.rs:848-879 in the shape benches/batch_ops.rs:19-39 times: host
+    // values in, host values out): a streaming session over the group (arkmpc_group_hostmul_*) -- every member runs its range of the same
+    // vectors over its own PCIe link, the vectors are pinned once per call (not at all if the caller allocated them pinned), and the d||e
+    // payload is a host vector where the network picks it up.  The triples come from the source as host vectors, or are lent in place.
+    std::vector<ScalarShare> batch_mul_host(const std::vector<ScalarShare>& x, const std::vector<ScalarShare>& y) {
+        if (x.size() != y.size()) throw std::invalid_argument("Cannot operate on batches of different sizes");
+        const size_t n = x.size();
+        if (n == 0) return {};
+        std::vector<ScalarShare> ha, hb, hc;
+        f_->next_triple_host(n, ha, hb, hc);
+        std::vector<Scalar> my_de(2 * n);
+        arkmpc_group_hostmul* s = nullptr;
+        gcheck(arkmpc_group_hostmul_begin(g_, n, &x[0].share.l[0], &y[0].share.l[0], &ha[0].share.l[0], &hb[0].share.l[0], &hc[0].share.l[0], &my_de[0].l[0], &s),
+               "group_hostmul_begin");
+        std::vector<Scalar> peer;
+        try {
+            gcheck(arkmpc_group_hostmul_wait_de(s), "group_hostmul_wait_de");
+            peer = f_->exchange_host_values(std::move(my_de));      // (the session's pin on my_de ended with _wait_de: the vector may move into the message)
+        } catch (...) { arkmpc_group_hostmul_abort(s); throw; }
+        std::vector<ScalarShare> out(n);
+        gcheck(arkmpc_group_hostmul_finish(s, (int)f_->party_id(), f_->mac_key().l, &peer[0].l[0], &out[0].share.l[0]), "group_hostmul_finish");
+        return out;
     }
     // open_authenticated_batch over the group (:278-354): opening, MAC-check shares, commit, three exchanges, verification
     GroupOpenResult open_authenticated_batch(const ShardedShares& x, const Scalar& blinder) {
@@ -1420,6 +1588,7 @@ std::pair<T, T> execute_mock_mpc(int field_id, int device,
             MpcNetwork* raw = net.get();
             auto fab = std::make_shared<MpcFabric>(p, eng, std::move(net), make_prep(p, *eng));
             if (const char* w = std::getenv("ARKMPC_MOCK_WIRE")) fab->set_wire_frames(w[0] == '1');
+            if (const char* tp = std::getenv("ARKMPC_TRIPLE_PREFETCH")) fab->set_triple_prefetch(tp[0] != '0');
             if (const char* sl = std::getenv("ARKMPC_SHARE_LAYOUT")) fab->set_share_layout(std::string(sl) == "aos" ? ARKMPC_LAYOUT_AOS : ARKMPC_LAYOUT_SPLIT);
             if (const char* l = std::getenv("ARKMPC_MOCK_LINK")) {            // host | device | wire
                 const std::string v = l;

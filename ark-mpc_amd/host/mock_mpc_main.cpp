@@ -109,9 +109,15 @@ int main(int argc, char** argv) {
         // ARKMPC_MOCK_DEALER=<seed>: a trusted-dealer source with random MAC key shares and triples instead of the reference's constant dummy source
         const char* dealer = std::getenv("ARKMPC_MOCK_DEALER");
         const uint64_t dealer_seed = dealer ? std::strtoull(dealer, nullptr, 0) : 0;
+        // ARKMPC_MOCK_VECTOR_TRIPLES=<count>: the triples are drawn from that source up front into pinned host memory and lent to the fabric in
+        // place, gate after gate (VectorBeaverSource: what a real offline phase's output looks like to this engine)
+        const char* vec = std::getenv("ARKMPC_MOCK_VECTOR_TRIPLES");
+        const size_t vec_cap = vec ? std::strtoull(vec, nullptr, 0) : 0;
         auto make_prep = [&](PartyId p, const Engine& e) {
-            return dealer ? std::unique_ptr<PreprocessingPhase>(new DealerBeaverSource(p, e, dealer_seed))
-                          : std::unique_ptr<PreprocessingPhase>(new PartyIDBeaverSource(p, e));
+            std::unique_ptr<PreprocessingPhase> src = dealer ? std::unique_ptr<PreprocessingPhase>(new DealerBeaverSource(p, e, dealer_seed))
+                                                             : std::unique_ptr<PreprocessingPhase>(new PartyIDBeaverSource(p, e));
+            if (vec) return std::unique_ptr<PreprocessingPhase>(new VectorBeaverSource(std::move(src), vec_cap));
+            return src;
         };
         auto program = [&](std::shared_ptr<MpcFabric> fabric) -> PartyOut {
             const Engine& eng = *fabric->engine();
@@ -187,6 +193,39 @@ int main(int argc, char** argv) {
                     sq = gf->shares_from_host(h);
                 }
                 GroupOpenResult o = gf->open_authenticated_batch(sq, blinder);
+                PartyOut out;
+                out.err = (o.err == MpcError::None) ? 0 : 2;
+                if (n) out.opened = eng.to_canonical(o.value);
+                return out;
+            } else if (scenario == "chain") {
+                // a depth-4 chain of dependent gates on resident operands, z <- z * b, then a gate of ANOTHER size on a slice (served from the
+                // read-ahead triples, in order) and one more of the full size: every gate pulls fresh triples from the source (read ahead by one
+                // gate unless ARKMPC_TRIPLE_PREFETCH=0); opens to 2 a b^5 (tests/test_host_fabric.py)
+                auto z = fabric->batch_share_scalar(a_m, n, PARTY0);
+                auto b = fabric->batch_share_scalar(b_m, n, PARTY1);
+                for (int k = 0; k < 4; ++k) z = AuthenticatedScalarBatch::batch_mul(z, b);
+                const size_t h = n / 2;
+                auto zh = AuthenticatedScalarBatch::batch_mul(z.slice(0, h), b.slice(0, h));             // a smaller request
+                auto zf = AuthenticatedScalarBatch::batch_mul(z, b);                                     // a larger one than what is left of the read-ahead
+                res = AuthenticatedScalarBatch::batch_add(zf, zf);
+                if (h) {
+                    auto fix = AuthenticatedScalarBatch::batch_sub(zh, zf.slice(0, h));                  // zh == zf on the first half: adds zero there
+                    std::vector<ScalarShare> add = fix.to_host(), all(n, ScalarShare{Scalar{{0, 0, 0, 0}}, Scalar{{0, 0, 0, 0}}});
+                    std::copy(add.begin(), add.end(), all.begin());
+                    res = AuthenticatedScalarBatch::batch_add(res, fabric->allocate_scalar_shares(all));
+                }
+            } else if (scenario == "group_mul_host") {
+                // GroupFabric::batch_mul_host: host records in, host records out, a streaming session over the group's members; then the
+                // authenticated opening of the product on the sharded path
+                std::vector<int> devs;
+                const char* gd = std::getenv("ARKMPC_GROUP_DEVICES");
+                for (std::string t = gd ? gd : "0,0,0"; !t.empty();) { const size_t c = t.find(','); devs.push_back(std::atoi(t.substr(0, c).c_str())); t = c == std::string::npos ? "" : t.substr(c + 1); }
+                std::vector<ScalarShare> ha = fabric->batch_share_scalar(a_m, n, PARTY0).to_host(), hb = fabric->batch_share_scalar(b_m, n, PARTY1).to_host();
+                auto gf = std::make_shared<GroupFabric>(fabric, devs);
+                std::vector<ScalarShare> prod = gf->batch_mul_host(ha, hb);
+                std::vector<ScalarShare> sq = gf->batch_mul_host(prod, prod);
+                if (fabric->party_id() == PARTY0 && n && (bad_mac || bad_share)) (bad_mac ? sq[n - 1].mac : sq[n - 1].share) = eng.from_u64(42);
+                GroupOpenResult o = gf->open_authenticated_batch(gf->shares_from_host(sq), blinder);
                 PartyOut out;
                 out.err = (o.err == MpcError::None) ? 0 : 2;
                 if (n) out.opened = eng.to_canonical(o.value);

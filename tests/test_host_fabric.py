@@ -422,3 +422,63 @@ def test_point_protocols_with_random_preprocessing(tmp_path, dealer_source, fid)
     want = comp(sum(u * v for u, v in zip(x, y)) % l)
     for nfail, got in _run_points(tmp_path, "msm", fid, x, y):
         assert nfail == 0 and got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prefetch", ["1", "0"])
+@pytest.mark.parametrize("source", ["vector_lent_in_place", "dealer_vecs"])
+def test_chain_of_gates_with_triples_read_ahead(tmp_path, dealer_source, prefetch, source):
+    """Six dependent Beaver gates on resident operands, every gate on fresh random triples from a host-memory source (fabric.rs:894-915,
+    offline_prep.rs:65-81) -- not the dummy source's one-record shortcut.  The triples go up asynchronously and, with prefetch on, one gate ahead
+    of their use; a gate of another size (half, then full again) is served from what was read ahead, in FIFO order.  n is large enough for
+    the vectors to be pinned in place and imported by the in-place kernel.  Both parties open 2 a b^5 with valid MACs."""
+    fid, n = 0, 20000
+    p = pyref.P[fid]
+    a, b = mixed_values(fid, n, 901), rand_values(fid, n, 902)
+    os.environ["ARKMPC_TRIPLE_PREFETCH"] = prefetch
+    if source == "vector_lent_in_place":
+        os.environ["ARKMPC_MOCK_VECTOR_TRIPLES"] = str(6 * n)
+    try:
+        res = run(tmp_path, "chain", fid, a, b)
+        want = [(2 * x * pow(y, 5, p)) % p for x, y in zip(a, b)]
+        assert res[0] == (0, want) and res[1] == (0, want)
+        res = run(tmp_path, "chain", fid, a, b, "--bad-mac")
+        assert res[0][0] == 2 and res[1][0] == 2
+    finally:
+        os.environ.pop("ARKMPC_TRIPLE_PREFETCH", None)
+        os.environ.pop("ARKMPC_MOCK_VECTOR_TRIPLES", None)
+
+
+@pytest.mark.gpu
+def test_vector_source_running_out_is_an_error_not_a_short_batch(tmp_path, dealer_source):
+    """LowGearPrep asserts when it runs out (offline-phase/src/structs.rs:189); reading ahead must not turn that into a silent short batch nor
+    fire before the triples are really needed: 5.5 n are needed, 5.5 n - 1 are there"""
+    fid, n = 0, 2000
+    a, b = mixed_values(fid, n, 903), rand_values(fid, n, 904)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(ints_to_limbs(a).tobytes() + ints_to_limbs(b).tobytes())
+    for cap, ok in ((5 * n + n // 2, True), (5 * n + n // 2 - 1, False)):
+        env = dict(os.environ, ARKMPC_MOCK_VECTOR_TRIPLES=str(cap))
+        r = subprocess.run([EXE, "chain", str(fid), str(n), str(inp), str(outp)], capture_output=True, text=True, timeout=300, env=env)
+        assert (r.returncode == 0) == ok, r.stderr
+        if not ok:
+            assert "preprocessing exhausted" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,n", [("0,0,0", 20011), ("0,0,0,0,0,0,0,0", 5), ("0", 257)])
+def test_group_fabric_host_vectors_through_group_sessions(tmp_path, dealer_source, devices, n):
+    """GroupFabric::batch_mul_host: host records in, host records out through arkmpc_group_hostmul_* (one range session per member), two
+    dependent gates, then the authenticated opening on the sharded path: (x y)^2 on both sides; a corrupted last element is detected"""
+    fid = 0
+    p = pyref.P[fid]
+    a, b = mixed_values(fid, n, 905), rand_values(fid, n, 906)
+    os.environ["ARKMPC_GROUP_DEVICES"] = devices
+    try:
+        res = run(tmp_path, "group_mul_host", fid, a, b)
+        want = [pow(x * y, 2, p) for x, y in zip(a, b)]
+        assert res[0] == (0, want) and res[1] == (0, want)
+        res = run(tmp_path, "group_mul_host", fid, a, b, "--bad-share")
+        assert res[0][0] == 2 and res[1][0] == 2
+    finally:
+        os.environ.pop("ARKMPC_GROUP_DEVICES", None)
