@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--total-log2n", type=int, default=24, help="--scaling strong: total gates per step over all GPUs")
     ap.add_argument("--only-e2e", action="store_true", help="run only the end-to-end (host records in, host records out) leg and print its JSON")
     ap.add_argument("--e2e-log2n", type=int, default=20, help="gates per party of the end-to-end leg")
+    ap.add_argument("--only-circuit", action="store_true", help="run only the circuit leg (resident operands, triples from host memory) and print its JSON")
+    ap.add_argument("--circuit-log2n", type=int, default=20, help="gates per batch_mul of the circuit leg")
+    ap.add_argument("--circuit-depth", type=int, default=8, help="dependent gates in the circuit leg's chain")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the timed ordered all-gather of opened-value buffers (config 5 shape, 64 MiB per rank)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for launch-path tests)")
     ap.add_argument("--sets", type=int, default=2, help="independent workload sets rotated step by step, so that no input line of step s "
@@ -210,10 +213,39 @@ def check_results(eng, n, parties, truth, layout):
     return bool(torch.equal(opened, prod)) and bool(torch.equal(mac, kprod))
 
 
+def host_description():
+    """nproc, CPU model, compiler and flags beside the CPU figure; step 1: the cargo probe"""
+    import shutil, subprocess
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    def first_line(cmd):
+        try:
+            return subprocess.run(cmd, capture_output=True, text=True, timeout=20).stdout.strip().splitlines()[0]
+        except Exception:            # noqa: BLE001
+            return None
+    flags = None
+    try:
+        for ln in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if ln.startswith("CFLAGS"):
+                flags = ln.split("=", 1)[1].strip(); break
+    except OSError:
+        pass
+    cargo = shutil.which("cargo")
+    return {"cpu_model": model, "nproc": os.cpu_count(), "compiler": first_line([os.environ.get("CC", "gcc"), "--version"]), "flags": flags,
+            "cargo_probe": (first_line(["cargo", "--version"]) or "present but not runnable") if cargo else "absent (`cargo` not on PATH): the reference's own "
+                           "`cargo bench --bench batch_ops` cannot run on this box; the CPU restatement below is timed instead (BASELINE.md section 3 steps 1-2)"}
+
+
 def cpu_baseline(parties, n, log2n_cpu, layout):
-    """The oracle's restatement of the reference's literal 9-pass batch_mul (both parties), timed on this host's
-    cores on the first 2^log2n_cpu gates of the same workload (kind = "port"): all cores via a static range split
-    in C (upper bound for the reference's rayon executor) and one thread (its default single executor thread)."""
+    """the oracle's restatement of the reference's batch_mul (both parties) timed on this host's cores on the first
+    2^log2n_cpu gates of the same workload (kind = "port"), in BOTH forms the plan names -- the literal nine passes (authenticated_scalar.rs:
+    848-879) and the fused single pass (:799-843 per element), so that the comparison is not hobbled by pass count -- each on all cores (static
+    range split in C: the upper bound for the reference's rayon executor) and on one thread (its default single executor thread)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api
     ora = oracle_api.load()
@@ -232,35 +264,47 @@ def cpu_baseline(parties, n, log2n_cpu, layout):
     de = [ora.beaver_mask(FID, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"]) for p in (0, 1)]   # the peers' d||e: untimed input
     res = [np.zeros(8 * m, dtype=np.uint64) for _ in (0, 1)]
     myde = [np.zeros(8 * m, dtype=np.uint64) for _ in (0, 1)]
-    fn = ora.lib.ora_batch_mul_9pass_mt
+    res_f = [np.zeros(8 * m, dtype=np.uint64) for _ in (0, 1)]
+    myde_f = [np.zeros(8 * m, dtype=np.uint64) for _ in (0, 1)]
     P = ora._p
 
-    def timed(nthreads):
+    def timed(fn, nthreads, o_de, o_res):
         t0 = time.perf_counter()
         for party in (0, 1):
             h = H[party]
             rc = fn(ctypes.c_int(FID), ctypes.c_size_t(m), ctypes.c_int(party), P(keys[party]), P(h["x"]), P(h["y"]), P(h["a"]), P(h["b"]),
-                    P(h["c"]), P(de[1 - party]), P(myde[party]), P(res[party]), ctypes.c_int(nthreads))
+                    P(h["c"]), P(de[1 - party]), P(o_de[party]), P(o_res[party]), ctypes.c_int(nthreads))
             assert rc == 0
         return time.perf_counter() - t0
 
-    timed(cores)  # warm
-    reps, tot = 0, 0.0
-    while tot < 6.0 and reps < 50:
-        tot += timed(cores); reps += 1
-    t_all = tot / reps
-    reps1, tot1 = 0, 0.0
-    while tot1 < 4.0 and reps1 < 10:
-        tot1 += timed(1); reps1 += 1
-    t_one = tot1 / reps1
+    def mean_time(fn, nthreads, o_de, o_res, budget_s, max_reps):
+        timed(fn, nthreads, o_de, o_res)  # warm
+        reps, tot = 0, 0.0
+        while tot < budget_s and reps < max_reps:
+            tot += timed(fn, nthreads, o_de, o_res); reps += 1
+        return tot / reps, reps
+
+    nine, fused = ora.lib.ora_batch_mul_9pass_mt, ora.lib.ora_batch_mul_fused_mt
+    t_all, reps = mean_time(nine, cores, myde, res, 4.0, 50)
+    t_one, reps1 = mean_time(nine, 1, myde, res, 3.0, 8)
+    tf_all, repsf = mean_time(fused, cores, myde_f, res_f, 3.0, 50)
+    tf_one, repsf1 = mean_time(fused, 1, myde_f, res_f, 3.0, 8)
     assert np.array_equal(myde[0], de[0]) and np.array_equal(myde[1], de[1])
-    return {
+    same = all(np.array_equal(myde_f[p], myde[p]) and np.array_equal(res_f[p], res[p]) for p in (0, 1))
+    assert same, "the fused CPU form disagrees with the nine passes"
+    return dict({
         "value": m / t_all, "unit": "gates/s", "cores": cores, "kind": "port",
+        "label": "CPU restatement of reference algorithm (not ark-mpc measured)",
         "sample": "first 2^%d gates of the same seeded workload, both parties, the reference's literal 9-pass batch_mul "
-                  "(oracle/ark_oracle.c ora_batch_mul_9pass_mt, gcc -O3), %d pthreads static range split, mean of %d runs; "
-                  "single_thread_value = 1 thread, mean of %d runs" % (int(np.log2(m)), cores, reps, reps1),
+                  "(oracle/ark_oracle.c ora_batch_mul_9pass_mt), %d pthreads static range split, mean of %d runs; "
+                  "single_thread_value = 1 thread, mean of %d runs; fused_single_pass = the single-gate Mul's closure per element in one sweep "
+                  "(ora_batch_mul_fused_mt, authenticated_scalar.rs:799-843), %d / %d runs" % (int(np.log2(m)), cores, reps, reps1, repsf, repsf1),
         "single_thread_value": m / t_one,
-    }, res, myde, m
+        "fused_single_pass": {"value": m / tf_all, "single_thread_value": m / tf_one, "unit": "gates/s", "cores": cores,
+                              "same_words_as_nine_passes": bool(same)},
+        "excludes": "the reference's DAG-executor overhead (13n+2 result slots per batch_mul, per-argument ResultValue clones, single_threaded.rs:322-356): "
+                    "an optimistic stand-in for the reference, i.e. a conservative speed-up denominator (BASELINE.md section 3 step 3)",
+    }, **host_description()), res, myde, m
 
 
 def run_pipeline(eng, n, sets, layout, args, steps, warmup, barrier, settle_ms=None, rounds=1):
@@ -911,6 +955,195 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
                              % (log2n, "ALL of them" if m == n else "the first 2^%d gates" % int(np.log2(m)), exact, 2 * m, "ok" if ok else "FAILED")}, ok
 
 
+def _pinned_array(lib, nwords):
+    """a numpy u64 array over an arkmpc_host_alloc block (pinned, recycled); returns (array, pointer)"""
+    q = ctypes.c_void_p()
+    if lib.arkmpc_host_alloc(ctypes.c_size_t(8 * nwords), ctypes.byref(q)) != 0:
+        raise RuntimeError("arkmpc_host_alloc(%d bytes)" % (8 * nwords))
+    return np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ctypes.c_uint64)), shape=(nwords,)), q
+
+
+def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
+    """A circuit whose operands are RESIDENT and whose triples are not: a chain of `depth` dependent batch_mul gates z <- z * y at 2^log2n gates,
+    both parties in-process on this GPU, d||e handed over in HBM (the mock's device link), every gate on FRESH random triples that lie in host
+    memory as a PreprocessingPhase hands them over (fabric.rs:894-915 next_triple_batch, offline_prep.rs:65-81) -- not the dummy source's
+    one-record shortcut.  192 B of triples per party-gate must cross the host link, which bounds the circuit whatever the kernels do (at 56 GB/s:
+    2.9e8 party-gates/s per GPU).  Measured: the product path (arkmpc_batch_from_host_async: in-place import kernel for split columns, gate k+1's
+    triples going up behind gate k), the same from pageable vectors (pinned in place per gate), the round-4 path (blocking copy + split pass per
+    triple vector, nothing overlapped), and the streaming session with resident operands (x, y and the result in HBM, triples read in place).
+    Every gate's d||e and result of both parties is compared with the oracle."""
+    lib = pkg.load_library()
+    n = 1 << log2n
+    cal = pcie_calibration()
+    first, truth = build_workload(eng, n, seed=0xA11CE0C0, layout="aos")
+    keys = [p.key for p in first]
+    S = eng.SCALAR_SHARE
+    hold = []                                                   # pinned blocks to give back
+
+    def to_pinned(t):
+        arr, q = _pinned_array(lib, 8 * n)
+        arr[:] = t.cpu().numpy().view(np.uint64)
+        hold.append(q)
+        return arr
+
+    trip = []                                                   # trip[k][p] = {"a","b","c"} pinned host record vectors
+    for k in range(depth):
+        ps = first if k == 0 else build_workload(eng, n, seed=0xA11CE0C0 + 101 * k, layout="aos", key_shares=keys)[0]
+        trip.append([{nm: to_pinned(getattr(ps[p], nm)) for nm in "abc"} for p in (0, 1)])
+    hx = [first[p].x.cpu().numpy().view(np.uint64).copy() for p in (0, 1)]
+    hy = [first[p].y.cpu().numpy().view(np.uint64).copy() for p in (0, 1)]
+    x_aos = [first[p].x for p in (0, 1)]
+    y_aos = [first[p].y for p in (0, 1)]
+    del truth
+    # resident operands in split columns
+    def split_of(t):
+        o = torch.empty_like(t)
+        eng.share_split(n, t, o[:4 * n], o[4 * n:])
+        return o
+    x_sp = [split_of(x_aos[p]) for p in (0, 1)]
+    y_sp = [split_of(y_aos[p]) for p in (0, 1)]
+    z = [[torch.empty(8 * n, dtype=torch.int64, device="cuda") for _ in range(depth)] for _ in (0, 1)]      # every gate's output stays resident for the check
+    de = [[torch.empty(8 * n, dtype=torch.int64, device="cuda") for _ in range(depth)] for _ in (0, 1)]
+    P = lambda t: t.data_ptr()
+    col = 32 * n                                                # byte offset of the MAC column
+
+    def run_batches(source, asynchronous, prefetch):
+        """source(k, p) -> {"a","b","c"} host vectors of gate k"""
+        def imp(k, p):
+            return [eng.batch_from_host(S, eng.SPLIT, n, source(k, p)[nm], asynchronous=asynchronous) for nm in "abc"]
+        t0 = time.perf_counter()
+        nxt = [imp(0, p) for p in (0, 1)]
+        for k in range(depth):
+            tri = nxt
+            zin = x_sp if k == 0 else [z[0][k - 1], z[1][k - 1]]
+            ptr = [[eng.batch_ptrs(b) for b in tri[p]] for p in (0, 1)]
+            for p in (0, 1):
+                for b in tri[p]:
+                    eng.batch_acquire(b)
+                (as_, am, st), (bs, bm, _), _c = ptr[p]
+                eng.beaver_mask_v(n, P(zin[p]), 4, P(y_sp[p]), 4, as_, st, bs, st, de[p][k])
+            if prefetch and k + 1 < depth:
+                nxt = [imp(k + 1, p) for p in (0, 1)]           # gate k+1's triples start on their way under gate k
+            for p in (0, 1):
+                (as_, am, st), (bs, bm, _), (cs, cm, _) = ptr[p]
+                eng.beaver_finish_fused_v(n, p, keys[p], de[p][k], de[1 - p][k], as_, am, st, bs, bm, st, cs, cm, st, P(z[p][k]), P(z[p][k]) + col, 4)
+            for p in (0, 1):
+                for b in tri[p]:
+                    eng.batch_host_release(b); eng.batch_destroy(b)
+            if not prefetch and k + 1 < depth:
+                nxt = [imp(k + 1, p) for p in (0, 1)]
+        eng.sync()
+        return time.perf_counter() - t0
+
+    def run_sessions():
+        """the streaming session as a circuit gate: x, y, the payloads and the result resident (AoS records), a, b, c read in place over the link"""
+        t0 = time.perf_counter()
+        for k in range(depth):
+            zin = x_aos if k == 0 else [zs[0][k - 1], zs[1][k - 1]]
+            ses = [eng.hostmul_begin_range(n, zin[p], y_aos[p], trip[k][p]["a"], trip[k][p]["b"], trip[k][p]["c"], des[p][k], P(des[p][k]) + 32 * n) for p in (0, 1)]
+            for p in (0, 1):
+                eng.hostmul_finish_async(ses[p], p, keys[p], des[1 - p][k], P(des[1 - p][k]) + 32 * n, zs[p][k])
+            for p in (0, 1):
+                eng.hostmul_end(ses[p])
+        eng.sync()
+        return time.perf_counter() - t0
+
+    pinned_src = lambda k, p: trip[k][p]
+
+    def run_pageable():                                         # NEW pageable vectors for every gate (numpy / Vec memory), made before the clock starts
+        fresh = {(k, p): {nm: trip[k][p][nm].copy() for nm in "abc"} for k in range(depth) for p in (0, 1)}
+        return run_batches(lambda k, p: fresh[(k, p)], True, True)
+
+    up_bytes = 192 * 2 * n * depth
+    floor_ms = up_bytes / cal["h2d_GBps"] / 1e6
+    modes = {}
+    ok = True
+
+    def record(name, what, fn, reps=3):
+        fn()                                                    # warm (pool blocks, events)
+        ts = [fn() for _ in range(reps)]
+        t = float(np.median(ts))
+        modes[name] = {"what": what, "ms": t * 1e3, "ms_per_gate": t * 1e3 / depth, "party_gates_per_s": 2 * n * depth / t,
+                       "triple_GBps_over_the_link": up_bytes / t / 1e9, "frac_of_link_floor": floor_ms / (t * 1e3)}
+
+    # the oracle's chain on the same host data (first m gates of every batch; the chain is elementwise)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    ora = oracle_api.load()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    m = n if cores >= 16 else min(n, 1 << 16)
+    sl8 = lambda a_: np.ascontiguousarray(a_[:8 * m])
+    want_de, want_z = [[], []], [[], []]
+    zc = [sl8(hx[0]), sl8(hx[1])]
+    for k in range(depth):
+        T = [{nm: sl8(trip[k][p][nm]) for nm in "abc"} for p in (0, 1)]
+        ode = [ora.beaver_mask_mt(FID, zc[p], sl8(hy[p]), T[p]["a"], T[p]["b"]) for p in (0, 1)]
+        nz = []
+        for p in (0, 1):
+            my_de, w = ora.batch_mul_9pass_mt(FID, p, keys[p], zc[p], sl8(hy[p]), T[p]["a"], T[p]["b"], T[p]["c"], ode[1 - p])
+            want_de[p].append(my_de); want_z[p].append(w); nz.append(w)
+        zc = nz
+
+    def exact_split(zbuf, debuf):
+        good = 0
+        for k in range(depth):
+            for p in (0, 1):
+                o = zbuf[p][k].cpu().numpy().view(np.uint64)
+                got = np.concatenate([o[:4 * m].reshape(m, 4), o[4 * n:4 * n + 4 * m].reshape(m, 4)], axis=1)
+                d_ = debuf[p][k].cpu().numpy().view(np.uint64)
+                g = (got == want_z[p][k].reshape(m, 8)).all(axis=1)
+                g &= (d_[:4 * m].reshape(m, 4) == want_de[p][k][:4 * m].reshape(m, 4)).all(axis=1) & (d_[4 * n:4 * n + 4 * m].reshape(m, 4) == want_de[p][k][4 * m:].reshape(m, 4)).all(axis=1)
+                good += int(g.sum())
+        return good
+
+    def wipe(bufs):
+        for row in bufs:
+            for t_ in row:
+                t_.zero_()
+
+    total = 2 * depth * m
+    st0 = eng.stats()
+    record("prefetched_async", "arkmpc_batch_from_host_async from pinned vectors (arkmpc_host_alloc: what a source that keeps its triples for this engine hands over): "
+           "k_import_split reads the records in place over the link and writes the columns; gate k+1's imports are issued after gate k's K1", lambda: run_batches(pinned_src, True, True))
+    st1 = eng.stats()
+    ex_a = exact_split(z, de); wipe(z); wipe(de)
+    record("async_no_prefetch", "the same imports issued only when the gate needs them (ARKMPC_TRIPLE_PREFETCH=0 in the host mirror)", lambda: run_batches(pinned_src, True, False))
+    ex_b = exact_split(z, de); wipe(z); wipe(de)
+    record("pageable_async", "the same from NEW pageable vectors for every gate (numpy / Vec memory): pinned in place by the import (hipHostRegister), unpinned at release",
+           run_pageable)
+    ex_c = exact_split(z, de); wipe(z); wipe(de)
+    record("round4_blocking", "arkmpc_batch_from_host as it was: blocking copy on the compute stream into a staging block, then a split pass, three times per party-gate, "
+           "nothing overlapped", lambda: run_batches(pinned_src, False, False))
+    ex_d = exact_split(z, de)
+    async_imports = st1["batch_async_imports"] - st0["batch_async_imports"]
+    # sessions with resident operands (AoS records)
+    zs = [[torch.empty(8 * n, dtype=torch.int64, device="cuda") for _ in range(depth)] for _ in (0, 1)]
+    des = [[torch.empty(8 * n, dtype=torch.int64, device="cuda") for _ in range(depth)] for _ in (0, 1)]
+    record("sessions_resident_operands", "arkmpc_hostmul_begin_range / _finish_async with x, y, both payloads and the result RESIDENT (arkworks records in HBM) and a, b, c "
+           "read in place from pinned host memory by the phase kernels: no import pass and no staging, but no read-ahead either", run_sessions)
+    good = 0
+    for k in range(depth):
+        for p in (0, 1):
+            o = zs[p][k].cpu().numpy().view(np.uint64)[:8 * m].reshape(m, 8)
+            d_ = des[p][k].cpu().numpy().view(np.uint64)
+            g = (o == want_z[p][k].reshape(m, 8)).all(axis=1)
+            g &= (d_[:4 * m].reshape(m, 4) == want_de[p][k][:4 * m].reshape(m, 4)).all(axis=1) & (d_[4 * n:4 * n + 4 * m].reshape(m, 4) == want_de[p][k][4 * m:].reshape(m, 4)).all(axis=1)
+            good += int(g.sum())
+    ok = ex_a == total and ex_b == total and ex_c == total and ex_d == total and good == total and async_imports == 4 * 6 * depth
+    for q in hold:
+        lib.arkmpc_host_free(q)
+    best = modes["prefetched_async"]
+    return {"what": "depth-%d chain z <- z * y of batch_mul gates at 2^%d, operands resident (split columns), both parties on this ONE GPU and its one host link, d||e handed "
+                    "over in HBM, every gate on fresh random triples from host memory (192 B per party-gate over the link); wall clock from the first import to the last "
+                    "kernel, the first gate's triples NOT read ahead" % (depth, log2n),
+            "party_gates_per_s": best["party_gates_per_s"], "frac_of_link_floor": best["frac_of_link_floor"], "ms_per_gate_both_parties": best["ms_per_gate"],
+            "link_floor": {"bytes_up_per_party_gate": 192, "measured_h2d_GBps": cal["h2d_GBps"], "floor_ms": floor_ms, "floor_party_gates_per_s": cal["h2d_GBps"] * 1e9 / 192,
+                           "note": "both parties share this GPU's one link: per party-gate the floor is the same as for one party per GPU"},
+            "modes": modes, "speedup_over_round4_path": modes["round4_blocking"]["ms"] / best["ms"],
+            "results_check": "every gate of the chain, both parties, d||e and result records == oracle (%s of each batch; %d party-gates x 5 runs), and every import of the "
+                             "headline mode went up asynchronously (%d): %s" % ("ALL gates" if m == n else "the first 2^%d" % int(np.log2(m)), total, async_imports, "ok" if ok else "FAILED")}, ok
+
+
 def leg_gather(dist, world, rank, backend):
     """Ordered all-gather of the opened-value buffers in BASELINE config 5's shape: 2^24 / 8 = 2^21 scalars = 64 MiB per rank,
     straight into the final ordered buffer (sharding.gather_ordered, even shards -> all_gather_into_tensor, no pad / cat)."""
@@ -942,6 +1175,117 @@ def clock_effect():
     return None
 
 
+def leg_group_end_to_end(pkg, devs, log2n, reps=6):
+    """--single-process --only-e2e: the host-to-host path of leg_end_to_end for a party that owns SEVERAL GPUs and is ONE process
+    (fabric.rs:402-466), through the group sessions of the C ABI (arkmpc_group_hostmul_*): one set of host record vectors of n = G * 2^log2n
+    gates, member g running gates [g n/G, (g+1) n/G) over ITS device's PCIe link.  Host-fed a party is link-bound 20x below the kernels'
+    rate, so the links are what more GPUs add; this leg prints every member's link rate and their sum.  Sessions of the two parties alternate
+    (the peer's payload precomputed), vectors registered once by the caller, so both phases run as kernels on the vectors in place."""
+    G = len(devs)
+    per = 1 << log2n
+    n = per * G
+    torch.cuda.set_device(devs[0])
+    eng = pkg.Engine(FID, device=devs[0], host_buffers=False, stream=torch.cuda.current_stream().cuda_stream)
+    lib = pkg.load_library()
+    parties, truth = build_workload(eng, n, seed=0xA11CE0E5, layout="aos")
+    calls = prepare_step(eng, n, parties, "aos", chunks=max(1, n >> 20))
+    step(calls)
+    torch.cuda.synchronize()
+    host = lambda t: np.ascontiguousarray(t.cpu().numpy().view(np.uint64))
+    hold = []
+
+    def pinned(arr):
+        a_, q = _pinned_array(lib, arr.size)
+        a_[:] = arr
+        hold.append(q)
+        return a_
+
+    H = [{k: pinned(host(getattr(p, k))) for k in "xyabc"} for p in parties]
+    # (the device pipeline chunks d||e per 2^20 gates: rebuild the full d || e vectors)
+    chunks = max(1, n >> 20)
+    def full_de(t):
+        v = host(t).reshape(chunks, 2, n // chunks, 4)
+        return np.ascontiguousarray(np.concatenate([v[:, 0].reshape(-1), v[:, 1].reshape(-1)]))
+    want_de = [pinned(full_de(p.de)) for p in parties]
+    want_out = [host(p.out) for p in parties]
+    keys = [p.key for p in parties]
+    del parties, truth, calls
+    torch.cuda.empty_cache()
+    cal = pcie_calibration()
+    de = [pinned(np.zeros(8 * n, dtype=np.uint64)) for _ in (0, 1)]
+    out = [pinned(np.zeros(8 * n, dtype=np.uint64)) for _ in (0, 1)]
+    grp = pkg.Group(FID, devs)
+
+    def session(p, timers=None):
+        if timers is not None:
+            for m in range(G):
+                lib.arkmpc_kernel_timer_arm(grp.member_ctx(m), ctypes.c_int(timers))
+        s_ = grp.hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p])
+        grp.hostmul_wait_de(s_)
+        if timers is not None:
+            for m in range(G):
+                lib.arkmpc_kernel_timer_arm(grp.member_ctx(m), ctypes.c_int(timers + 1))
+        grp.hostmul_finish(s_, p, keys[p], want_de[1 - p], out[p])
+
+    session(0); session(1)
+    ok = all(np.array_equal(de[p], want_de[p]) and np.array_equal(out[p], want_out[p]) for p in (0, 1))
+    for p in (0, 1):
+        de[p].fill(0); out[p].fill(0)
+    ts = []
+    t0 = time.perf_counter()
+    for k in range(reps):
+        t_ = time.perf_counter(); session(k & 1); ts.append(time.perf_counter() - t_)
+    t = (time.perf_counter() - t0) / reps
+    ok = ok and all(np.array_equal(de[p], want_de[p]) and np.array_equal(out[p], want_out[p]) for p in (0, 1))
+    # one more session with the members' phase kernels timed (dispatch-bound HIP events on every member's context)
+    session(0, timers=0)
+    per_member = []
+    ms = ctypes.c_float(0)
+    single_launch = per <= (1 << 20)
+    for m in range(G):
+        lo, cnt = grp.shard_range(n, m)
+        row = {"member": m, "device": devs[m], "gates": cnt, "path": grp.member_stats(m)["hostmul_zero_copy_phases"]}
+        if single_launch:                                       # (a phase is one launch per 2^20 gates: the timer binds to the first)
+            lib.arkmpc_kernel_timer_ms(grp.member_ctx(m), ctypes.c_int(0), ctypes.byref(ms)); p1 = ms.value
+            lib.arkmpc_kernel_timer_ms(grp.member_ctx(m), ctypes.c_int(1), ctypes.byref(ms)); p2 = ms.value
+            row.update({"phase1_kernel_ms": p1, "phase2_kernel_ms": p2,
+                        "phase1_link_up_GBps": cnt * 256 / (p1 * 1e-3) / 1e9 if p1 > 0 else None,      # a, b, x, y records (only the share halves of x, y are used, but the link moves 64-byte reads)
+                        "phase2_link_up_GBps": cnt * 128 / (p2 * 1e-3) / 1e9 if p2 > 0 else None})     # c records + the peer's d||e
+        row["session_link_up_GBps"] = cnt * E2E_UP_BYTES / t / 1e9
+        per_member.append(row)
+    distinct = len(set(devs))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    ora = oracle_api.load()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    m_ = n if cores >= 16 else min(n, 1 << 16)
+    sl8 = lambda a_: np.ascontiguousarray(a_[:8 * m_])
+    ode = [ora.beaver_mask_mt(FID, sl8(H[p]["x"]), sl8(H[p]["y"]), sl8(H[p]["a"]), sl8(H[p]["b"])) for p in (0, 1)]
+    exact = 0
+    for p in (0, 1):
+        my_de, w = ora.batch_mul_9pass_mt(FID, p, keys[p], sl8(H[p]["x"]), sl8(H[p]["y"]), sl8(H[p]["a"]), sl8(H[p]["b"]), sl8(H[p]["c"]), ode[1 - p])
+        good = (out[p][:8 * m_].reshape(m_, 8) == w.reshape(m_, 8)).all(axis=1)
+        good &= (de[p][:4 * m_].reshape(m_, 4) == my_de[:4 * m_].reshape(m_, 4)).all(axis=1) & (de[p][4 * n:4 * n + 4 * m_].reshape(m_, 4) == my_de[4 * m_:].reshape(m_, 4)).all(axis=1)
+        exact += int(good.sum())
+    ok = ok and exact == 2 * m_
+    grp.close(); eng.close()
+    for q in hold:
+        lib.arkmpc_host_free(q)
+    res = {"what": "host arkworks records in -> host records out through ONE group session per batch_mul: n = %d x 2^%d gates per party, member g on gates [g n/G, (g+1) n/G) of the "
+                   "same host vectors over its own device's link (arkmpc_group_hostmul_*); vectors pinned by the caller, sessions of the two parties alternating back to back"
+                   % (G, log2n),
+           "members": G, "devices": devs, "distinct_devices": distinct, "oversubscribed": distinct < G,
+           "oversubscribed_note": ("the members share %d physical GPU(s) and therefore %d host link(s): the sum below is bounded by that, it is NOT an N-link measurement"
+                                   % (distinct, distinct)) if distinct < G else None,
+           "ms_per_session": t * 1e3, "ms_each_session": [round(x * 1e3, 3) for x in ts], "party_gates_per_s": n / t,
+           "link_up_GBps_sum_over_members": n * E2E_UP_BYTES / t / 1e9, "link_down_GBps_sum_over_members": n * E2E_DOWN_BYTES / t / 1e9,
+           "per_member": per_member, "measured_pcie_one_link": cal,
+           "frac_of_links": (n * E2E_UP_BYTES / t / 1e9) / (cal["h2d_GBps"] * distinct),
+           "results_check": "both parties' d||e and result records == the device-resident pipeline's on all %d gates, and == oracle on %s (%d of %d party-gates exact): %s"
+                            % (n, "ALL of them" if m_ == n else "the first 2^%d" % int(np.log2(m_)), exact, 2 * m_, "ok" if ok else "FAILED")}
+    return res, ok
+
+
 def main_single_process(args):
     """N GPUs, ONE process: the multi-device group of the C ABI (include/arkmpc.h arkmpc_group_*).  Each party is a group over the same
     devices; member g of both parties lives on device g and owns gates [g*n/G, (g+1)*n/G) of a step of n = G * 2^log2n gates (weak
@@ -954,6 +1298,12 @@ def main_single_process(args):
     if len(devs) != args.gpus:
         raise SystemExit("--devices must list --gpus ids")
     G = len(devs)
+    if args.only_e2e:
+        r, ok = leg_group_end_to_end(pkg, devs, args.e2e_log2n)
+        print(json.dumps(r), flush=True)
+        if not ok:
+            raise SystemExit("result check failed")
+        return
     if args.log2n is None:
         args.log2n = 21 if G == 8 else 20
     per = 1 << args.log2n
@@ -1174,6 +1524,13 @@ def main():
     cdev = "cuda" if args.dist_backend == "nccl" else "cpu"       # where collective tensors live
     pkg = importlib.import_module("ark-mpc_amd")
     eng = pkg.Engine(FID, device=dev, host_buffers=False, stream=torch.cuda.current_stream().cuda_stream)
+    if args.only_circuit:
+        r, ok = leg_circuit(pkg, eng, dev, args.circuit_log2n, args.circuit_depth)
+        print(json.dumps(r), flush=True)
+        eng.close()
+        if not ok:
+            raise SystemExit("result check failed")
+        return
     if args.only_e2e:
         r, ok = leg_end_to_end(pkg, eng, dev, args.e2e_log2n)
         print(json.dumps(r), flush=True)
@@ -1265,14 +1622,16 @@ def main():
         value = gates / elapsed
         m_launch = n // chunks                       # gates per kernel launch
         ach = m_launch * ALG_BYTES_K3 / (k3_ms * 1e-3) / 1e9
-        traffic, rocprof_ms, traffic_source = None, None, None   # from the committed rocprofv3 passes of the same workload, see profiles/
+        traffic, rocprof_ms, traffic_source, prof_file = None, None, None, None   # from the committed rocprofv3 passes of the same workload, see profiles/
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.layout)
         if os.path.exists(tf) and m_launch == (1 << 20):
             prof = json.load(open(tf))
             kp = prof["k_beaver_finish_asm"]
             traffic = kp["hbm_bytes_per_launch"]
             rocprof_ms = kp.get("rocprof_avg_launch_ms")
+            prof_file = "profiles/traffic_%s.json" % args.layout
             traffic_source = "profiles/traffic_%s.json: %s -- committed rocprofv3 PMC passes of this workload, NOT measured in this run" % (args.layout, prof.get("source", ""))
+        ach_prof = (m_launch * ALG_BYTES_K3 / (rocprof_ms * 1e-3) / 1e9) if rocprof_ms else None
         if n * world == (1 << 24) and world > 1:
             wl = "2^24 AuthenticatedScalar Beaver muls over BN254 Fr sharded across %d GPUs, 2^%d contiguous gates per GPU per step (BASELINE.json configs[2])" % (world, args.log2n)
         else:
@@ -1295,15 +1654,18 @@ def main():
                        "headline_layout_note": "engine-native split columns (what gate outputs are kept in between gates; north_star allows SoA).  The arkworks AoS records the "
                                                "boundary receives run the same pipeline at the fraction reported as aos_pipeline_frac_of_hbm_peak",
                        "parallelism": "gate-range sharding, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": ("k_beaver_finish_asm_sw<0>" if args.layout == "split" else "k_beaver_finish_asm_aos<0>") + " (K2+K3 fused, hand-scheduled)", "achieved": ach, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+            "roofline": {"bound": "hbm", "kernel": ("k_beaver_finish_asm_sw<0>" if args.layout == "split" else "k_beaver_finish_asm_aos<0>") + " (K2+K3 fused, hand-scheduled)",
+                         "achieved": ach_prof if ach_prof else ach, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": (ach_prof if ach_prof else ach) / HBM_PEAK_GBPS,
+                         "frac_source": ("the committed rocprofv3 --kernel-trace average of this kernel on this workload (%s, rocprof_avg_launch_ms): the figure anyone can recompute "
+                                         "from profiles/ -- it includes the profiler's own effect on the kernel; this run's own dispatch-bound HIP events give frac_hip_events" % prof_file) if ach_prof
+                                        else "this run's dispatch-bound HIP events (no committed profile for this layout / launch size)",
+                         "achieved_hip_events": ach, "frac_hip_events": ach / HBM_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": m_launch * ALG_BYTES_K3, "gates_per_launch": m_launch, "avg_launch_ms": k3_ms,
                          "avg_launch_ms_note": "HIP events bound to the kernel dispatch (hipExtLaunchKernelGGL) on sampled steps of the timed region",
                          "rocprof_avg_launch_ms": rocprof_ms,
-                         "frac_rocprof": (m_launch * ALG_BYTES_K3 / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if rocprof_ms else None,
-                         "frac_rocprof_note": "the same fraction priced with the committed rocprofv3 --kernel-trace average of this kernel (profiles/): the figure that "
-                                              "follows from profiles/ alone.  `frac` uses this run's dispatch-bound HIP events; the two differ by the profiler's own "
-                                              "effect on the kernel (see clock_effect)",
+                         "frac_rocprof": (ach_prof / HBM_PEAK_GBPS) if ach_prof else None,
                          "ceiling_note": "two-kernel pipeline: 580 B moved per 512 B counted per party-gate (the 64 B own-d||e re-read by K2+K3 and 4 B of K1 slack), so at the "
                                          "~6.3 TB/s the memory system sustains the pipeline tops out at 6.3 x 512/580 / 8 = 0.695 of the 8 TB/s peak (DESIGN.md section 3)",
                          "clock_effect": clock_effect()},
@@ -1336,6 +1698,11 @@ def main():
             torch.cuda.empty_cache()
             out["end_to_end"], ok_e = leg_end_to_end(pkg, eng, dev, args.e2e_log2n)
             torch.cuda.empty_cache()
+            out["circuit"], ok_c = leg_circuit(pkg, eng, dev, args.circuit_log2n, args.circuit_depth)
+            torch.cuda.empty_cache()
+            ok = ok and ok_c
+            out["circuit_party_gates_per_s"] = out["circuit"]["party_gates_per_s"]
+            out["circuit_frac_of_link_floor"] = out["circuit"]["frac_of_link_floor"]
             out["aos"], ok_a = leg_aos(eng, n, args)
             out["config4"], ok_4 = leg_config4(eng)
             torch.cuda.empty_cache()

@@ -973,3 +973,35 @@ void ora_ed_batch_to_affine_mt(size_t n, const u64* pts, u64* out_xy, int nthrea
     eda_ctx c = {pts, out_xy};
     par_for(n, nthreads, eda_range, &c);
 }
+
+/* The FUSED single-pass form of one party's batch_mul: per gate, what the single-gate `Mul` does (authenticated_scalar.rs:799-843) -- the
+ * two masking subtractions (:809-812; only the `.share()` halves are ever used, :141-145), the combine with the peer's payload (:161-171) and
+ * the gate closure  res = d * b_share + e * a_share + c_share;  res.add_public(de, mac_key, party_id)  (:835-840) -- in ONE sweep over
+ * memory instead of the nine of ora_batch_mul_9pass_local.  BASELINE.md section 3 asks for this beside the 9-pass "so that the comparison
+ * is not unfairly hobbled by pass count".  Same words as the 9-pass (field addition is associative and commutative on canonical residues;
+ * tests/test_oracle_field.py checks it).  peer_de / my_de are d||e buffers of the FULL batch. */
+typedef struct { int fid, party; size_t n; const u64 *key, *x, *y, *a, *b, *c, *peer_de; u64 *my_de, *out; } fus_ctx;
+static void fus_range(void* p, size_t lo, size_t hi) {
+    fus_ctx* q = (fus_ctx*)p;
+    const ora_field* f = ora_get_field(q->fid);
+    const size_t n = q->n;
+    for (size_t i = lo; i < hi; ++i) {
+        u64 d[4], e[4], de[4], db[8], ea[8], t[8], res[8];
+        ora_fp_sub(f, q->x + 8 * i, q->a + 8 * i, q->my_de + 4 * i);            /* masked_lhs.share()                 :809-812, :141-145 */
+        ora_fp_sub(f, q->y + 8 * i, q->b + 8 * i, q->my_de + 4 * (n + i));      /* masked_rhs.share()                                    */
+        ora_fp_add(f, q->my_de + 4 * i, q->peer_de + 4 * i, d);                 /* open: mine + peer                  :161-171           */
+        ora_fp_add(f, q->my_de + 4 * (n + i), q->peer_de + 4 * (n + i), e);
+        ora_fp_mul(f, d, e, de);                                                /* let de = d * e                     :836               */
+        share_mul_public(f, q->b + 8 * i, d, db);                               /* d * b_share                        :837               */
+        share_mul_public(f, q->a + 8 * i, e, ea);                               /* e * a_share                                           */
+        share_add(f, db, ea, t);
+        share_add(f, t, q->c + 8 * i, res);                                     /* + c_share                                             */
+        share_add_public(f, q->party, q->key, res, de, q->out + 8 * i);         /* res.add_public(de, mac_key, party) :838               */
+    }
+}
+int ora_batch_mul_fused_mt(int fid, size_t n, int party, const u64 key[4], const u64* x, const u64* y, const u64* a, const u64* b,
+                           const u64* c, const u64* peer_de, u64* my_de, u64* out, int nthreads) {
+    fus_ctx q = {fid, party, n, key, x, y, a, b, c, peer_de, my_de, out};
+    par_for(n, nthreads, fus_range, &q);
+    return 0;
+}

@@ -96,6 +96,10 @@ void ora_batch_mul_9pass_local(int field_id, size_t n, int party_id, const u64 m
 /* the same, range-split over nthreads pthreads (cpu_baseline "all cores"); returns 0 on success */
 int ora_batch_mul_9pass_mt(int field_id, size_t n, int party_id, const u64 mac_key[4], const u64* x, const u64* y,
                            const u64* a, const u64* b, const u64* c, const u64* peer_de, u64* my_de, u64* out, int nthreads);
+/* the fused single-pass form (the single-gate Mul's closure, authenticated_scalar.rs:799-843, per element in one sweep): same words as the
+ * 9-pass; BASELINE.md section 3's second CPU-baseline variant.  nthreads = 1: a plain loop */
+int ora_batch_mul_fused_mt(int field_id, size_t n, int party_id, const u64 mac_key[4], const u64* x, const u64* y,
+                           const u64* a, const u64* b, const u64* c, const u64* peer_de, u64* my_de, u64* out, int nthreads);
 /* K4: chk_i = mac_key * opened_i - share_i.mac  (:299-311) */
 void ora_mac_check_shares(int field_id, size_t n, const u64 mac_key[4], const u64* opened, const u64* shares, u64* out);
 /* K5: all(mine_i + peer_i == 0) (:218-219) */

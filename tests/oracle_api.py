@@ -257,6 +257,17 @@ class Oracle:
         assert rc == 0
         return my_de, out
 
+    def batch_mul_fused_mt(self, fid, party, key, x, y, a, b, c, peer_de, nthreads=None):
+        """the fused single-pass form (authenticated_scalar.rs:799-843 per element): same words as the 9-pass"""
+        n = len(a) // 8
+        my_de = np.zeros(2 * n * 4, dtype=np.uint64)
+        out = np.zeros(n * 8, dtype=np.uint64)
+        rc = self.lib.ora_batch_mul_fused_mt(ctypes.c_int(fid), ctypes.c_size_t(n), ctypes.c_int(party), self._p(key), self._p(x), self._p(y),
+                                             self._p(a), self._p(b), self._p(c), self._p(peer_de), self._p(my_de), self._p(out),
+                                             ctypes.c_int(nthreads or self.host_threads()))
+        assert rc == 0
+        return my_de, out
+
     def open_and_mac_check_mt(self, fid, key, shares, peer, nthreads=None):
         n = len(shares) // 8
         opened = np.zeros(4 * n, dtype=np.uint64); chk = np.zeros(4 * n, dtype=np.uint64)

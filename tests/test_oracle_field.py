@@ -136,3 +136,33 @@ def test_reductions_vs_bigint(oracle, fid):
         b = mixed_values(fid, n, seed=901 + n + fid)[::-1]
         rec = np.ascontiguousarray(np.concatenate([am.reshape(-1, 4), mont_array(fid, b).reshape(-1, 4)], axis=1).reshape(-1))
         assert from_mont_array(fid, oracle.share_sum(fid, rec)) == [sum(a) % p, sum(b) % p]
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_fused_single_pass_batch_mul_equals_the_nine_passes_and_bigints(oracle, fid, threads):
+    """BASELINE.md section 3 times two CPU forms of batch_mul: the reference's literal nine passes (authenticated_scalar.rs:848-879) and the
+    fused single pass (the single-gate Mul's closure, :799-843).  Both parties through both forms: identical words; and the opened product is
+    x * y with MAC key * x * y in Python ints."""
+    from helpers import authenticated_shares, rand_values
+    p = pyref.P[fid]
+    n = 333
+    k0, k1 = rand_values(fid, 2, 41 + fid)
+    key = (k0 + k1) % p
+    keys = [mont_array(fid, [k0]), mont_array(fid, [k1])]
+    x, y, a, b = (mixed_values(fid, n, seed=50 + i + fid) if i < 2 else rand_values(fid, n, 60 + i + fid) for i in range(4))
+    c = [(u * v) % p for u, v in zip(a, b)]
+    sh = {nm: authenticated_shares(fid, v, key, 70 + i) for i, (nm, v) in enumerate(zip("xyabc", (x, y, a, b, c)))}
+    de = [oracle.beaver_mask(fid, sh["x"][q], sh["y"][q], sh["a"][q], sh["b"][q]) for q in (0, 1)]
+    outs = []
+    for q in (0, 1):
+        args = (fid, q, keys[q], sh["x"][q], sh["y"][q], sh["a"][q], sh["b"][q], sh["c"][q], de[1 - q])
+        d9, o9 = oracle.batch_mul_9pass_local(*args)
+        df, of = oracle.batch_mul_fused_mt(*args, nthreads=threads)
+        assert np.array_equal(d9, de[q]) and np.array_equal(df, de[q])
+        assert np.array_equal(o9, of)
+        outs.append(of.reshape(n, 8))
+    share = [(u + v) % p for u, v in zip(from_mont_array(fid, np.ascontiguousarray(outs[0][:, :4]).reshape(-1)), from_mont_array(fid, np.ascontiguousarray(outs[1][:, :4]).reshape(-1)))]
+    mac = [(u + v) % p for u, v in zip(from_mont_array(fid, np.ascontiguousarray(outs[0][:, 4:]).reshape(-1)), from_mont_array(fid, np.ascontiguousarray(outs[1][:, 4:]).reshape(-1)))]
+    assert share == [(u * v) % p for u, v in zip(x, y)]
+    assert mac == [(key * u * v) % p for u, v in zip(x, y)]
