@@ -44,11 +44,26 @@ def _check(line, n_gpus, steps, warmup, scaling="weak"):
 
 def test_single_process_default_shape():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--log2n", "16",
-                        "--cpu-log2n", "12"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-log2n", "12", "--circuit-log2n", "17", "--circuit-depth", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _check(r.stdout.strip().splitlines()[-1], 1, 6, 2)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "gates/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # BASELINE.md section 3 in full: both CPU forms on all cores and on one thread, the host description, the cargo probe, the label
+    assert cb["label"] == "CPU restatement of reference algorithm (not ark-mpc measured)"
+    fs = cb["fused_single_pass"]
+    assert fs["value"] > 0 and fs["single_thread_value"] > 0 and fs["same_words_as_nine_passes"] is True and cb["single_thread_value"] > 0
+    for k in ("cpu_model", "nproc", "compiler", "flags", "cargo_probe", "excludes"):
+        assert cb.get(k), k
+    assert "gcc" in cb["compiler"] and "-O3" in cb["flags"]
+    # the top-level roofline fraction is the reproducible one; the live HIP-event figure rides beside it
+    rf = d["roofline"]
+    assert rf["frac_hip_events"] > 0 and rf["achieved_hip_events"] > 0 and "frac_source" in rf
+    # the circuit leg: resident operands, random triples from host memory, bit-exact, priced against the 192 B / party-gate link floor
+    c = d["circuit"]
+    assert c["results_check"].endswith("ok") and 0 < c["frac_of_link_floor"] <= 1.05 and c["party_gates_per_s"] > 0
+    assert set(c["modes"]) >= {"prefetched_async", "round4_blocking", "pageable_async", "sessions_resident_operands"}
+    assert d["circuit_party_gates_per_s"] == c["party_gates_per_s"]
     # the N = 1 line leads with the figures a reader needs beside `value`: the arkworks-layout fraction, the host-to-host rate, config 5's wall time
     for k in ("aos_pipeline_frac_of_hbm_peak", "end_to_end_party_gates_per_s", "config5_end_to_end_ms", "end_to_end"):
         assert k in d, k
@@ -151,3 +166,15 @@ def test_steps_above_2p20_gates_run_in_ranges():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["config"]["launches_per_step"] == 8 and d["roofline"]["gates_per_launch"] == 1 << 20
     assert d["results_check"].endswith("ok") and d["value"] > 0
+
+
+def test_single_process_group_end_to_end_leg():
+    """`bench.py --single-process --only-e2e`: group sessions over members sharing device 0, per-member link rates and their sum in the line"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "3", "--devices", "0,0,0", "--only-e2e", "--e2e-log2n", "16"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["members"] == 3 and d["oversubscribed"] is True and d["distinct_devices"] == 1 and d["results_check"].endswith("ok")
+    assert len(d["per_member"]) == 3 and all(m["gates"] == 1 << 16 and m["session_link_up_GBps"] > 0 and m["phase1_link_up_GBps"] > 0 for m in d["per_member"])
+    assert abs(sum(m["session_link_up_GBps"] for m in d["per_member"]) - d["link_up_GBps_sum_over_members"]) < 1e-6 * d["link_up_GBps_sum_over_members"]
+    assert all(tuple(m["path"]) >= (1, 1) for m in d["per_member"])          # the members' phases ran in place on the pinned vectors
