@@ -375,15 +375,54 @@ static bool append_stripped(const unsigned char* in, size_t a, size_t b, std::ve
     return true;
 }
 // in: a whole frame (8-byte prefix + JSON text).  out: the canonical compact frame of the same message, or err set.
+// Both forms a serde-derived struct deserialises from are read (serde's derive implements visit_map AND visit_seq): the object
+// {"result_id": .., "payload": ..} with the semantics listed in include/arkmpc.h, and the two-element sequence [result_id, payload] --
+// fields in declaration order (network.rs:33-40), a missing or a third element is an error (invalid length / trailing characters).
 static bool normalise_message(const std::vector<unsigned char>& in, std::vector<unsigned char>& out, std::string& err) {
     JsonScan sc{in.data(), in.size(), 8, {}};
     auto bad = [&](const char* what) { err = sc.err.empty() ? what : sc.err; return false; };
-    sc.ws();
-    if (sc.i >= sc.n || sc.p[sc.i] != '{') return bad("malformed message: expected an object");
-    ++sc.i;
     size_t rid_a = 0, rid_b = 0, arr_a = 0, arr_b = 0;
     bool have_rid = false, have_payload = false;
     std::string variant;
+    // the two fields' values, wherever they stand
+    auto read_rid = [&]() -> bool {
+        sc.ws(); rid_a = sc.i;
+        if (sc.i >= sc.n || !((sc.p[sc.i] >= '0' && sc.p[sc.i] <= '9') || sc.p[sc.i] == '-')) return bad("malformed message: result_id");
+        if (!sc.number()) return bad("malformed message: result_id");
+        rid_b = sc.i;
+        return true;
+    };
+    auto read_payload = [&]() -> bool {
+        sc.ws();
+        if (sc.i >= sc.n || sc.p[sc.i] != '{') return bad("malformed message: payload");
+        ++sc.i; sc.ws();
+        if (!sc.string(&variant)) return bad("malformed message: payload variant");
+        sc.ws();
+        if (sc.i >= sc.n || sc.p[sc.i] != ':') return bad("malformed message: payload");
+        ++sc.i; sc.ws(); arr_a = sc.i;
+        if (sc.i >= sc.n || sc.p[sc.i] != '[') return bad("malformed message: payload");
+        if (!sc.value(1)) return bad("malformed message: payload");
+        arr_b = sc.i; sc.ws();
+        if (sc.i >= sc.n || sc.p[sc.i] != '}') return bad("malformed message: payload is not a single-variant object");
+        ++sc.i;
+        return true;
+    };
+    sc.ws();
+    if (sc.i < sc.n && sc.p[sc.i] == '[') {                  // the sequence form
+        ++sc.i;
+        if (!read_rid()) return false;
+        have_rid = true;
+        sc.ws();
+        if (sc.i >= sc.n || sc.p[sc.i] != ',') return bad("malformed message: a sequence needs two elements (result_id, payload)");
+        ++sc.i;
+        if (!read_payload()) return false;
+        have_payload = true;
+        sc.ws();
+        if (sc.i >= sc.n || sc.p[sc.i] != ']') return bad("malformed message: a sequence of more than two elements");
+        ++sc.i;
+    } else {
+    if (sc.i >= sc.n || sc.p[sc.i] != '{') return bad("malformed message: expected an object");
+    ++sc.i;
     sc.ws();
     if (sc.i < sc.n && sc.p[sc.i] == '}') ++sc.i;
     else while (true) {
@@ -396,25 +435,11 @@ static bool normalise_message(const std::vector<unsigned char>& in, std::vector<
         if (key == "result_id") {
             if (have_rid) return bad("malformed message: duplicate field `result_id`");
             have_rid = true;
-            sc.ws(); rid_a = sc.i;
-            if (sc.i >= sc.n || !((sc.p[sc.i] >= '0' && sc.p[sc.i] <= '9') || sc.p[sc.i] == '-')) return bad("malformed message: result_id");
-            if (!sc.number()) return bad("malformed message: result_id");
-            rid_b = sc.i;
+            if (!read_rid()) return false;
         } else if (key == "payload") {
             if (have_payload) return bad("malformed message: duplicate field `payload`");
             have_payload = true;
-            sc.ws();
-            if (sc.i >= sc.n || sc.p[sc.i] != '{') return bad("malformed message: payload");
-            ++sc.i; sc.ws();
-            if (!sc.string(&variant)) return bad("malformed message: payload variant");
-            sc.ws();
-            if (sc.i >= sc.n || sc.p[sc.i] != ':') return bad("malformed message: payload");
-            ++sc.i; sc.ws(); arr_a = sc.i;
-            if (sc.i >= sc.n || sc.p[sc.i] != '[') return bad("malformed message: payload");
-            if (!sc.value(1)) return bad("malformed message: payload");
-            arr_b = sc.i; sc.ws();
-            if (sc.i >= sc.n || sc.p[sc.i] != '}') return bad("malformed message: payload is not a single-variant object");
-            ++sc.i;
+            if (!read_payload()) return false;
         } else if (!sc.value(1)) {
             return bad("malformed message: value of an unknown field");
         }
@@ -423,6 +448,7 @@ static bool normalise_message(const std::vector<unsigned char>& in, std::vector<
         if (sc.p[sc.i] == ',') { ++sc.i; continue; }
         if (sc.p[sc.i] == '}') { ++sc.i; break; }
         return bad("malformed message: expected ',' or '}'");
+    }
     }
     sc.ws();
     if (sc.i != sc.n) return bad("malformed message: trailing characters");

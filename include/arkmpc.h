@@ -484,7 +484,8 @@ int arkmpc_edshare_sum(arkmpc_ctx* ctx, size_t n, const uint64_t* shares, uint64
  * directly) is re-read on the host with the semantics serde_json::from_slice gives a derived struct (network/quic.rs:233-251): JSON
  * whitespace between tokens, the two fields in any order, unknown fields skipped whatever value they hold, escaped keys compared after
  * unescaping, a known field given twice = error, the payload an object with exactly one variant key, nothing but whitespace after the
- * closing brace, nesting limited to 128 levels -- and, if it is a message, rewritten to the compact form and parsed on the GPU.
+ * closing brace, nesting limited to 128 levels; also the two-element SEQUENCE form [result_id, payload] a derived struct deserialises from
+ * (fields in declaration order, network.rs:33-40; one or three elements = error) -- and, if it is a message, rewritten to the compact form and parsed on the GPU.
  * A device-mode frame buffer needs no padding: no byte at or beyond frame_len is read. */
 #define ARKMPC_WIRE_SCALAR_BATCH 0
 #define ARKMPC_WIRE_POINT_BATCH 1

@@ -182,6 +182,10 @@ def serde_model(fid, body, variant="ScalarBatch"):
         msg = json.loads(text, object_pairs_hook=_Obj, parse_int=lambda t: ("int", t), parse_float=lambda t: ("float", t), parse_constant=_no_const)
     except (ValueError, RecursionError):
         return None
+    if isinstance(msg, list) and not isinstance(msg, _Obj):     # serde's derive also implements visit_seq: [result_id, payload], exactly two elements
+        if len(msg) != 2:
+            return None
+        msg = _Obj([("result_id", msg[0]), ("payload", msg[1])])
     if not isinstance(msg, _Obj):
         return None
     strings, depth = _strings_and_depth(msg, 0)
@@ -298,6 +302,14 @@ def _object_shapes(fid, vals, rid):
     yield "unknown value nested 200 deep", b'{"deep":' + deep(200) + b"," + R + b"," + P + b"}", False
     yield "byte order mark", b"\xef\xbb\xbf{" + R + b"," + P + b"}", False
     yield "top-level array", b"[" + R[12:] + b"]", False
+    pay = b'{"ScalarBatch":' + arr + b"}"
+    yield "sequence form [result_id, payload]", b"[%d," % rid + pay + b"]", True
+    yield "sequence form with whitespace", b" [ %d ,\n " % rid + pay.replace(b":", b" : ", 1) + b" ]\t", True
+    yield "sequence of three", b"[%d," % rid + pay + b",null]", False
+    yield "sequence in the wrong order", b"[" + pay + b",%d]" % rid, False
+    yield "sequence with a trailing comma", b"[%d," % rid + pay + b",]", False
+    yield "sequence then garbage", b"[%d," % rid + pay + b"]]", False
+    yield "sequence with a float id", b"[%d.5," % rid + pay + b"]", False
 
 
 @pytest.mark.gpu
