@@ -1007,8 +1007,9 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
     P = lambda t: t.data_ptr()
     col = 32 * n                                                # byte offset of the MAC column
 
-    def run_batches(source, asynchronous, prefetch):
-        """source(k, p) -> {"a","b","c"} host vectors of gate k"""
+    def run_batches(source, asynchronous, prefetch, net_ms=0.0):
+        """source(k, p) -> {"a","b","c"} host vectors of gate k.  net_ms > 0: every gate's d||e exchange takes that long (the payload is complete,
+        the host waits, then K2+K3 is issued) -- the network round a real two-party deployment has between K1 and K2+K3 of every gate"""
         def imp(k, p):
             return [eng.batch_from_host(S, eng.SPLIT, n, source(k, p)[nm], asynchronous=asynchronous) for nm in "abc"]
         t0 = time.perf_counter()
@@ -1024,6 +1025,9 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
                 eng.beaver_mask_v(n, P(zin[p]), 4, P(y_sp[p]), 4, as_, st, bs, st, de[p][k])
             if prefetch and k + 1 < depth:
                 nxt = [imp(k + 1, p) for p in (0, 1)]           # gate k+1's triples start on their way under gate k
+            if net_ms > 0:
+                eng.sync()                                      # the payload is complete ...
+                time.sleep(net_ms * 1e-3)                       # ... and crosses the network
             for p in (0, 1):
                 (as_, am, st), (bs, bm, _), (cs, cm, _) = ptr[p]
                 eng.beaver_finish_fused_v(n, p, keys[p], de[p][k], de[1 - p][k], as_, am, st, bs, bm, st, cs, cm, st, P(z[p][k]), P(z[p][k]) + col, 4)
@@ -1115,6 +1119,15 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
     record("round4_blocking", "arkmpc_batch_from_host as it was: blocking copy on the compute stream into a staging block, then a split pass, three times per party-gate, "
            "nothing overlapped", lambda: run_batches(pinned_src, False, False))
     ex_d = exact_split(z, de)
+    # the same three with a network round of NET_MS per gate between K1 and K2+K3: what reading ahead is for -- without it the link idles during
+    # every round and the round idles during every upload
+    NET_MS = 2.0
+    with_net = {}
+    for name, (asyn, pre) in (("prefetched_async", (True, True)), ("async_no_prefetch", (True, False)), ("round4_blocking", (False, False))):
+        run_batches(pinned_src, asyn, pre, NET_MS)
+        ts_ = [run_batches(pinned_src, asyn, pre, NET_MS) for _ in range(2)]
+        with_net[name] = {"ms_per_gate": float(np.median(ts_)) * 1e3 / depth, "party_gates_per_s": 2 * n * depth / float(np.median(ts_))}
+    ex_e = exact_split(z, de)
     async_imports = st1["batch_async_imports"] - st0["batch_async_imports"]
     # sessions with resident operands (AoS records)
     zs = [[torch.empty(8 * n, dtype=torch.int64, device="cuda") for _ in range(depth)] for _ in (0, 1)]
@@ -1129,7 +1142,7 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
             g = (o == want_z[p][k].reshape(m, 8)).all(axis=1)
             g &= (d_[:4 * m].reshape(m, 4) == want_de[p][k][:4 * m].reshape(m, 4)).all(axis=1) & (d_[4 * n:4 * n + 4 * m].reshape(m, 4) == want_de[p][k][4 * m:].reshape(m, 4)).all(axis=1)
             good += int(g.sum())
-    ok = ex_a == total and ex_b == total and ex_c == total and ex_d == total and good == total and async_imports == 4 * 6 * depth
+    ok = ex_a == total and ex_b == total and ex_c == total and ex_d == total and ex_e == total and good == total and async_imports == 4 * 6 * depth
     for q in hold:
         lib.arkmpc_host_free(q)
     best = modes["prefetched_async"]
@@ -1140,6 +1153,10 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
             "link_floor": {"bytes_up_per_party_gate": 192, "measured_h2d_GBps": cal["h2d_GBps"], "floor_ms": floor_ms, "floor_party_gates_per_s": cal["h2d_GBps"] * 1e9 / 192,
                            "note": "both parties share this GPU's one link: per party-gate the floor is the same as for one party per GPU"},
             "modes": modes, "speedup_over_round4_path": modes["round4_blocking"]["ms"] / best["ms"],
+            "with_network_round": {"net_round_ms_per_gate": NET_MS, "modes": with_net,
+                                   "speedup_over_round4_path": with_net["round4_blocking"]["ms_per_gate"] / with_net["prefetched_async"]["ms_per_gate"],
+                                   "what": "the same chain with a %.1f ms network round per gate between K1 and K2+K3 (host sleep after the payload is complete): read ahead, the "
+                                           "next gate's triples cross the link during the round; otherwise link and network take turns" % NET_MS},
             "results_check": "every gate of the chain, both parties, d||e and result records == oracle (%s of each batch; %d party-gates x 5 runs), and every import of the "
                              "headline mode went up asynchronously (%d): %s" % ("ALL gates" if m == n else "the first 2^%d" % int(np.log2(m)), total, async_imports, "ok" if ok else "FAILED")}, ok
 
@@ -1167,7 +1184,7 @@ def leg_gather(dist, world, rank, backend):
 def clock_effect():
     """Measured effect of the profiler on the dominant kernel, from the committed PMC pass (profiles/r0N/clock_effect.json, written by
     tools/profile.sh): GRBM_GUI_ACTIVE cycles / the kernel's wall time under rocprofv3 = the shader clock it ran at while profiled."""
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         f = os.path.join(ROOT, "profiles", rnd, "clock_effect.json")
         if os.path.exists(f):
             d = json.load(open(f)); d["source"] = "profiles/%s/clock_effect.json" % rnd

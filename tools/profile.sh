@@ -8,9 +8,11 @@
 #   pmc_clock/           GRBM_GUI_ACTIVE of the split loop with the kernel trace: busy cycles / kernel wall time = the clock under the profiler
 #   pmc_k3/ pmc_ec/      VALU issue counters of K1 / K2+K3 and of the scalar-mul kernels (config 4)
 #   e2e_trace/           --kernel-trace --memory-copy-trace of `bench.py --only-e2e` (the streaming host-to-host sessions)
+#   bench_circuit_run.json / circuit_trace/     `bench.py --only-circuit` (resident operands, triples from host memory) and its kernel / copy trace
+#   bench_group_e2e.jsonl                       `bench.py --single-process --only-e2e` with 1, 2, 4, 8 members sharing device 0 (2^20 gates in total)
 # Summary: tools/summarize_prof.py
 set -u
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
 if [ "${1:-}" = "collect" ]; then
@@ -19,6 +21,8 @@ if [ "${1:-}" = "collect" ]; then
   mkdir -p profiles/$ROUND profiles/${ROUND}_host profiles/${ROUND}_ec profiles/${ROUND}_e2e
   cp $S/summary.txt $S/bench_default_run.json $S/bench_driver_shape_run.json $S/bench_default_under_rocprof.json $S/clock_effect.json profiles/$ROUND/
   [ -f $S/bench_single_process.jsonl ] && cp $S/bench_single_process.jsonl profiles/$ROUND/
+  for f in bench_circuit_run.json bench_group_e2e.jsonl; do [ -f $S/$f ] && cp $S/$f profiles/${ROUND}_e2e/; done
+  [ -f $S/circuit_trace/circuit_kernel_stats.csv ] && cp $S/circuit_trace/circuit_kernel_stats.csv $S/circuit_trace/circuit_memory_copy_stats.csv profiles/${ROUND}_e2e/ 2>/dev/null
   cp $S/trace_default/trace_kernel_stats.csv profiles/$ROUND/trace_default_kernel_stats.csv
   cp $S/trace_split/trace_kernel_stats.csv profiles/$ROUND/trace_split_kernel_stats.csv
   cp $S/trace_aos/trace_kernel_stats.csv profiles/$ROUND/trace_aos_kernel_stats.csv
@@ -59,6 +63,13 @@ A="--steps 100 --warmup 10 --no-cpu-baseline --no-extras --no-cold"
 $B > $OUT/bench_default_run.json 2> $OUT/bench_default_run.log
 $B --steps 20 --warmup 5 > $OUT/bench_driver_shape_run.json 2> $OUT/bench_driver_shape_run.log
 $B --only-e2e > $OUT/bench_e2e_run.json 2> $OUT/bench_e2e_run.log
+$B --only-circuit > $OUT/bench_circuit_run.json 2> $OUT/bench_circuit_run.log
+for d in "0" "0,0" "0,0,0,0" "0,0,0,0,0,0,0,0"; do
+  N=$(echo $d | tr ',' '\n' | wc -l)
+  $B --single-process --gpus $N --devices $d --only-e2e --e2e-log2n $((20 - (N > 1 ? (N > 2 ? (N > 4 ? 3 : 2) : 1) : 0))) >> $OUT/bench_group_e2e.jsonl 2>> $OUT/bench_group_e2e.log
+done
+mkdir -p $OUT/circuit_trace
+rocprofv3 --kernel-trace --memory-copy-trace --stats -f csv -d $OUT/circuit_trace -o circuit -- $B --only-circuit --circuit-depth 4 > $OUT/circuit_trace/bench_circuit_under_rocprof.json 2> $OUT/circuit_trace/rocprof.log
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_default -o trace -- $B > $OUT/bench_default_under_rocprof.json 2> $OUT/trace_default.log
 for L in split aos; do
   rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_$L -o trace -- $B --layout $L $A > $OUT/bench_trace_$L.json 2> $OUT/trace_$L.log
