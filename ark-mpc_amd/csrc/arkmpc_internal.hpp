@@ -500,7 +500,7 @@ static inline void launch_k_lds(arkmpc_ctx* ctx, unsigned lds_bytes, K kernel, d
 template <typename K, typename... A>
 static inline void launch_k(arkmpc_ctx* ctx, K kernel, dim3 grid, dim3 block, A... args) {
     // experiment hook: ARKMPC_TEST_DYN_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups a CU can hold (occupancy sensitivity
-    // of the streaming kernels: tools/k3_occupancy_probe.sh); 0 / unset in production
+    // of the streaming kernels: tools/k3_occupancy_probe.sh @77e688c); 0 / unset in production
     static const unsigned dyn_lds = getenv("ARKMPC_TEST_DYN_LDS") ? (unsigned)atoi(getenv("ARKMPC_TEST_DYN_LDS")) : 0u;
     if (ctx->timer_slot >= 0) {
         const int s = ctx->timer_slot;

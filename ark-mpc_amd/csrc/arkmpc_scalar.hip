@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(TPB) k_beaver_finish_asm_sw(u32 n, u32 mask, F
                                                               const u64* c_s, const u64* c_m, u64* out_s, u64* out_m) {
     typedef u32 v4u __attribute__((ext_vector_type(4)));
     // 16 KiB are used; the allocation is 44 KiB so that a CU holds THREE workgroups (three waves per SIMD), not the four the 115 VGPRs would allow:
-    // the kernel is bound by the memory system, not by latency -- measured with tools/k3_occupancy_probe.sh: 4 / 3 / 2 / 1 waves per SIMD =
+    // the kernel is bound by the memory system, not by latency -- measured with tools/k3_occupancy_probe.sh @77e688c: 4 / 3 / 2 / 1 waves per SIMD =
     // 57.8 / 57.0 / 59.4 / 82 us -- and the fourth wave only adds contention
     __shared__ v4u lds[2816];
     const u32 first = blockIdx.x * TPB, i = first + threadIdx.x;
@@ -492,7 +492,7 @@ static void launch_mask(arkmpc_ctx* ctx, size_t n, Col x, Col y, Col a, Col b, u
     static const bool xcd_map = getenv("ARKMPC_K1_XCD") && getenv("ARKMPC_K1_XCD")[0] == '1';
     const u32 xcd = (xcd_map && g.x % 8 == 0 && n % TPB == 0) ? g.x : 0u;
     // unused dynamic LDS caps the workgroups per CU (160 KB per CU): K1 is bound by the memory system and runs best with few waves in flight
-    // (tools/k1_occupancy_probe.sh, 2^20 gates: 8+ / 4 / 3 / 2 / 1 workgroups per CU = 36.5 / 36.0 / 35.9 / 35.1 / 36.0 us): two workgroups per CU for large batches
+    // (tools/k1_occupancy_probe.sh @77e688c, 2^20 gates: 8+ / 4 / 3 / 2 / 1 workgroups per CU = 36.5 / 36.0 / 35.9 / 35.1 / 36.0 us): two workgroups per CU for large batches
     static const int k1_lds_env = getenv("ARKMPC_K1_LDS") ? atoi(getenv("ARKMPC_K1_LDS")) : -1;
     // the cap is only applied where a workgroup may own that much LDS (gfx950: 160 KB); elsewhere the launch would fail, so it is dropped
     if (!ctx->lds_per_wg) { int v = 0; ctx->lds_per_wg = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0 ? (unsigned)v : 65536u; }
@@ -534,7 +534,7 @@ static void launch_finish_fused(arkmpc_ctx* ctx, size_t n, int party, const Fe& 
                 const size_t cnt = (n - lo < CH) ? (n - lo) : CH;
                 const size_t cs = (size_t)a_s.stride * lo, os = (size_t)o_s.stride * lo;
                 // split-column layout (stride 4): once-streamed data carries non-temporal hints; AoS: none (halves share lines)
-                // ARKMPC_K3_NT (A/B switch, split columns; measured at 2^20 gates, tools/ab_k3_nt.sh): 3 (default) = non-temporal hints on the
+                // ARKMPC_K3_NT (A/B switch, split columns; measured at 2^20 gates, tools/ab_k3_nt.sh @77e688c): 3 (default) = non-temporal hints on the
                 // once-streamed loads, result staged through LDS and written with whole-line non-temporal stores: 58.4 us; 1 = the same hints with the
                 // body's own 16-byte stores: 61.1 us (partial-line write amplification); 2 = hints on the loads only: 66 us (plain stores keep the
                 // results in the cache K3's re-reads want); 0 = no hints: 74 us

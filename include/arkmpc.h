@@ -132,7 +132,9 @@ int arkmpc_batch_from_host(arkmpc_ctx* ctx, int kind, int layout, size_t n, cons
  *                   it themselves; call it before handing arkmpc_batch_data() pointers to the pointer-level ones.
  *   _host_release   blocks until the import has read host_records to its end and drops the pin; only then may the vector be freed or
  *                   overwritten (arkmpc_batch_destroy does the same if it was never called).
- * Vectors that cannot be pinned (below 1 MiB, read-only mappings) take the blocking path of arkmpc_batch_from_host. */
+ * Vectors that cannot be pinned (below 1 MiB, read-only mappings) take the blocking path of arkmpc_batch_from_host.
+ * A handle's import state belongs to the thread that drives the batch: _acquire / _host_release / _destroy of ONE handle are not to be
+ * called concurrently (different handles, and retained clones once the import has been released, are independent). */
 int arkmpc_batch_from_host_async(arkmpc_ctx* ctx, int kind, int layout, size_t n, const void* host_records, arkmpc_batch** out_batch);
 int arkmpc_batch_acquire(arkmpc_ctx* ctx, arkmpc_batch* batch);
 int arkmpc_batch_host_release(arkmpc_ctx* ctx, arkmpc_batch* batch);
