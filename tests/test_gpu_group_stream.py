@@ -391,3 +391,51 @@ def test_prefetched_triples_feed_a_chain_of_gates(pkg, oracle):
             cur[p][0] = outb[p]
     e.close()
     arena.free()
+
+
+def test_group_sessions_soak_random_sizes_members_and_placements(pkg, eng0):
+    """48 group sessions of random size (1 ... 70 000 gates), member count (1 ... 8, all on device 0) and vector placement (pinned pools /
+    pageable / freshly allocated per session), two parties interleaved, each against a single-context session on the same records (itself
+    checked against the oracle elsewhere).  Leaks of events, pins or device blocks show as errors or a growing pool; ordering bugs as wrong words."""
+    import random
+    fid = 0
+    rng = random.Random(515)
+    base = 70000
+    _, keys, sh = _inputs(fid, base, seed=9950, tile_from=2500)
+    arena = _PinnedArena(pkg)
+    pinned = {k: (arena.copy(v[0]), arena.copy(v[1])) for k, v in sh.items()}
+    pool_de = [arena.zeros(8 * base), arena.zeros(8 * base)]
+    pool_out = [arena.zeros(8 * base), arena.zeros(8 * base)]
+    groups = {}
+    for it in range(24):
+        n = rng.choice([1, 2, 255, 257, 4095, 4096, 4097, 9000, 16385, 33000, 65536, base])
+        G = rng.choice([1, 2, 3, 5, 8])
+        how = rng.choice(["pinned", "pageable", "mixed"])
+        o = rng.randrange(0, base - n + 1)
+        sl = lambda a: a[8 * o: 8 * (o + n)]
+        if G not in groups:
+            groups[G] = [pkg.Group(fid, [0] * G) for _ in (0, 1)]
+        grp = groups[G]
+        src = pinned if how != "pageable" else sh
+        H = [{k: (sl(src[k][p]) if how != "mixed" or k in "xa" else sl(sh[k][p]).copy()) for k in "xyabc"} for p in (0, 1)]
+        if how == "pageable":
+            de = [np.zeros(8 * n, dtype=np.uint64) for _ in (0, 1)]; out = [np.zeros(8 * n, dtype=np.uint64) for _ in (0, 1)]
+        else:
+            de = [pool_de[p][:8 * n] for p in (0, 1)]; out = [pool_out[p][:8 * n] for p in (0, 1)]
+            for a_ in de + out:
+                a_.fill(0)
+        ses = [grp[p].hostmul_begin(n, H[p]["x"], H[p]["y"], H[p]["a"], H[p]["b"], H[p]["c"], de[p]) for p in (0, 1)]
+        for p in (0, 1):
+            grp[p].hostmul_wait_de(ses[p])
+        for p in (0, 1):
+            grp[p].hostmul_finish(ses[p], p, keys[p], de[1 - p], out[p])
+        sub = {nm: (np.ascontiguousarray(sl(sh[nm][0])), np.ascontiguousarray(sl(sh[nm][1]))) for nm in "xyabc"}
+        one_de, one_out = _run_two_party(eng0, n, keys, sub)
+        for p in (0, 1):
+            assert np.array_equal(de[p], one_de[p]) and np.array_equal(out[p], one_out[p]), (it, n, G, how, o, p)
+    for pair in groups.values():
+        for g in pair:
+            g.close()
+    st = eng0.stats()
+    assert st["hostmul_device_bytes_peak"] <= 512 * base
+    arena.free()
