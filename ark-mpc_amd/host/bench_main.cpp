@@ -3,6 +3,7 @@
 // region the reference times.  The reference publishes no numbers for these; this driver produces
 // the MI355X side of the table.
 //   batch_ops        online-phase/benches/batch_ops.rs:20-39    share x, share y, batch_mul, open_authenticated_batch
+//   group_batch_ops  the same for a party over several GPUs (ARKMPC_GROUP_DEVICES): batch_mul as a streaming session over the group
 //   mul_throughput   benches/circuit_mul_throughput.rs:24-36    n SEQUENTIAL squarings res = res * res, then open
 //   msm_throughput   benches/circuit_msm_throughput.rs:24-38    AuthenticatedPointResult::msm of n (one, identity) pairs, open
 //   point_batch_mul  BASELINE config 4 secondary op: AuthenticatedPointResult::batch_mul (authenticated_curve.rs:682-714)
@@ -41,6 +42,27 @@ int main(int argc, char** argv) {
                     auto b = fabric->batch_share_scalar(b_m, n, PARTY0);
                     auto res = AuthenticatedScalarBatch::batch_mul(a, b);
                     AuthenticatedOpenResult o = res.open_authenticated_batch(blinder);
+                    if (o.err != MpcError::None) throw std::runtime_error("authentication failed");
+                } else if (bench == "group_batch_ops") {
+                    // the same shape for a party that owns several GPUs (ARKMPC_GROUP_DEVICES, default 0,0): the shares leave the sharing step as host
+                    // vectors, batch_mul runs as a streaming session over the group (every member on its range of the vectors, its own link), the
+                    // product is opened on the sharded path
+                    std::vector<int> devs;
+                    const char* gd = std::getenv("ARKMPC_GROUP_DEVICES");
+                    for (std::string t = gd ? gd : "0,0"; !t.empty();) { const size_t c = t.find(','); devs.push_back(std::atoi(t.substr(0, c).c_str())); t = c == std::string::npos ? "" : t.substr(c + 1); }
+                    static thread_local std::shared_ptr<GroupFabric> gf;
+                    if (!gf || gf->fabric() != fabric) gf = std::make_shared<GroupFabric>(fabric, devs);
+                    const bool tr = std::getenv("ARKMPC_BENCH_TRACE") && fabric->party_id() == 0;
+                    auto lap = [&](const char* what) { if (tr) std::fprintf(stderr, "  %-28s %8.2f ms\n", what, std::chrono::duration<double>(Clock::now() - t0).count() * 1e3); };
+                    std::vector<ScalarShare> a = fabric->batch_share_scalar(a_m, n, PARTY0).to_host();
+                    std::vector<ScalarShare> b = fabric->batch_share_scalar(b_m, n, PARTY0).to_host();
+                    lap("share x, y -> host vectors");
+                    std::vector<ScalarShare> res = gf->batch_mul_host(a, b);
+                    lap("batch_mul_host");
+                    ShardedShares sres = gf->shares_from_host(res);
+                    lap("shares_from_host");
+                    GroupOpenResult o = gf->open_authenticated_batch(sres, blinder);
+                    lap("open_authenticated_batch");
                     if (o.err != MpcError::None) throw std::runtime_error("authentication failed");
                 } else if (bench == "mul_throughput") {
                     auto res = fabric->batch_share_scalar(std::vector<Scalar>(1, eng.from_u64(1)), 1, PARTY0);

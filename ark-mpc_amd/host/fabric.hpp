@@ -617,6 +617,8 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
         return std::move(m.payload);
     }
     // the next n triples as host vectors (PreprocessingPhase::next_triplet_batch, offline_prep.rs:65-81), ids advanced as next_triple_batch
+    PreprocessingPhase& preprocessing() { return *prep_; }
+    void advance_ids(uint64_t count) { next_id_ += count; }          // result ids of values a caller took from the source itself (fabric.rs:894-915 allocates 3n per triple batch)
     void next_triple_host(size_t n, std::vector<ScalarShare>& a, std::vector<ScalarShare>& b, std::vector<ScalarShare>& c) {
         if (pending_) throw std::logic_error("next_triple_host after triples were read ahead into HBM: turn the prefetch off on a fabric that is driven through host-vector triples");
         prep_->next_triplet_batch(n, a, b, c);
@@ -1444,7 +1446,10 @@ class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
         if (arkmpc_group_create(f_->engine()->field_id(), (int)device_ids.size(), device_ids.data(), &g_) != ARKMPC_OK)
             throw std::runtime_error("arkmpc_group_create failed: the engine needs GPUs, there is no CPU fallback");
     }
-    ~GroupFabric() { if (g_) arkmpc_group_destroy(g_); }
+    ~GroupFabric() {
+        for (auto* q : const_trip_) if (q) arkmpc_host_free(q);
+        if (g_) arkmpc_group_destroy(g_);
+    }
     GroupFabric(const GroupFabric&) = delete;
     arkmpc_group* group() const { return g_; }
     int layout() const { return f_->share_layout(); }
@@ -1465,13 +1470,28 @@ class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
         gcheck(arkmpc_group_shares_to_host(g_, layout(), a.n, a.buf.cptrs(), a.n ? &v[0].share.l[0] : nullptr), "group_shares_to_host");
         return v;
     }
+    // Payload vectors are RECYCLED: a fresh 64 MiB std::vector costs 20-25 ms before the first useful byte (mmap, 16 K page faults, zero
+    // fill) -- three times the gate it carries.  Every exchange gives one vector away (it moves into the message) and gets one of the same
+    // size back (the peer's), so the received vector, once consumed, is the next payload of that size: after the first round of a given size
+    // no exchange allocates.  (A Rust caller gets the same from a Vec pool or the Pinned allocator of INTEGRATION.md section 2a.)
+    std::vector<Scalar> take_scalars(size_t count) {
+        for (size_t i = 0; i < spare_.size(); ++i)
+            if (spare_[i].size() == count) { std::vector<Scalar> v = std::move(spare_[i]); spare_.erase(spare_.begin() + i); return v; }
+        return std::vector<Scalar>(count);
+    }
+    void give_back(std::vector<Scalar>&& v) {
+        if (v.empty()) return;
+        if (spare_.size() >= 8) spare_.erase(spare_.begin());
+        spare_.push_back(std::move(v));
+    }
     // the d||e / share-value / MAC-check exchanges: range DMAs to the host, the message, range DMAs back (ids as MpcFabric::exchange_values)
     ShardedBuf exchange(const ShardedBuf& mine, size_t n, size_t segs) {
-        std::vector<Scalar> pay(n * segs);
+        std::vector<Scalar> pay = take_scalars(n * segs);
         gcheck(arkmpc_group_gather_d2h(g_, n, segs, 4, mine.cptrs(), n ? &pay[0].l[0] : nullptr), "group_gather_d2h");
         std::vector<Scalar> peer = f_->exchange_host_values(std::move(pay));
         ShardedBuf r(g_, n, segs, 4);
         gcheck(arkmpc_group_scatter_h2d(g_, n, segs, 4, n ? &peer[0].l[0] : nullptr, r.ptrs()), "group_scatter_h2d");
+        give_back(std::move(peer));
         return r;
     }
     // Beaver multiplication over the group (authenticated_scalar.rs:848-879)
@@ -1496,22 +1516,47 @@ class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
     // payload is a host vector where the network picks it up.  The triples come from the source as host vectors, or are lent in place.
     std::vector<ScalarShare> batch_mul_host(const std::vector<ScalarShare>& x, const std::vector<ScalarShare>& y) {
         if (x.size() != y.size()) throw std::invalid_argument("Cannot operate on batches of different sizes");
-        const size_t n = x.size();
-        if (n == 0) return {};
+        std::vector<ScalarShare> out(x.size());
+        batch_mul_host_into(x.data(), y.data(), x.size(), out.data());
+        return out;
+    }
+    // the same on raw record pointers (x, y: n records each; out: n records the caller owns -- e.g. pinned memory it reuses from gate to gate)
+    void batch_mul_host_into(const ScalarShare* x, const ScalarShare* y, size_t n, ScalarShare* out) {
+        if (n == 0) return;
+        // the triples: lent in place by a source that keeps them in memory; n copies of one record for a constant source (built once per size
+        // in pinned memory and kept: offline_prep.rs:137-158 returns the same Vec every time); else the source's Vecs
+        const ScalarShare *pa = nullptr, *pb = nullptr, *pc = nullptr;
         std::vector<ScalarShare> ha, hb, hc;
-        f_->next_triple_host(n, ha, hb, hc);
-        std::vector<Scalar> my_de(2 * n);
+        ScalarShare ca, cb, cc;
+        if (f_->preprocessing().borrow_triplet_batch(n, &pa, &pb, &pc)) f_->advance_ids(3 * n);
+        else if (f_->preprocessing().constant_triplet(ca, cb, cc)) {
+            if (const_n_ != n) {
+                for (int k = 0; k < 3; ++k) {
+                    if (const_trip_[k]) arkmpc_host_free(const_trip_[k]);
+                    void* q = nullptr;
+                    if (arkmpc_host_alloc(n * sizeof(ScalarShare), &q) != ARKMPC_OK) throw std::runtime_error("arkmpc_host_alloc failed");
+                    const_trip_[k] = static_cast<ScalarShare*>(q);
+                    std::fill(const_trip_[k], const_trip_[k] + n, k == 0 ? ca : (k == 1 ? cb : cc));
+                }
+                const_n_ = n;
+            }
+            pa = const_trip_[0]; pb = const_trip_[1]; pc = const_trip_[2];
+            f_->advance_ids(3 * n);
+        } else {
+            f_->next_triple_host(n, ha, hb, hc);
+            pa = ha.data(); pb = hb.data(); pc = hc.data();
+        }
+        std::vector<Scalar> my_de = take_scalars(2 * n);
         arkmpc_group_hostmul* s = nullptr;
-        gcheck(arkmpc_group_hostmul_begin(g_, n, &x[0].share.l[0], &y[0].share.l[0], &ha[0].share.l[0], &hb[0].share.l[0], &hc[0].share.l[0], &my_de[0].l[0], &s),
+        gcheck(arkmpc_group_hostmul_begin(g_, n, &x[0].share.l[0], &y[0].share.l[0], &pa[0].share.l[0], &pb[0].share.l[0], &pc[0].share.l[0], &my_de[0].l[0], &s),
                "group_hostmul_begin");
         std::vector<Scalar> peer;
         try {
             gcheck(arkmpc_group_hostmul_wait_de(s), "group_hostmul_wait_de");
             peer = f_->exchange_host_values(std::move(my_de));      // (the session's pin on my_de ended with _wait_de: the vector may move into the message)
         } catch (...) { arkmpc_group_hostmul_abort(s); throw; }
-        std::vector<ScalarShare> out(n);
         gcheck(arkmpc_group_hostmul_finish(s, (int)f_->party_id(), f_->mac_key().l, &peer[0].l[0], &out[0].share.l[0]), "group_hostmul_finish");
-        return out;
+        give_back(std::move(peer));
     }
     // open_authenticated_batch over the group (:278-354): opening, MAC-check shares, commit, three exchanges, verification
     GroupOpenResult open_authenticated_batch(const ShardedShares& x, const Scalar& blinder) {
@@ -1544,6 +1589,9 @@ class GroupFabric : public std::enable_shared_from_this<GroupFabric> {
   private:
     std::shared_ptr<MpcFabric> f_;
     arkmpc_group* g_ = nullptr;
+    std::vector<std::vector<Scalar>> spare_;             // payload vectors waiting for their next exchange (take_scalars / give_back)
+    ScalarShare* const_trip_[3] = {nullptr, nullptr, nullptr};   // a constant source's triple batch of const_n_ records each, pinned
+    size_t const_n_ = 0;
 };
 
 // gadgets.rs:105-148 prefix_product: blind in a telescoping manner with inverse pairs, open, scan in public, unblind

@@ -1288,6 +1288,21 @@ def leg_group_end_to_end(pkg, devs, log2n, reps=6):
     grp.close(); eng.close()
     for q in hold:
         lib.arkmpc_host_free(q)
+    # the reference's own bench shape (benches/batch_ops.rs:19-39: share x, share y, batch_mul, open_authenticated_batch; both parties in-process, time =
+    # max over the parties) for a party over this group, through the C++ host mirror (GroupFabric::batch_mul_host + the sharded opening)
+    ref_shape = None
+    exe = os.path.join(ROOT, "ark-mpc_amd", "lib", "arkmpc_host_bench")
+    if os.path.exists(exe):
+        import subprocess
+        try:
+            r_ = subprocess.run([exe, "group_batch_ops", str(n), "2"], capture_output=True, text=True, timeout=300,
+                                env=dict(os.environ, ARKMPC_GROUP_DEVICES=",".join(str(d) for d in devs), ARKMPC_MOCK_LINK="host"))
+            dd = json.loads(r_.stdout.strip().splitlines()[-1])
+            ref_shape = {"ms": dd["seconds"] * 1e3, "elements_per_s": dd["elements_per_s"],
+                         "what": "benches/batch_ops.rs:19-39 as written for n = %d over the group (host/bench_main.cpp group_batch_ops): batch_share_scalar x 2, batch_mul as a group "
+                                 "session on host vectors, open_authenticated_batch on shards (two sequential SHA3-256 sponges over 32 n bytes per party: the floor of this shape)" % n}
+        except Exception as ex:      # noqa: BLE001
+            ref_shape = {"error": repr(ex)[:200]}
     res = {"what": "host arkworks records in -> host records out through ONE group session per batch_mul: n = %d x 2^%d gates per party, member g on gates [g n/G, (g+1) n/G) of the "
                    "same host vectors over its own device's link (arkmpc_group_hostmul_*); vectors pinned by the caller, sessions of the two parties alternating back to back"
                    % (G, log2n),
@@ -1296,7 +1311,7 @@ def leg_group_end_to_end(pkg, devs, log2n, reps=6):
                                    % (distinct, distinct)) if distinct < G else None,
            "ms_per_session": t * 1e3, "ms_each_session": [round(x * 1e3, 3) for x in ts], "party_gates_per_s": n / t,
            "link_up_GBps_sum_over_members": n * E2E_UP_BYTES / t / 1e9, "link_down_GBps_sum_over_members": n * E2E_DOWN_BYTES / t / 1e9,
-           "per_member": per_member, "measured_pcie_one_link": cal,
+           "per_member": per_member, "measured_pcie_one_link": cal, "reference_bench_shape": ref_shape,
            "frac_of_links": (n * E2E_UP_BYTES / t / 1e9) / (cal["h2d_GBps"] * distinct),
            "results_check": "both parties' d||e and result records == the device-resident pipeline's on all %d gates, and == oracle on %s (%d of %d party-gates exact): %s"
                             % (n, "ALL of them" if m_ == n else "the first 2^%d" % int(np.log2(m_)), exact, 2 * m_, "ok" if ok else "FAILED")}
