@@ -86,6 +86,70 @@ extern "C" __attribute__((visibility("hidden"))) ARK_T512 void arkmpc_keccak_abs
     _mm512_mask_storeu_epi64(st + 15, m5, P3); _mm512_mask_storeu_epi64(st + 20, m5, P4);
 }
 
+
+// ---- one lane per vector register (round 5) -----------------------------------------------------------------------------
+// The plane form above pays 17 lane permutations per round for its 5-wide registers, and they sit on the round's critical path.
+// With AVX-512VL the 25 lanes fit in 25 of the 32 xmm registers as plain 64-bit values and a round is 90 operations, none of them
+// a permutation: the column parity is two three-input XORs (vpternlogq 0x96), theta's apply is one more (a ^ c[x-1] ^ rol(c[x+1], 1)),
+// every rho rotation is one vprolq (any count), chi is one vpternlogq 0xD2 per lane, pi is register naming.  Two rounds per loop
+// iteration so the compiler does not have to move lanes back at the loop edge.
+namespace { typedef __m128i V; }
+#define X3(a, b, c) _mm_ternarylogic_epi64(a, b, c, 0x96)
+#define CHI(a, b, c) _mm_ternarylogic_epi64(a, b, c, 0xD2)
+#define ROL(a, n) _mm_rol_epi64(a, n)
+#define LD(p) _mm_loadl_epi64((const __m128i*)(p))
+
+#define ROUND(rc)                                                                                                              \
+    {                                                                                                                          \
+        V c0 = X3(X3(a00, a05, a10), a15, a20), c1 = X3(X3(a01, a06, a11), a16, a21), c2 = X3(X3(a02, a07, a12), a17, a22),     \
+          c3 = X3(X3(a03, a08, a13), a18, a23), c4 = X3(X3(a04, a09, a14), a19, a24);                                           \
+        V r0 = ROL(c0, 1), r1 = ROL(c1, 1), r2 = ROL(c2, 1), r3 = ROL(c3, 1), r4 = ROL(c4, 1);                                  \
+        V b00 = X3(a00, c4, r1), b10 = ROL(X3(a01, c0, r2), 1), b20 = ROL(X3(a02, c1, r3), 62), b05 = ROL(X3(a03, c2, r4), 28), \
+          b15 = ROL(X3(a04, c3, r0), 27);                                                                                      \
+        V b16 = ROL(X3(a05, c4, r1), 36), b01 = ROL(X3(a06, c0, r2), 44), b11 = ROL(X3(a07, c1, r3), 6),                        \
+          b21 = ROL(X3(a08, c2, r4), 55), b06 = ROL(X3(a09, c3, r0), 20);                                                      \
+        V b07 = ROL(X3(a10, c4, r1), 3), b17 = ROL(X3(a11, c0, r2), 10), b02 = ROL(X3(a12, c1, r3), 43),                        \
+          b12 = ROL(X3(a13, c2, r4), 25), b22 = ROL(X3(a14, c3, r0), 39);                                                      \
+        V b23 = ROL(X3(a15, c4, r1), 41), b08 = ROL(X3(a16, c0, r2), 45), b18 = ROL(X3(a17, c1, r3), 15),                       \
+          b03 = ROL(X3(a18, c2, r4), 21), b13 = ROL(X3(a19, c3, r0), 8);                                                       \
+        V b14 = ROL(X3(a20, c4, r1), 18), b24 = ROL(X3(a21, c0, r2), 2), b09 = ROL(X3(a22, c1, r3), 61),                        \
+          b19 = ROL(X3(a23, c2, r4), 56), b04 = ROL(X3(a24, c3, r0), 14);                                                      \
+        a00 = _mm_xor_si128(CHI(b00, b01, b02), LD(&(rc))); a01 = CHI(b01, b02, b03); a02 = CHI(b02, b03, b04);                 \
+        a03 = CHI(b03, b04, b00); a04 = CHI(b04, b00, b01);                                                                    \
+        a05 = CHI(b05, b06, b07); a06 = CHI(b06, b07, b08); a07 = CHI(b07, b08, b09); a08 = CHI(b08, b09, b05); a09 = CHI(b09, b05, b06); \
+        a10 = CHI(b10, b11, b12); a11 = CHI(b11, b12, b13); a12 = CHI(b12, b13, b14); a13 = CHI(b13, b14, b10); a14 = CHI(b14, b10, b11); \
+        a15 = CHI(b15, b16, b17); a16 = CHI(b16, b17, b18); a17 = CHI(b17, b18, b19); a18 = CHI(b18, b19, b15); a19 = CHI(b19, b15, b16); \
+        a20 = CHI(b20, b21, b22); a21 = CHI(b21, b22, b23); a22 = CHI(b22, b23, b24); a23 = CHI(b23, b24, b20); a24 = CHI(b24, b20, b21); \
+    }
+
+extern "C" __attribute__((visibility("hidden"))) ARK_T512 void arkmpc_keccak_absorb136_lanes(uint64_t st[25], const unsigned char* data, size_t nblocks) {
+    V a00 = LD(st + 0), a01 = LD(st + 1), a02 = LD(st + 2), a03 = LD(st + 3), a04 = LD(st + 4), a05 = LD(st + 5), a06 = LD(st + 6),
+      a07 = LD(st + 7), a08 = LD(st + 8), a09 = LD(st + 9), a10 = LD(st + 10), a11 = LD(st + 11), a12 = LD(st + 12), a13 = LD(st + 13),
+      a14 = LD(st + 14), a15 = LD(st + 15), a16 = LD(st + 16), a17 = LD(st + 17), a18 = LD(st + 18), a19 = LD(st + 19), a20 = LD(st + 20),
+      a21 = LD(st + 21), a22 = LD(st + 22), a23 = LD(st + 23), a24 = LD(st + 24);
+    for (size_t blk = 0; blk < nblocks; ++blk, data += 136) {
+#define AB(v, i) v = _mm_xor_si128(v, LD(data + 8 * (i)))
+        AB(a00, 0); AB(a01, 1); AB(a02, 2); AB(a03, 3); AB(a04, 4); AB(a05, 5); AB(a06, 6); AB(a07, 7); AB(a08, 8); AB(a09, 9);
+        AB(a10, 10); AB(a11, 11); AB(a12, 12); AB(a13, 13); AB(a14, 14); AB(a15, 15); AB(a16, 16);
+#undef AB
+        for (int r = 0; r < 24; r += 2) {
+            ROUND(RC[r]);
+            ROUND(RC[r + 1]);
+        }
+    }
+#define ST(v, i) _mm_storel_epi64((__m128i*)(st + (i)), v)
+    ST(a00, 0); ST(a01, 1); ST(a02, 2); ST(a03, 3); ST(a04, 4); ST(a05, 5); ST(a06, 6); ST(a07, 7); ST(a08, 8); ST(a09, 9);
+    ST(a10, 10); ST(a11, 11); ST(a12, 12); ST(a13, 13); ST(a14, 14); ST(a15, 15); ST(a16, 16); ST(a17, 17); ST(a18, 18); ST(a19, 19);
+    ST(a20, 20); ST(a21, 21); ST(a22, 22); ST(a23, 23); ST(a24, 24);
+#undef ST
+}
+
+#undef X3
+#undef CHI
+#undef ROL
+#undef LD
+#undef ROUND
+
 // ---- portable 64-bit code, compiled twice: baseline x86-64 and with BMI1/BMI2 (andn, rorx) ------------------------------
 namespace {
 static inline __attribute__((always_inline)) uint64_t rol64(uint64_t x, int s) { return (x << s) | (x >> (64 - s)); }
@@ -130,4 +194,5 @@ extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_sc
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_bmi(uint64_t*, const unsigned char*, size_t) {}
 extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_avx512(void) { return 0; }
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_avx512(uint64_t*, const unsigned char*, size_t) {}
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_lanes(uint64_t*, const unsigned char*, size_t) {}
 #endif

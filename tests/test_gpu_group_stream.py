@@ -393,14 +393,29 @@ def test_prefetched_triples_feed_a_chain_of_gates(pkg, oracle):
     arena.free()
 
 
-def test_group_sessions_soak_random_sizes_members_and_placements(pkg, eng0):
-    """48 group sessions of random size (1 ... 70 000 gates), member count (1 ... 8, all on device 0) and vector placement (pinned pools /
+def _where_differs(name, got, ref, orc):
+    """which words of a group session's vector differ from the single-context session's, where they lie relative to 4 KiB pages, and which of
+    the two the oracle sides with"""
+    idx = np.nonzero(got != ref)[0]
+    if not idx.size:
+        return "%s equal" % name
+    runs = np.split(idx, np.nonzero(np.diff(idx) > 1)[0] + 1)
+    base = got.ctypes.data
+    return "%s: %d of %d words differ in %d run(s) %s (byte address mod 4096 of the runs' ends: %s); group == oracle: %s, one context == oracle: %s, group words there all zero: %s" % (
+        name, idx.size, got.size, len(runs), [(int(r[0]), int(r[-1])) for r in runs[:6]],
+        [((base + 8 * int(r[0])) % 4096, (base + 8 * int(r[-1]) + 8) % 4096) for r in runs[:6]],
+        bool(np.array_equal(got, orc)), bool(np.array_equal(ref, orc)), bool(np.all(got[idx] == 0)))
+
+
+def test_group_sessions_soak_random_sizes_members_and_placements(pkg, oracle):
+    """24 group sessions of random size (1 ... 70 000 gates), member count (1 ... 8, all on device 0) and vector placement (pinned pools /
     pageable / freshly allocated per session), two parties interleaved, each against a single-context session on the same records (itself
     checked against the oracle elsewhere).  Leaks of events, pins or device blocks show as errors or a growing pool; ordering bugs as wrong words."""
     import random
     fid = 0
     rng = random.Random(515)
     base = 70000
+    eng0 = pkg.Engine(fid, device=0)             # its own context: hostmul_device_bytes_peak is per context, and the module's has run larger sessions
     _, keys, sh = _inputs(fid, base, seed=9950, tile_from=2500)
     arena = _PinnedArena(pkg)
     pinned = {k: (arena.copy(v[0]), arena.copy(v[1])) for k, v in sh.items()}
@@ -432,10 +447,14 @@ def test_group_sessions_soak_random_sizes_members_and_placements(pkg, eng0):
         sub = {nm: (np.ascontiguousarray(sl(sh[nm][0])), np.ascontiguousarray(sl(sh[nm][1]))) for nm in "xyabc"}
         one_de, one_out = _run_two_party(eng0, n, keys, sub)
         for p in (0, 1):
-            assert np.array_equal(de[p], one_de[p]) and np.array_equal(out[p], one_out[p]), (it, n, G, how, o, p)
+            if not (np.array_equal(de[p], one_de[p]) and np.array_equal(out[p], one_out[p])):
+                ode, want = _oracle_two_party(oracle, fid, n, keys, sub)
+                pytest.fail("session %r, party %d: %s" % ((it, n, G, how, o), p, "; ".join(
+                    _where_differs(nm, got, ref, orc) for nm, got, ref, orc in (("d||e", de[p], one_de[p], ode[p]), ("result", out[p], one_out[p], want[p])))))
     for pair in groups.values():
         for g in pair:
             g.close()
     st = eng0.stats()
     assert st["hostmul_device_bytes_peak"] <= 512 * base
+    eng0.close()
     arena.free()

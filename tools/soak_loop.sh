@@ -1,0 +1,14 @@
+#!/bin/bash
+# tools/soak_loop.sh [runs] -- the group-session soak in fresh processes, one line per run (result + seconds); host facts first.
+# Used to chase a box-dependent flake (one failure in ~90 runs, seen only on a box where the run took 10x longer than usual).
+runs=${1:-8}
+mkdir -p gpurun_out/soak
+{
+  echo "host: $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2) | thp=$(cat /sys/kernel/mm/transparent_hugepage/enabled 2>/dev/null) | numa_balancing=$(cat /proc/sys/kernel/numa_balancing 2>/dev/null) | iommu_groups=$(ls /sys/kernel/iommu_groups 2>/dev/null | wc -l) | cmdline=$(cat /proc/cmdline 2>/dev/null | tr ' ' '\n' | grep -E 'iommu|hugepage' | tr '\n' ' ') | mem_free_kb=$(grep -m1 MemAvailable /proc/meminfo | awk '{print $2}')"
+  for i in $(seq 1 "$runs"); do
+    t0=$(date +%s%N)
+    timeout 600 python -m pytest tests/test_gpu_group_stream.py -m gpu -x -q -k soak 2>&1 | grep -E "Failed:|passed|failed|Error" | head -4
+    echo "run $i: $(( ($(date +%s%N) - t0) / 1000000 )) ms"
+  done
+} > gpurun_out/soak/soak_$(date +%s).log 2>&1
+cat gpurun_out/soak/soak_*.log | tail -40
