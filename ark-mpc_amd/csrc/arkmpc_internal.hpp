@@ -147,6 +147,38 @@ static inline bool runtime_knows(const void* p) {
 static inline bool runtime_knows_range(const void* p, size_t bytes) {
     return bytes && runtime_knows(p) && runtime_knows((const char*)p + bytes - 1);
 }
+// Devices this process has (had) a context on: what drain_after_registration() below waits for.
+inline std::atomic<unsigned>& devices_in_use() { static std::atomic<unsigned> m{0}; return m; }
+// DRAIN AFTER REGISTRATION (round 5).  Finding: a kernel (or blit) that reads or writes a caller's vector this library has just registered in
+// place can see stale memory in a few of the vector's pages -- one XCD's workgroups do, another XCD's workgroups reading the same page do not --
+// when the vector's address had been registered, unregistered, freed and handed out again by malloc with NEW physical pages, AND other GPU work of
+// the process is in flight around the registration (the in-process peer's phase, the previous session).  Seen once in ~100 unperturbed runs of
+// the group-session soak (on a box where the run took 10x longer than usual), in a fifth of the runs while another thread keeps the kernel migrating
+// the process's pages between NUMA nodes (probes/group_pageable_race_probe.py: 12 of 30, 6 of 25 repetitions), and in NONE of 80 repetitions once
+// every registration is followed by a wait for the device to go idle -- with or without an extra map + unmap of a page of our own, so it is the
+// wait that matters.  Vectors from arkmpc_host_alloc / hipHostMalloc, and vectors the caller registered once and keeps, are not affected: their
+// translation never changes.  The wait costs nothing on an idle device; back-to-back sessions on pageable vectors lose the overlap of one session's
+// pinning with the previous session's tail.  ARKMPC_PIN_DRAIN=0 turns it off, =2 adds the map + unmap (the probe's control).
+static inline void drain_after_registration() {
+    static const int mode = getenv("ARKMPC_PIN_DRAIN") ? atoi(getenv("ARKMPC_PIN_DRAIN")) : 1;
+    if (!mode) return;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    const unsigned mask = devices_in_use().load(std::memory_order_relaxed);
+    bool moved = false;
+    for (int d = 0; d < 32; ++d) {
+        if (!(mask >> d & 1u)) continue;
+        if (have_cur && d != cur) { if (hipSetDevice(d) != hipSuccess) continue; moved = true; }
+        (void)hipDeviceSynchronize();
+    }
+    if (!mask) (void)hipDeviceSynchronize();
+    if (moved && have_cur) (void)hipSetDevice(cur);
+    if (mode == 2) {
+        static void* page = aligned_alloc(4096, 4096);
+        if (page && hipHostRegister(page, 4096, hipHostRegisterDefault) == hipSuccess) (void)hipHostUnregister(page);
+    }
+    (void)hipGetLastError();
+}
 struct PinRegistry {
     std::mutex mu;
     struct Ent { size_t bytes; int refs; };
@@ -163,6 +195,7 @@ struct PinRegistry {
         if (runtime_knows_range(p, bytes)) return 0;                           // pinned by the caller already (or not host memory)
         if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
         ents[a] = Ent{bytes, 1};
+        drain_after_registration();
         return a;
     }
     // the same for a range already known to be pinned (by the caller, or by an entry of this registry): a reference if it is ours, no runtime calls

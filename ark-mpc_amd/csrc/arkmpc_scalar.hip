@@ -684,6 +684,7 @@ int arkmpc_ctx_create(int field_id, int device, arkmpc_ctx** out_ctx) {
     c->d_vgate = c->d_flag + 8;                         // second word group of the 64-byte device flag block
     if (hipMemset(c->d_flag, 0, 64) != hipSuccess) { (void)hipFree(c->d_flag); (void)hipHostFree(c->h_flag); (void)hipHostFree(c->h_vflag); delete c; return ARKMPC_ERR_HIP; }
     if (device < 16) { std::lock_guard<std::mutex> lk(g_pool[device].mu); g_pool[device].refs++; }
+    if (device < 32) devices_in_use().fetch_or(1u << device, std::memory_order_relaxed);
     *out_ctx = c;
     return ARKMPC_OK;
 }
