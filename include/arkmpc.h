@@ -274,7 +274,10 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
  * (hipHostRegister; skipped for buffers that are already pinned).  A caller that keeps its vectors across calls pins them once, and
  * gets the faster form for it: a phase whose vectors are all pinned (and 16-byte aligned) runs with NO copies -- one kernel reads the
  * records where they lie in host memory and writes the payload / result vector in place (7.3 instead of 8.1 ms per 2^20 gates, 0.97 of
- * the link).  Same words either way; sessions with several open on one context (both parties of an in-process run) are supported. */
+ * the link).  Same words either way; sessions with several open on one context (both parties of an in-process run) are supported.
+ * Every in-place registration -- the library's own per call, and arkmpc_host_register -- is followed by a wait for the devices this process
+ * uses to go idle (a kernel could otherwise read stale memory through a vector whose address had an earlier registered life: DESIGN section 4;
+ * ARKMPC_PIN_DRAIN=0 turns the wait off).  Vectors from arkmpc_host_alloc, or registered once and kept, never pay it: register once, not per gate. */
 int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK */
 int arkmpc_host_unregister(void* ptr);
 int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc), RECYCLED: a freed block comes back from a free list by size */
