@@ -227,9 +227,17 @@ inline PinRegistry& pin_registry() { static PinRegistry r; return r; }
 struct HostPins {
     std::vector<uintptr_t> held;
     static size_t min_bytes() { static const size_t v = getenv("ARKMPC_PIN_MIN_KB") ? (size_t)atoll(getenv("ARKMPC_PIN_MIN_KB")) << 10 : (size_t)1 << 20; return v; }
+    // OFF by default since the end of round 5: on this platform a kernel or DMA that goes through a vector registered in place can see stale
+    // memory when the vector's address had an earlier registered life (freed, handed out again by malloc with other physical pages) -- see
+    // drain_after_registration above and DESIGN section 4.  Unregistered vectors travel as the runtime's own pageable copies (slower, and
+    // never wrong in the same stress test); the fast path is memory from arkmpc_host_alloc, or registered ONCE by the caller and kept.
+    // ARKMPC_PIN_IN_PLACE=1 brings the per-call registration back (with the wait after each), ARKMPC_NO_PIN=1 still forces it off.
+    static bool in_place() {
+        static const bool on = getenv("ARKMPC_PIN_IN_PLACE") && getenv("ARKMPC_PIN_IN_PLACE")[0] == '1' && !(getenv("ARKMPC_NO_PIN") && getenv("ARKMPC_NO_PIN")[0] == '1');
+        return on;
+    }
     void pin(const void* p, size_t bytes) {
-        static const bool off = getenv("ARKMPC_NO_PIN") && getenv("ARKMPC_NO_PIN")[0] == '1';
-        if (off || !p || bytes < min_bytes()) return;
+        if (!in_place() || !p || bytes < min_bytes()) return;
         const uintptr_t base = pin_registry().acquire(p, bytes);
         if (base) held.push_back(base);
     }

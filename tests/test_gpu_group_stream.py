@@ -7,6 +7,9 @@
   * group transfers from pinned host memory (in-place import kernel for split columns);
   * asynchronous batch imports (arkmpc_batch_from_host_async / _acquire / _host_release)."""
 import ctypes
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -322,7 +325,10 @@ def test_batch_from_host_async_equals_the_blocking_import(pkg, layout, how):
     after = e.stats()
     assert np.array_equal(got, want_rec)
     went_async = after["batch_async_imports"] - before["batch_async_imports"]
-    assert went_async == (0 if how == "small" else 1) and after["batch_blocking_imports"] - before["batch_blocking_imports"] == 1 - went_async
+    # a pageable vector is registered in place only with ARKMPC_PIN_IN_PLACE=1; by default it takes the blocking import
+    in_place = os.environ.get("ARKMPC_PIN_IN_PLACE") == "1"
+    assert went_async == (0 if how == "small" or (how == "pageable" and not in_place) else 1)
+    assert after["batch_blocking_imports"] - before["batch_blocking_imports"] == 1 - went_async
     # the columns themselves (split): share column then MAC column
     if layout == "split":
         sp, mp, stride = e.batch_ptrs(b)
@@ -458,3 +464,24 @@ def test_group_sessions_soak_random_sizes_members_and_placements(pkg, oracle):
     assert st["hostmul_device_bytes_peak"] <= 512 * base
     eng0.close()
     arena.free()
+
+
+def test_opt_in_registration_in_place_still_produces_the_same_words():
+    """ARKMPC_PIN_IN_PLACE=1 (the per-call hipHostRegister of pageable vectors, off by default since the end of round 5: DESIGN section 4) is read
+    once per process, so the session, group-session and import tests that involve pageable vectors run again in a child with it set"""
+    env = dict(os.environ, ARKMPC_PIN_IN_PLACE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+           os.path.join(here, "test_gpu_stream.py"), os.path.join(here, "test_gpu_group_stream.py"),
+           "-k", "(bitexact_vs_oracle or mixed_zero_copy or oversubscribed or batch_from_host_async or fresh or pageable) and not opt_in"]
+    # This path is the one with the platform hazard (about one run in a hundred reads stale memory, or aborts, on an otherwise idle box): a
+    # logic error in it fails every attempt, the hazard does not -- up to three attempts, the count is reported.
+    tails = []
+    for attempt in range(3):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0:
+            if attempt:
+                print("opt-in in-place registration: passed on attempt %d; earlier: %s" % (attempt + 1, tails))
+            return
+        tails.append((r.stdout[-1500:] + r.stderr[-500:]).strip())
+    pytest.fail("three attempts failed:\n" + "\n-----\n".join(tails))
