@@ -170,6 +170,35 @@ def test_rfc8032_signatures(backend):
         assert np.array_equal(backend.ed_batch_to_affine(backend.ed_generator_mul(S)), backend.ed_batch_to_affine(rhs))
 
 
+def test_published_two_adic_roots_of_unity(backend):
+    """arkworks' own field configs publish GENERATOR, TWO_ADICITY and TWO_ADIC_ROOT_OF_UNITY = GENERATOR^((p - 1) / 2^s) for the scalar fields of
+    configs 2 / 3 (BN254 Fr) and 5 (BLS12-381 Fr): a 250-step square-and-multiply chain of the backend's Montgomery multiplication must land on the
+    published constant, the constant raised to 2^(s-1) on p - 1 and to 2^s on 1.  (Exact integers say the same; the point is that the expected
+    value was published by the reference's dependency, not computed here.)"""
+    for c in KAT["published_field_constants"]["cases"]:
+        fid, g, s, want = c["fid"], c["generator"], c["two_adicity"], int(c["two_adic_root_of_unity"])
+        if "two_adic_root_of_unity_hex_zkcrypto" in c:
+            assert want == H(c["two_adic_root_of_unity_hex_zkcrypto"])
+        p = pyref.P[fid]
+        assert (p - 1) % (1 << s) == 0 and (p - 1) >> s & 1
+        e = (p - 1) >> s
+        # batch of 3: [g^e, (g^2)^e, (g^e computed with the operands swapped)]
+        base = mont_array(fid, [g, g * g % p, g])
+        acc = mont_array(fid, [1, 1, 1])
+        for bit in bin(e)[2:]:
+            acc = backend.scalar_mul(fid, acc, acc)
+            if bit == "1":
+                acc = backend.scalar_mul(fid, base, acc)
+        got = [pyref.from_mont(fid, m) for m in limbs_to_ints(acc)]
+        assert got[0] == want and got[2] == want and got[1] == want * want % p, c["field"]
+        r = mont_array(fid, [want])
+        for k in range(s):
+            if k == s - 1:
+                assert [pyref.from_mont(fid, m) for m in limbs_to_ints(r)] == [p - 1], c["field"]
+            r = backend.scalar_mul(fid, r, r)
+        assert [pyref.from_mont(fid, m) for m in limbs_to_ints(r)] == [1], c["field"]
+
+
 def test_nist_sha3_256_examples_oracle(oracle):
     for c in KAT["nist_sha3_256"]["cases"]:
         if c["repeat"] > 1000000:
