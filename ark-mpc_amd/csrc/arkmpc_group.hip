@@ -63,6 +63,37 @@ inline void range(const arkmpc_group* g, size_t n, int m, size_t* lo, size_t* cn
     const size_t b = (size_t)(((unsigned __int128)n * (unsigned)(m + 1)) / (unsigned)g->G);
     *lo = a; *cnt = b - a;
 }
+
+// PAGEABLE host vectors and N links.  The library no longer registers a caller's vector per call, so a pageable vector travels
+// as the runtime's pageable copies -- and those run ON THE CALLING THREAD (the runtime stages or pins the memory itself and returns when the copy
+// is done).  Issued member after member from one thread they use one link at a time, which is what the round-4 review objected to.  So when the
+// members sit on DISTINCT devices, the member calls that touch a pageable vector are made from one short-lived host thread per member: each
+// thread blocks in its own member's copies, all links run.  Members that share a device (the one-GPU test box) share a link and gain nothing:
+// they keep the single thread.  ARKMPC_GROUP_THREADS=1 forces the threads (the tests do, in a child process), =0 forbids them.  Pinned vectors
+// never need this: their member calls only enqueue.
+inline bool members_in_threads(const arkmpc_group* g) {
+    static const int env = getenv("ARKMPC_GROUP_THREADS") ? atoi(getenv("ARKMPC_GROUP_THREADS")) : -1;
+    if (env == 0 || g->G < 2) return false;
+    if (env > 0) return true;
+    for (int m = 1; m < g->G; ++m) if (g->dev[m] != g->dev[0]) return true;
+    return false;
+}
+inline bool pageable_host(const arkmpc_group* g, const void* p, size_t bytes) {
+    return p && bytes && classify(g->ctx[0], p, bytes).kind == Mem::Pageable;
+}
+// fn(m) for every member: in G threads (joined before returning) or in a loop.  fn reports through its own per-member slots.
+template <class F> void for_members(arkmpc_group* g, bool threads, F fn) {
+    int started = 0;
+    std::vector<std::thread> th;
+    if (threads) {
+        try {
+            th.reserve(g->G);
+            for (; started < g->G; ++started) th.emplace_back([&fn, started] { fn(started); });
+        } catch (...) {}                                  // (no more threads to be had: the rest runs here)
+    }
+    for (int m = started; m < g->G; ++m) fn(m);
+    for (auto& t : th) t.join();
+}
 inline bool layout_ok(int layout) { return layout == ARKMPC_LAYOUT_AOS || layout == ARKMPC_LAYOUT_SPLIT; }
 // share / MAC column view of member m's shard of a ScalarShare vector
 struct ShareView { const u64* s; const u64* m; size_t stride; };
@@ -245,7 +276,27 @@ static int host_xfer(arkmpc_group* g, bool to_device, size_t n, size_t segs, siz
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
     HostPins pins;
-    if (n) pins.pin(to_device ? (const void*)host_c : (const void*)host_m, segs * n * ew * 8);
+    const void* hp = to_device ? (const void*)host_c : (const void*)host_m;
+    if (n) pins.pin(hp, segs * n * ew * 8);
+    if (n && members_in_threads(g) && pageable_host(g, hp, segs * n * ew * 8)) {
+        // pageable copies block their caller: one thread per member, so that every member's link is busy (see members_in_threads)
+        std::vector<int> bad(g->G, 0);
+        for_members(g, true, [&](int m) {
+            size_t lo, cnt; range(g, n, m, &lo, &cnt);
+            if (!cnt) return;
+            bool ok = hipSetDevice(g->dev[m]) == hipSuccess;
+            for (size_t sgm = 0; sgm < segs && ok; ++sgm) {
+                u64* d = shards[m] + sgm * cnt * ew;
+                const size_t hoff = (sgm * n + lo) * ew;
+                ok = (to_device ? hipMemcpyAsync(d, host_c + hoff, cnt * ew * 8, hipMemcpyHostToDevice, g->ctx[m]->stream)
+                                : hipMemcpyAsync(host_m + hoff, d, cnt * ew * 8, hipMemcpyDeviceToHost, g->ctx[m]->stream)) == hipSuccess;
+            }
+            ok = ok && hipStreamSynchronize(g->ctx[m]->stream) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); bad[m] = 1; }
+        });
+        for (int m = 0; m < g->G; ++m) if (bad[m]) { gset_err(g, "member " + std::to_string(m) + ": host transfer failed"); return ARKMPC_ERR_HIP; }
+        return ARKMPC_OK;
+    }
     for (int m = 0; m < g->G; ++m) {
         size_t lo, cnt; range(g, n, m, &lo, &cnt);
         if (!cnt) continue;
@@ -381,13 +432,17 @@ int arkmpc_group_hostmul_begin(arkmpc_group* g, size_t n, const uint64_t* x, con
     s->ses.assign(g->G, nullptr);
     const size_t rec = n * 64;
     if (n) { s->pins_in.pin(x, rec); s->pins_in.pin(y, rec); s->pins_in.pin(a, rec); s->pins_in.pin(b, rec); s->pins_de.pin(out_de, rec); }
-    for (int m = 0; m < g->G; ++m) {
+    // a phase whose vectors are pageable is made of blocking copies: one thread per member then (members_in_threads)
+    const bool thr = n && members_in_threads(g) && (pageable_host(g, x, rec) || pageable_host(g, y, rec) || pageable_host(g, a, rec) || pageable_host(g, b, rec) ||
+                                                     pageable_host(g, out_de, rec));
+    std::vector<int> rcs(g->G, ARKMPC_OK);
+    for_members(g, thr, [&](int m) {
         size_t lo, cnt; range(g, n, m, &lo, &cnt);
-        if (!cnt) continue;
-        const int rc = arkmpc_hostmul_begin_range(g->ctx[m], cnt, x + 8 * lo, y + 8 * lo, a + 8 * lo, b + 8 * lo, c + 8 * lo, out_de + 4 * lo, out_de + 4 * (n + lo),
-                                                  ARKMPC_HOSTMUL_NO_PIN, &s->ses[m]);
-        if (rc) return ghm_end_all(s, gfail(g, m, rc, "arkmpc_hostmul_begin_range"));
-    }
+        if (!cnt) return;
+        rcs[m] = arkmpc_hostmul_begin_range(g->ctx[m], cnt, x + 8 * lo, y + 8 * lo, a + 8 * lo, b + 8 * lo, c + 8 * lo, out_de + 4 * lo, out_de + 4 * (n + lo),
+                                            ARKMPC_HOSTMUL_NO_PIN, &s->ses[m]);
+    });
+    for (int m = 0; m < g->G; ++m) if (rcs[m]) return ghm_end_all(s, gfail(g, m, rcs[m], "arkmpc_hostmul_begin_range"));
     if (n) s->pins_c.pin(c, rec);                          // under the members' phase 1: c is not looked at before _wait_de / _finish
     *out_session = s;
     return ARKMPC_OK;
@@ -426,11 +481,15 @@ int arkmpc_group_hostmul_finish(arkmpc_group_hostmul* s, int party_id, const uin
     else if (!mac_key) rc = gbad(g, "null mac_key");
     else if (n && (!peer_de || !out)) rc = gbad(g, "null pointer");
     if (!rc && n) { s->pins_peer.pin(peer_de, n * 64); s->pins_out.pin(out, n * 64); }
-    for (int m = 0; m < g->G && !rc; ++m) {                // phase 2 of every member enqueued before any of them is waited for
-        size_t lo, cnt; range(g, n, m, &lo, &cnt);
-        if (!cnt) continue;
-        const int r = arkmpc_hostmul_finish_async(s->ses[m], party_id, mac_key, peer_de + 4 * lo, peer_de + 4 * (n + lo), out + 8 * lo);
-        if (r) rc = gfail(g, m, r, "arkmpc_hostmul_finish_async");
+    if (!rc) {                                             // phase 2 of every member enqueued (or, for pageable vectors, copied by its own thread) before any of them is waited for
+        const bool thr = n && members_in_threads(g) && (pageable_host(g, peer_de, n * 64) || pageable_host(g, out, n * 64));
+        std::vector<int> rcs(g->G, ARKMPC_OK);
+        for_members(g, thr, [&](int m) {
+            size_t lo, cnt; range(g, n, m, &lo, &cnt);
+            if (!cnt) return;
+            rcs[m] = arkmpc_hostmul_finish_async(s->ses[m], party_id, mac_key, peer_de + 4 * lo, peer_de + 4 * (n + lo), out + 8 * lo);
+        });
+        for (int m = 0; m < g->G; ++m) if (rcs[m] && !rc) rc = gfail(g, m, rcs[m], "arkmpc_hostmul_finish_async");
     }
     return ghm_end_all(s, rc);
 }

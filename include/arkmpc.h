@@ -561,7 +561,8 @@ int arkmpc_group_shares_to_host(arkmpc_group* grp, int layout, size_t n, const u
  * a, b, c = n ScalarShare records each in HOST memory, out_de / peer_de = 2n Scalars (d then e), out = n records.  Member g runs gates
  * [g n/G, (g+1) n/G) of the same vectors as a range session on its own device and PCIe link; vectors from arkmpc_host_alloc /
  * arkmpc_host_register are read and written in place -- the form that reaches the links' rate -- (pageable ones travel as the runtime's pageable
- * copies, member after member, unless ARKMPC_PIN_IN_PLACE=1 has the call register them once, whole), and because the member
+ * copies, which block their caller: with members on distinct devices each member's calls are then made from a host thread of its own so that
+ * all links run; ARKMPC_PIN_IN_PLACE=1 has the call register them once, whole, instead), and because the member
  * calls only enqueue, all G links are busy together from one host thread.  Host-fed, a party is link-bound 20x below the kernels' rate, so the
  * links are what more GPUs add.  _begin returns once phase 1 is enqueued on every member; _poll_de = leading gates of d AND e complete in out_de
  * (members in range order); _wait_de blocks until all of out_de is (it is the caller's again afterwards); _finish blocks until `out` is

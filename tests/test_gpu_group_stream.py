@@ -485,3 +485,18 @@ def test_opt_in_registration_in_place_still_produces_the_same_words():
             return
         tails.append((r.stdout[-1500:] + r.stderr[-500:]).strip())
     pytest.fail("three attempts failed:\n" + "\n-----\n".join(tails))
+
+
+def test_group_members_in_threads_for_pageable_vectors():
+    """ARKMPC_GROUP_THREADS=1: the member calls that touch a pageable vector run in one host thread per member (what the group does by itself
+    when its members sit on distinct devices -- pageable copies block their caller, so this is what keeps N links busy without registering the
+    caller's memory).  The variable is read once per process: the group tests run again in a child with it set, members sharing device 0, and
+    the C99 group caller too."""
+    env = dict(os.environ, ARKMPC_GROUP_THREADS="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_group_stream.py"), os.path.join(here, "test_group.py"),
+                        "-k", "group and not opt_in and not in_threads and not distinct"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
