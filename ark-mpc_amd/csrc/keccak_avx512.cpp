@@ -144,11 +144,55 @@ extern "C" __attribute__((visibility("hidden"))) ARK_T512 void arkmpc_keccak_abs
 #undef ST
 }
 
+// The same round scheduled ROW BY ROW (round 5, late): theta's D in five registers, then for each row of the new state its five B values and
+// the row's chi at once -- five B values live at a time instead of twenty-five, so the 25 lanes + C + D fit the 32 registers without spills.
+// 95 operations instead of 90 (the three-input fold of theta's apply is given up for the shorter live ranges) and still faster on Zen 5:
+// 0.82 GB/s built with g++, 0.87 with ROCm's clang++ against 0.77 for the form above (probes/keccak_lanes_probe.cpp).
+#define ROUND2(rc) { \
+  V c0 = X3(X3(a00, a05, a10), a15, a20), c1 = X3(X3(a01, a06, a11), a16, a21), c2 = X3(X3(a02, a07, a12), a17, a22), c3 = X3(X3(a03, a08, a13), a18, a23), c4 = X3(X3(a04, a09, a14), a19, a24); \
+  V d0 = _mm_xor_si128(c4, ROL(c1, 1)), d1 = _mm_xor_si128(c0, ROL(c2, 1)), d2 = _mm_xor_si128(c1, ROL(c3, 1)), d3 = _mm_xor_si128(c2, ROL(c4, 1)), d4 = _mm_xor_si128(c3, ROL(c0, 1)); \
+  { V b0 = _mm_xor_si128(a00, d0), b1 = ROL(_mm_xor_si128(a06, d1), 44), b2 = ROL(_mm_xor_si128(a12, d2), 43), b3 = ROL(_mm_xor_si128(a18, d3), 21), b4 = ROL(_mm_xor_si128(a24, d4), 14); \
+    n00 = CHI(b0, b1, b2); n01 = CHI(b1, b2, b3); n02 = CHI(b2, b3, b4); n03 = CHI(b3, b4, b0); n04 = CHI(b4, b0, b1); } \
+  { V b0 = ROL(_mm_xor_si128(a03, d3), 28), b1 = ROL(_mm_xor_si128(a09, d4), 20), b2 = ROL(_mm_xor_si128(a10, d0), 3), b3 = ROL(_mm_xor_si128(a16, d1), 45), b4 = ROL(_mm_xor_si128(a22, d2), 61); \
+    n05 = CHI(b0, b1, b2); n06 = CHI(b1, b2, b3); n07 = CHI(b2, b3, b4); n08 = CHI(b3, b4, b0); n09 = CHI(b4, b0, b1); } \
+  { V b0 = ROL(_mm_xor_si128(a01, d1), 1), b1 = ROL(_mm_xor_si128(a07, d2), 6), b2 = ROL(_mm_xor_si128(a13, d3), 25), b3 = ROL(_mm_xor_si128(a19, d4), 8), b4 = ROL(_mm_xor_si128(a20, d0), 18); \
+    n10 = CHI(b0, b1, b2); n11 = CHI(b1, b2, b3); n12 = CHI(b2, b3, b4); n13 = CHI(b3, b4, b0); n14 = CHI(b4, b0, b1); } \
+  { V b0 = ROL(_mm_xor_si128(a04, d4), 27), b1 = ROL(_mm_xor_si128(a05, d0), 36), b2 = ROL(_mm_xor_si128(a11, d1), 10), b3 = ROL(_mm_xor_si128(a17, d2), 15), b4 = ROL(_mm_xor_si128(a23, d3), 56); \
+    n15 = CHI(b0, b1, b2); n16 = CHI(b1, b2, b3); n17 = CHI(b2, b3, b4); n18 = CHI(b3, b4, b0); n19 = CHI(b4, b0, b1); } \
+  { V b0 = ROL(_mm_xor_si128(a02, d2), 62), b1 = ROL(_mm_xor_si128(a08, d3), 55), b2 = ROL(_mm_xor_si128(a14, d4), 39), b3 = ROL(_mm_xor_si128(a15, d0), 41), b4 = ROL(_mm_xor_si128(a21, d1), 2); \
+    n20 = CHI(b0, b1, b2); n21 = CHI(b1, b2, b3); n22 = CHI(b2, b3, b4); n23 = CHI(b3, b4, b0); n24 = CHI(b4, b0, b1); } \
+  n00 = _mm_xor_si128(n00, LD(&(rc))); \
+  a00 = n00; a01 = n01; a02 = n02; a03 = n03; a04 = n04; a05 = n05; a06 = n06; a07 = n07; a08 = n08; a09 = n09; a10 = n10; a11 = n11; a12 = n12; a13 = n13; a14 = n14; a15 = n15; a16 = n16; a17 = n17; a18 = n18; a19 = n19; a20 = n20; a21 = n21; a22 = n22; a23 = n23; a24 = n24; \
+}
+extern "C" __attribute__((visibility("hidden"))) ARK_T512 void arkmpc_keccak_absorb136_rows(uint64_t st[25], const unsigned char* data, size_t nblocks) {
+    V a00 = LD(st + 0), a01 = LD(st + 1), a02 = LD(st + 2), a03 = LD(st + 3), a04 = LD(st + 4), a05 = LD(st + 5), a06 = LD(st + 6),
+      a07 = LD(st + 7), a08 = LD(st + 8), a09 = LD(st + 9), a10 = LD(st + 10), a11 = LD(st + 11), a12 = LD(st + 12), a13 = LD(st + 13),
+      a14 = LD(st + 14), a15 = LD(st + 15), a16 = LD(st + 16), a17 = LD(st + 17), a18 = LD(st + 18), a19 = LD(st + 19), a20 = LD(st + 20),
+      a21 = LD(st + 21), a22 = LD(st + 22), a23 = LD(st + 23), a24 = LD(st + 24);
+    V n00, n01, n02, n03, n04, n05, n06, n07, n08, n09, n10, n11, n12, n13, n14, n15, n16, n17, n18, n19, n20, n21, n22, n23, n24;
+    for (size_t blk = 0; blk < nblocks; ++blk, data += 136) {
+#define AB(v, i) v = _mm_xor_si128(v, LD(data + 8 * (i)))
+        AB(a00, 0); AB(a01, 1); AB(a02, 2); AB(a03, 3); AB(a04, 4); AB(a05, 5); AB(a06, 6); AB(a07, 7); AB(a08, 8); AB(a09, 9);
+        AB(a10, 10); AB(a11, 11); AB(a12, 12); AB(a13, 13); AB(a14, 14); AB(a15, 15); AB(a16, 16);
+#undef AB
+        for (int r = 0; r < 24; r += 2) {
+            ROUND2(RC[r]);
+            ROUND2(RC[r + 1]);
+        }
+    }
+#define ST(v, i) _mm_storel_epi64((__m128i*)(st + (i)), v)
+    ST(a00, 0); ST(a01, 1); ST(a02, 2); ST(a03, 3); ST(a04, 4); ST(a05, 5); ST(a06, 6); ST(a07, 7); ST(a08, 8); ST(a09, 9);
+    ST(a10, 10); ST(a11, 11); ST(a12, 12); ST(a13, 13); ST(a14, 14); ST(a15, 15); ST(a16, 16); ST(a17, 17); ST(a18, 18); ST(a19, 19);
+    ST(a20, 20); ST(a21, 21); ST(a22, 22); ST(a23, 23); ST(a24, 24);
+#undef ST
+}
+
 #undef X3
 #undef CHI
 #undef ROL
 #undef LD
 #undef ROUND
+#undef ROUND2
 
 // ---- portable 64-bit code, compiled twice: baseline x86-64 and with BMI1/BMI2 (andn, rorx) ------------------------------
 namespace {
@@ -195,4 +239,5 @@ extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_bm
 extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_avx512(void) { return 0; }
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_avx512(uint64_t*, const unsigned char*, size_t) {}
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_lanes(uint64_t*, const unsigned char*, size_t) {}
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_rows(uint64_t*, const unsigned char*, size_t) {}
 #endif

@@ -64,11 +64,12 @@ inline void absorb136(uint64_t* st, const unsigned char* blk) {
 
 // Inner loops from keccak_avx512.cpp.  Which one is fastest depends on the host (measured: the AVX-512 form wins 1.7x on a
 // 2.1 GHz Xeon, the 64-bit form compiled with BMI wins on EPYC 9575F), so the first multi-block update times each candidate
-// on 64 blocks and keeps the winner.  ARKMPC_KECCAK=portable|scalar|bmi|avx512|lanes forces one.
+// on 64 blocks and keeps the winner.  ARKMPC_KECCAK=portable|scalar|bmi|avx512|lanes|rows forces one.
 extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_avx512(void);
 extern "C" __attribute__((visibility("hidden"))) int arkmpc_cpu_has_bmi(void);
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_avx512(uint64_t st[25], const unsigned char* data, size_t nblocks);
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_lanes(uint64_t st[25], const unsigned char* data, size_t nblocks);
+extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_rows(uint64_t st[25], const unsigned char* data, size_t nblocks);
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_scalar(uint64_t st[25], const unsigned char* data, size_t nblocks);
 extern "C" __attribute__((visibility("hidden"))) void arkmpc_keccak_absorb136_bmi(uint64_t st[25], const unsigned char* data, size_t nblocks);
 typedef void (*absorb_fn)(uint64_t*, const unsigned char*, size_t);
@@ -79,7 +80,8 @@ absorb_fn pick_absorb() {
     struct Cand { const char* name; absorb_fn fn; bool ok; };
     const Cand cands[] = {{"portable", absorb136_portable, true}, {"scalar", arkmpc_keccak_absorb136_scalar, sizeof(void*) == 8},
                           {"bmi", arkmpc_keccak_absorb136_bmi, arkmpc_cpu_has_bmi() != 0}, {"avx512", arkmpc_keccak_absorb136_avx512, arkmpc_cpu_has_avx512() != 0},
-                          {"lanes", arkmpc_keccak_absorb136_lanes, arkmpc_cpu_has_avx512() != 0}};
+                          {"lanes", arkmpc_keccak_absorb136_lanes, arkmpc_cpu_has_avx512() != 0},
+                          {"rows", arkmpc_keccak_absorb136_rows, arkmpc_cpu_has_avx512() != 0}};
     if (const char* force = getenv("ARKMPC_KECCAK"))
         for (const Cand& c : cands) if (c.ok && !strcmp(force, c.name)) return c.fn;
     static unsigned char probe[64 * 136];

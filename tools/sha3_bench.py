@@ -15,5 +15,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps({"inner_loop": os.environ.get("ARKMPC_KECCAK", "auto (timed at first use)"), "GBps": len(m) / t / 1e9,
                       "hashlib_openssl_GBps": len(m) / th / 1e9}))
 else:
-    for env in ({}, {"ARKMPC_KECCAK": "portable"}, {"ARKMPC_KECCAK": "scalar"}, {"ARKMPC_KECCAK": "bmi"}, {"ARKMPC_KECCAK": "avx512"}, {"ARKMPC_KECCAK": "lanes"}):
+    for env in ({}, {"ARKMPC_KECCAK": "portable"}, {"ARKMPC_KECCAK": "scalar"}, {"ARKMPC_KECCAK": "bmi"}, {"ARKMPC_KECCAK": "avx512"}, {"ARKMPC_KECCAK": "lanes"}, {"ARKMPC_KECCAK": "rows"}):
         print(subprocess.run([sys.executable, __file__, "child"], env={**os.environ, **env}, capture_output=True, text=True).stdout.strip())
