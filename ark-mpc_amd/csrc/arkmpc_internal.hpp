@@ -149,18 +149,14 @@ static inline bool runtime_knows_range(const void* p, size_t bytes) {
 }
 // Devices this process has (had) a context on: what drain_after_registration() below waits for.
 inline std::atomic<unsigned>& devices_in_use() { static std::atomic<unsigned> m{0}; return m; }
-// DRAIN AFTER REGISTRATION (round 5).  Finding: a kernel (or blit) that reads or writes a caller's vector this library has just registered in
-// place can see stale memory in a few of the vector's pages -- one XCD's workgroups do, another XCD's workgroups reading the same page do not --
-// when the vector's address had been registered, unregistered, freed and handed out again by malloc with NEW physical pages, AND other GPU work of
-// the process is in flight around the registration (the in-process peer's phase, the previous session).  Seen once in ~100 unperturbed runs of
-// the group-session soak (on a box where the run took 10x longer than usual), in a fifth of the runs while another thread keeps the kernel migrating
-// the process's pages between NUMA nodes (probes/group_pageable_race_probe.py: 12 of 30, 6 of 25 repetitions), and in NONE of 80 repetitions once
-// every registration is followed by a wait for the device to go idle -- with or without an extra map + unmap of a page of our own, so it is the
-// wait that matters.  Vectors from arkmpc_host_alloc / hipHostMalloc, and vectors the caller registered once and keeps, are not affected: their
-// translation never changes.  The wait costs nothing on an idle device; back-to-back sessions on pageable vectors lose the overlap of one session's
-// pinning with the previous session's tail.  ARKMPC_PIN_DRAIN=0 turns it off, =2 adds the map + unmap (the probe's control).
+// WAIT AFTER REGISTRATION (round 5; opt-in, ARKMPC_PIN_DRAIN=1, =2 adds a map + unmap of a page of our own).  Chasing a flaky soak showed that a
+// KERNEL which addresses in place a caller's vector that this library registered itself can read stale memory in a few of the vector's pages when
+// the vector's address had an earlier registered life (freed, handed out again by malloc with other physical pages) -- DESIGN section 4,
+// probes/group_pageable_race_probe.py.  Waiting for the device after every registration shrank that window (0 failures in 80 stress repetitions,
+// then 9 in 30 on another box) without closing it; what closed it is not letting kernels address such vectors at all (Place::zc below: they
+// travel by DMA, 0 failures in 30 repetitions with the registrations still made).  The wait is kept as a switch for the probe.
 static inline void drain_after_registration() {
-    static const int mode = getenv("ARKMPC_PIN_DRAIN") ? atoi(getenv("ARKMPC_PIN_DRAIN")) : 1;
+    static const int mode = getenv("ARKMPC_PIN_DRAIN") ? atoi(getenv("ARKMPC_PIN_DRAIN")) : 0;
     if (!mode) return;
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
@@ -208,6 +204,15 @@ struct PinRegistry {
         if (a >= it->first && a + bytes <= it->first + it->second.bytes) { it->second.refs++; return it->first; }
         return 0;
     }
+    // is [p, p + bytes) inside a range THIS LIBRARY registered (no reference taken)?
+    bool covers(const void* p, size_t bytes) {
+        const uintptr_t a = (uintptr_t)p;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = ents.upper_bound(a);
+        if (it == ents.begin()) return false;
+        --it;
+        return a >= it->first && a + bytes <= it->first + it->second.bytes;
+    }
     void release(uintptr_t base) {
         std::lock_guard<std::mutex> lk(mu);
         auto it = ents.find(base);
@@ -227,14 +232,12 @@ inline PinRegistry& pin_registry() { static PinRegistry r; return r; }
 struct HostPins {
     std::vector<uintptr_t> held;
     static size_t min_bytes() { static const size_t v = getenv("ARKMPC_PIN_MIN_KB") ? (size_t)atoll(getenv("ARKMPC_PIN_MIN_KB")) << 10 : (size_t)1 << 20; return v; }
-    // OFF by default since the end of round 5: on this platform a kernel or DMA that goes through a vector registered in place can see stale
-    // memory when the vector's address had an earlier registered life (freed, handed out again by malloc with other physical pages) -- see
-    // drain_after_registration above and DESIGN section 4.  Unregistered vectors travel as the runtime's own pageable copies (slower, and
-    // never wrong in the same stress test); the fast path is memory from arkmpc_host_alloc, or registered ONCE by the caller and kept.
-    // ARKMPC_PIN_IN_PLACE=1 brings the per-call registration back (with the wait after each), ARKMPC_NO_PIN=1 still forces it off.
+    // Per-call registration of a caller's pageable vector, for the DMA copy pipeline (true asynchronous DMAs instead of the runtime's blocking
+    // pageable copies: 8.2 instead of 13.2 ms per 2^20-gate session).  On by default; what is NOT done any more with such a vector is letting a
+    // kernel address it in place (Place::zc).  ARKMPC_PIN_IN_PLACE=0 or ARKMPC_NO_PIN=1: never register (the runtime's pageable copies).
     static bool in_place() {
-        static const bool on = getenv("ARKMPC_PIN_IN_PLACE") && getenv("ARKMPC_PIN_IN_PLACE")[0] == '1' && !(getenv("ARKMPC_NO_PIN") && getenv("ARKMPC_NO_PIN")[0] == '1');
-        return on;
+        static const bool off = (getenv("ARKMPC_PIN_IN_PLACE") && getenv("ARKMPC_PIN_IN_PLACE")[0] == '0') || (getenv("ARKMPC_NO_PIN") && getenv("ARKMPC_NO_PIN")[0] == '1');
+        return !off;
     }
     void pin(const void* p, size_t bytes) {
         if (!in_place() || !p || bytes < min_bytes()) return;
@@ -258,7 +261,12 @@ enum class Mem { Pageable, Pinned, Device, Foreign };
 struct Place {
     Mem kind = Mem::Pageable;
     void* dev = nullptr;                                   // what a kernel dereferences: the pointer itself (Device), its mapped alias (Pinned)
-    bool zc() const { return dev && !((uintptr_t)dev & 15) && (kind == Mem::Device || kind == Mem::Pinned); }    // (the zero-copy kernels move 16-byte quarters; a Rust Vec only promises 8)
+    bool ours = false;                                     // pinned because THIS LIBRARY registered it in place (per call), not because the caller holds it in pinned memory
+    // may a kernel address the vector where it lies?  Not a vector this library registered itself: kernels that read or write such a vector in
+    // place are what the stale-memory hazard of DESIGN section 4 needs (30 stress repetitions with them: up to 27 wrong vectors; the same
+    // registrations used by DMA only: none) -- those vectors travel by DMA, as they did in round 4.  ARKMPC_ZC_ON_OWN_PINS=1 lifts the rule.
+    static bool zc_on_own_pins() { static const bool on = getenv("ARKMPC_ZC_ON_OWN_PINS") && getenv("ARKMPC_ZC_ON_OWN_PINS")[0] == '1'; return on; }
+    bool zc() const { return dev && !((uintptr_t)dev & 15) && (kind == Mem::Device || (kind == Mem::Pinned && (!ours || zc_on_own_pins()))); }    // (the zero-copy kernels move 16-byte quarters; a Rust Vec only promises 8)
     bool device() const { return kind == Mem::Device; }
 };
 static inline Place classify(const arkmpc_ctx* ctx, const void* p, size_t bytes) {
@@ -275,6 +283,7 @@ static inline Place classify(const arkmpc_ctx* ctx, const void* p, size_t bytes)
     if (!runtime_knows((const char*)p + bytes - 1)) return pl;                                          // a range that only begins inside somebody's registration
     pl.kind = Mem::Pinned;
     pl.dev = attr.devicePointer;
+    pl.ours = pin_registry().covers(p, bytes);
     return pl;
 }
 // The same for a vector a kernel is going to address in place: the registry reference is taken FIRST (HostPins::keep), the pointer is looked

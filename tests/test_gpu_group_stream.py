@@ -325,8 +325,9 @@ def test_batch_from_host_async_equals_the_blocking_import(pkg, layout, how):
     after = e.stats()
     assert np.array_equal(got, want_rec)
     went_async = after["batch_async_imports"] - before["batch_async_imports"]
-    # a pageable vector is registered in place only with ARKMPC_PIN_IN_PLACE=1; by default it takes the blocking import
-    in_place = os.environ.get("ARKMPC_PIN_IN_PLACE") == "1"
+    # a pageable vector is registered in place for the import (then DMA + split from a staging block: no kernel addresses a vector the library
+    # registered itself) unless ARKMPC_PIN_IN_PLACE=0 / ARKMPC_NO_PIN=1: then it takes the blocking import
+    in_place = os.environ.get("ARKMPC_PIN_IN_PLACE") != "0" and os.environ.get("ARKMPC_NO_PIN") != "1"
     assert went_async == (0 if how == "small" or (how == "pageable" and not in_place) else 1)
     assert after["batch_blocking_imports"] - before["batch_blocking_imports"] == 1 - went_async
     # the columns themselves (split): share column then MAC column
@@ -466,25 +467,36 @@ def test_group_sessions_soak_random_sizes_members_and_placements(pkg, oracle):
     arena.free()
 
 
-def test_opt_in_registration_in_place_still_produces_the_same_words():
-    """ARKMPC_PIN_IN_PLACE=1 (the per-call hipHostRegister of pageable vectors, off by default since the end of round 5: DESIGN section 4) is read
-    once per process, so the session, group-session and import tests that involve pageable vectors run again in a child with it set"""
-    env = dict(os.environ, ARKMPC_PIN_IN_PLACE="1")
+def _rerun_in_child(env_extra, k_expr, attempts=1):
+    env = dict(os.environ, **env_extra)
     here = os.path.dirname(os.path.abspath(__file__))
     cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-           os.path.join(here, "test_gpu_stream.py"), os.path.join(here, "test_gpu_group_stream.py"),
-           "-k", "(bitexact_vs_oracle or mixed_zero_copy or oversubscribed or batch_from_host_async or fresh or pageable) and not opt_in"]
-    # This path is the one with the platform hazard (about one run in a hundred reads stale memory, or aborts, on an otherwise idle box): a
-    # logic error in it fails every attempt, the hazard does not -- up to three attempts, the count is reported.
+           os.path.join(here, "test_gpu_stream.py"), os.path.join(here, "test_gpu_group_stream.py"), "-k", k_expr]
     tails = []
-    for attempt in range(3):
+    for attempt in range(attempts):
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        if r.returncode == 0:
+        if r.returncode == 0 and " passed" in r.stdout:
             if attempt:
-                print("opt-in in-place registration: passed on attempt %d; earlier: %s" % (attempt + 1, tails))
+                print("%r: passed on attempt %d; earlier: %s" % (env_extra, attempt + 1, tails))
             return
         tails.append((r.stdout[-1500:] + r.stderr[-500:]).strip())
-    pytest.fail("three attempts failed:\n" + "\n-----\n".join(tails))
+    pytest.fail("%r, %d attempt(s) failed:\n" % (env_extra, attempts) + "\n-----\n".join(tails))
+
+
+_PAGEABLE_TESTS = "(bitexact_vs_oracle or mixed_zero_copy or oversubscribed or batch_from_host_async or fresh or pageable or soak) and not child"
+
+
+def test_child_never_registering_callers_vectors_produces_the_same_words():
+    """ARKMPC_PIN_IN_PLACE=0: the library never registers a caller's vector; pageable vectors travel as the runtime's own pageable copies.  (The
+    variable is read once per process, hence the child.)"""
+    _rerun_in_child({"ARKMPC_PIN_IN_PLACE": "0"}, _PAGEABLE_TESTS)
+
+
+def test_child_kernels_on_vectors_the_library_registered_opt_in():
+    """ARKMPC_ZC_ON_OWN_PINS=1: kernels may address in place the vectors the library registered itself -- the combination that was the default for
+    most of round 5 and that the stale-memory hazard of DESIGN section 4 needs (about one run in a hundred on an idle box reads stale memory, or
+    aborts).  A logic error in that path fails every attempt, the hazard does not: up to three attempts, the count is reported."""
+    _rerun_in_child({"ARKMPC_ZC_ON_OWN_PINS": "1"}, _PAGEABLE_TESTS, attempts=3)
 
 
 def test_group_members_in_threads_for_pageable_vectors():
@@ -492,11 +504,11 @@ def test_group_members_in_threads_for_pageable_vectors():
     when its members sit on distinct devices -- pageable copies block their caller, so this is what keeps N links busy without registering the
     caller's memory).  The variable is read once per process: the group tests run again in a child with it set, members sharing device 0, and
     the C99 group caller too."""
-    env = dict(os.environ, ARKMPC_GROUP_THREADS="1")
+    env = dict(os.environ, ARKMPC_GROUP_THREADS="1", ARKMPC_PIN_IN_PLACE="0")      # (unregistered vectors of every size: registered ones only enqueue and need no threads)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
                         os.path.join(here, "test_gpu_group_stream.py"), os.path.join(here, "test_group.py"),
-                        "-k", "group and not opt_in and not in_threads and not distinct"],
+                        "-k", "group and not child and not in_threads and not distinct"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
