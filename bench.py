@@ -770,7 +770,7 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
                 "party_gates_per_s_isolated_call": n / float(np.median(iso)), "h2d_GBps": n * E2E_UP_BYTES / t / 1e9,
                 "d2h_GBps": n * E2E_DOWN_BYTES / t / 1e9, "frac_of_measured_pcie": (n * E2E_UP_BYTES / t / 1e9) / cal["h2d_GBps"]}
 
-    pageable = timed_one("pageable, NEW vectors for every session (numpy / Vec memory): the runtime's own pageable copies (the library registers a caller's vector per call only with ARKMPC_PIN_IN_PLACE=1, DESIGN section 4: 8.2 ms that way)", True)
+    pageable = timed_one("pageable, NEW vectors for every session (numpy / Vec memory); pinned in place inside each call and moved by DMA (no kernel addresses a vector the library registered itself, DESIGN section 4)", True)
     regs = [a for p in (0, 1) for a in list(H[p].values())] + de + out + want_de
     for a in regs:
         lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))
@@ -969,7 +969,7 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
     memory as a PreprocessingPhase hands them over (fabric.rs:894-915 next_triple_batch, offline_prep.rs:65-81) -- not the dummy source's
     one-record shortcut.  192 B of triples per party-gate must cross the host link, which bounds the circuit whatever the kernels do (at 56 GB/s:
     2.9e8 party-gates/s per GPU).  Measured: the product path (arkmpc_batch_from_host_async: in-place import kernel for split columns, gate k+1's
-    triples going up behind gate k), the same from pageable vectors (blocking imports unless ARKMPC_PIN_IN_PLACE=1), the round-4 path (blocking copy + split pass per
+    triples going up behind gate k), the same from pageable vectors (pinned in place per gate, DMA into a staging block, split from HBM), the round-4 path (blocking copy + split pass per
     triple vector, nothing overlapped), and the streaming session with resident operands (x, y and the result in HBM, triples read in place).
     Every gate's d||e and result of both parties is compared with the oracle."""
     lib = pkg.load_library()
@@ -1113,7 +1113,7 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
     ex_a = exact_split(z, de); wipe(z); wipe(de)
     record("async_no_prefetch", "the same imports issued only when the gate needs them (ARKMPC_TRIPLE_PREFETCH=0 in the host mirror)", lambda: run_batches(pinned_src, True, False))
     ex_b = exact_split(z, de); wipe(z); wipe(de)
-    record("pageable_async", "the same from NEW pageable vectors for every gate (numpy / Vec memory): the import falls back to the blocking copy (a caller's vector is registered in place per call only with ARKMPC_PIN_IN_PLACE=1, DESIGN section 4)",
+    record("pageable_async", "the same from NEW pageable vectors for every gate (numpy / Vec memory): pinned in place by the import (hipHostRegister), DMA into a staging block, split kernel from HBM, unpinned at release",
            run_pageable)
     ex_c = exact_split(z, de); wipe(z); wipe(de)
     record("round4_blocking", "arkmpc_batch_from_host as it was: blocking copy on the compute stream into a staging block, then a split pass, three times per party-gate, "

@@ -127,8 +127,9 @@ int arkmpc_batch_from_host(arkmpc_ctx* ctx, int kind, int layout, size_t n, cons
  * (fabric.rs:894-915 next_triple_batch, offline_prep.rs:65-81; 192 B per party-gate, what bounds a circuit whose operands are resident):
  * the records go up on the context's upload stream behind whatever its compute stream is doing.  ScalarShare batches in
  * ARKMPC_LAYOUT_SPLIT are read IN PLACE over the link by one kernel that writes the two columns (no staging copy, no split pass); everything
- * else is one DMA.  That is for vectors the caller holds in pinned memory (arkmpc_host_alloc / arkmpc_host_register); a pageable vector takes
- * the blocking import above (the library registers a caller's vector by itself only with ARKMPC_PIN_IN_PLACE=1, see the streaming sessions).
+ * else is one DMA.  The in-place kernel is for vectors the caller holds in pinned memory (arkmpc_host_alloc / arkmpc_host_register); a pageable
+ * vector is registered for the call and goes up by DMA into a staging block that the split kernel then reads (no kernel addresses a vector the
+ * library registered itself, see the streaming sessions).
  *   _acquire        the context's compute stream waits, on the device, for the import (returns at once).  The batch-level entry points do
  *                   it themselves; call it before handing arkmpc_batch_data() pointers to the pointer-level ones.
  *   _host_release   blocks until the import has read host_records to its end and drops the pin; only then may the vector be freed or
@@ -271,16 +272,16 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
  * wants host vectors back: what benches/batch_ops.rs:19-39 times.  Over PCIe the path is bound by the host link (384 B up, 128 B down
  * per party-gate), so these entry points run a three-stream pipeline (upload DMA | kernels | download DMA) that keeps the upload
  * direction busy from the first byte to the last and hides the kernels and the downloads under it.  They take HOST pointers whatever
- * the context's buffer mode, any alignment a Rust Vec has (8 bytes).  Pageable buffers travel as the runtime's pageable copies (correct,
- * about half the rate).  A caller that keeps its vectors in pinned memory -- arkmpc_host_alloc, or arkmpc_host_register ONCE for vectors it
+ * the context's buffer mode, any alignment a Rust Vec has (8 bytes).  Pageable buffers are pinned in place for the duration of the call
+ * (hipHostRegister) so that the copies are true DMAs.  A caller that keeps its vectors in pinned memory -- arkmpc_host_alloc, or arkmpc_host_register ONCE for vectors it
  * keeps -- gets the fast form: a phase whose vectors are all pinned (and 16-byte aligned) runs with NO copies -- one kernel reads the
  * records where they lie in host memory and writes the payload / result vector in place (7.3 instead of 8.1 ms per 2^20 gates, 0.97 of
  * the link).  Same words either way; sessions with several open on one context (both parties of an in-process run) are supported.
- * The library does NOT register a caller's vector per call by itself (it did until the end of round 5: 8.2 instead of ~15 ms per 2^20 gates on
- * pageable vectors): on this platform a kernel can read stale memory through a vector whose ADDRESS had an earlier registered life -- freed, handed
- * out again by malloc with other physical pages -- and nothing in user space closes that window (ARKMPC_PIN_IN_PLACE=1 brings
- * the per-call registration back, each followed by a wait for the device).  arkmpc_host_register is for vectors that are registered once and kept;
- * it too waits for the device to go idle before it returns. */
+ * A pageable buffer is registered in place for the duration of the call and moved by DMA (8.2 ms per 2^20 gates); NO KERNEL addresses a vector
+ * the library registered itself: on this platform such a kernel can read stale memory when the vector's address had an earlier registered life
+ * (freed, handed out again by malloc with other physical pages) -- DESIGN section 4.  Kernels address in place only what the CALLER holds in
+ * pinned memory: arkmpc_host_alloc, or arkmpc_host_register ONCE for a vector it keeps (register once, not per gate).  ARKMPC_PIN_IN_PLACE=0
+ * never registers (the runtime's pageable copies, about half the rate), ARKMPC_ZC_ON_OWN_PINS=1 lifts the rule. */
 int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK */
 int arkmpc_host_unregister(void* ptr);
 int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc), RECYCLED: a freed block comes back from a free list by size */
@@ -560,9 +561,8 @@ int arkmpc_group_shares_to_host(arkmpc_group* grp, int layout, size_t n, const u
  * above for a party that owns several GPUs and whose operands are host vectors (benches/batch_ops.rs:19-39).  Same arguments, same words: x, y,
  * a, b, c = n ScalarShare records each in HOST memory, out_de / peer_de = 2n Scalars (d then e), out = n records.  Member g runs gates
  * [g n/G, (g+1) n/G) of the same vectors as a range session on its own device and PCIe link; vectors from arkmpc_host_alloc /
- * arkmpc_host_register are read and written in place -- the form that reaches the links' rate -- (pageable ones travel as the runtime's pageable
- * copies, which block their caller: with members on distinct devices each member's calls are then made from a host thread of its own so that
- * all links run; ARKMPC_PIN_IN_PLACE=1 has the call register them once, whole, instead), and because the member
+ * arkmpc_host_register are read and written in place -- the form that reaches the links' rate -- (pageable ones are registered once per
+ * call, whole, and every member moves its range by DMA), and because the member
  * calls only enqueue, all G links are busy together from one host thread.  Host-fed, a party is link-bound 20x below the kernels' rate, so the
  * links are what more GPUs add.  _begin returns once phase 1 is enqueued on every member; _poll_de = leading gates of d AND e complete in out_de
  * (members in range order); _wait_de blocks until all of out_de is (it is the caller's again afterwards); _finish blocks until `out` is
