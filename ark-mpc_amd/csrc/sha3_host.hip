@@ -84,7 +84,7 @@ absorb_fn pick_absorb() {
                           {"rows", arkmpc_keccak_absorb136_rows, arkmpc_cpu_has_avx512() != 0}};
     if (const char* force = getenv("ARKMPC_KECCAK"))
         for (const Cand& c : cands) if (c.ok && !strcmp(force, c.name)) return c.fn;
-    static unsigned char probe[64 * 136];
+    static unsigned char probe[512 * 136];                // (64 blocks x 3 runs picked a slower loop now and then on a busy host: config 5 end to end 1.22 vs 1.40 s)
     for (size_t i = 0; i < sizeof(probe); ++i) probe[i] = (unsigned char)(i * 131u + 7u);
     absorb_fn best = absorb136_portable;
     double best_t = 1e300;
@@ -92,9 +92,9 @@ absorb_fn pick_absorb() {
         if (!c.ok) continue;
         uint64_t st[25] = {0};
         double t = 1e300;
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int rep = 0; rep < 7; ++rep) {
             const auto t0 = std::chrono::steady_clock::now();
-            c.fn(st, probe, 64);
+            c.fn(st, probe, 512);
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (dt < t) t = dt;
         }
