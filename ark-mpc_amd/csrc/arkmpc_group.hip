@@ -64,7 +64,7 @@ inline void range(const arkmpc_group* g, size_t n, int m, size_t* lo, size_t* cn
     *lo = a; *cnt = b - a;
 }
 
-// PAGEABLE host vectors and N links.  The library no longer registers a caller's vector per call, so a pageable vector travels
+// UNREGISTERED host vectors and N links.  A vector the library does not register (below ARKMPC_PIN_MIN_KB, or ARKMPC_PIN_IN_PLACE=0) travels
 // as the runtime's pageable copies -- and those run ON THE CALLING THREAD (the runtime stages or pins the memory itself and returns when the copy
 // is done).  Issued member after member from one thread they use one link at a time, which is what the round-4 review objected to.  So when the
 // members sit on DISTINCT devices, the member calls that touch a pageable vector are made from one short-lived host thread per member: each
@@ -396,8 +396,10 @@ int arkmpc_group_shares_to_host(arkmpc_group* g, int layout, size_t n, const uin
 // rate, so the links -- one per GPU -- are what more GPUs add.  A group session is one range session per member
 // (arkmpc_hostmul_begin_range on [g n/G, (g+1) n/G) of the SAME host vectors: x + 8 lo, ..., d at out_de + 4 lo, e at out_de + 4 (n + lo)),
 // each on its member's context, device and link.  The caller's vectors are pinned once per call, whole (nothing to do for vectors it
-// registered or allocated pinned); the member sessions then run their phases as kernels that address their ranges in place, and because
-// every member call only ENQUEUES (begin_range, finish_async), one host thread keeps all G links busy at once; _finish ends the members
+// registered or allocated pinned); the member sessions then run their phases on their ranges -- as kernels that address the ranges in place when the
+// CALLER holds the vectors in pinned memory, through the DMA pipeline when the pin is the library's own (no kernel addresses a vector the
+// library registered itself: DESIGN section 4) -- and because every member call only ENQUEUES (begin_range, finish_async), one host thread keeps
+// all G links busy at once; _finish ends the members
 // after all of them have been started.  Vectors that cannot be pinned travel as the runtime's pageable copies, member after member.
 struct arkmpc_group_hostmul {
     arkmpc_group* g = nullptr;
