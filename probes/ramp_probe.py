@@ -1,7 +1,7 @@
 import importlib, sys, os, time, json
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
-import bench
+from benchlib import common as bench
 pkg = importlib.import_module("ark-mpc_amd")
 torch.cuda.set_device(0)
 eng = pkg.Engine(0, device=0, stream=torch.cuda.current_stream().cuda_stream)

@@ -4,7 +4,7 @@ batch_mul gates at once): does the aggregate beat one worker's 1.30e8 party-gate
 import ctypes, importlib, json, os, sys, threading, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-import bench
+from benchlib import common as bench
 pkg = importlib.import_module("ark-mpc_amd"); lib = pkg.load_library()
 torch.cuda.set_device(0)
 eng = pkg.Engine(0, device=0, stream=torch.cuda.current_stream().cuda_stream)

@@ -1,5 +1,6 @@
-"""The driver-facing contract of bench.py: one JSON line on rank 0 with the agreed fields, for a plain launch and for a
-`python -m torch.distributed.run` launch (2 ranks; gloo backend here because the GPU box has one GPU)."""
+"""The driver-facing contract of bench.py: rank 0 ends stdout with ONE compact JSON line (under 4 KB, numbers and short identifiers only)
+with the agreed fields, for a plain launch and for a `python -m torch.distributed.run` launch (2 ranks; gloo backend here because the GPU box
+has one GPU); every leg's full record goes to the detail file."""
 import json
 import os
 import socket
@@ -12,7 +13,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data", "config", "roofline", "timed_rounds", "timed_steps_total", "timed_region_ms", "ranks_seen", "distinct_devices", "rank_devices",
-            "per_rank_ms_per_step"]
+            "per_rank_ms_per_step", "results_check", "pipeline_frac_of_hbm_peak"]
+ROOFLINE_KEYS = {"bound", "kernel", "achieved", "peak", "unit", "frac", "frac_hip_events", "traffic", "algorithmic_bytes_per_launch", "gates_per_launch",
+                 "avg_launch_ms", "rocprof_avg_launch_ms", "frac_priced_from"}
+CPU_KEYS = {"value", "unit", "cores", "kind", "label", "sample", "single_thread_value", "fused_value", "fused_single_thread_value", "cpu_model", "nproc",
+            "compiler", "flags", "cargo_probe"}
+LINE_BUDGET = 4096
+
+
+def _no_prose(o, path=""):
+    """the compact line carries numbers and short identifiers: no string value longer than 160 characters, no nesting below two levels"""
+    if isinstance(o, dict):
+        assert path.count(".") < 2, "nested too deep: " + path
+        for k, v in o.items():
+            _no_prose(v, path + "." + k)
+    elif isinstance(o, str):
+        assert len(o) <= 160, "prose on the headline line at %s (%d chars)" % (path, len(o))
+
+
+def _last_line(stdout):
+    """the headline is the LAST stdout line, the only one, and under the budget"""
+    lines = stdout.strip().splitlines()
+    js = [ln for ln in lines if ln.startswith("{")]
+    assert len(js) == 1 and lines[-1] == js[0], "stdout must hold exactly one JSON line, at its end"
+    assert len(js[0]) < LINE_BUDGET, "headline line is %d bytes" % len(js[0])
+    return js[0]
 
 
 def _free_port():
@@ -31,52 +56,66 @@ def _check(line, n_gpus, steps, warmup, scaling="weak"):
     assert d["timed_region_ms"] >= 50.0 or d["timed_rounds"] > 1 or steps * d["ms_per_step"] >= 50.0
     # self-proving rank / device census
     assert d["ranks_seen"] == n_gpus and len(d["rank_devices"]) == n_gpus and 1 <= d["distinct_devices"] <= n_gpus
-    assert all("name" in i and "local_device" in i for i in d["rank_devices"])
+    assert all(isinstance(i, str) and "@" in i for i in d["rank_devices"])
     pr = d["per_rank_ms_per_step"]
-    assert len(pr["all"]) == n_gpus and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
+    assert pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
     assert d["metric"].startswith("authenticated Beaver mul-gates/sec over BN254 Fr")
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "workload" in d["config"] and "model" not in d["config"] and {"gates_per_gpu", "field", "layout"} <= set(d["config"])
     r = d["roofline"]
+    assert set(r) - {"frac_cold"} == ROOFLINE_KEYS
+    _no_prose(d)
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
     assert d["value"] > 0 and d["results_check"].endswith("ok")
     return d
 
 
-def test_single_process_default_shape():
+def test_single_process_default_shape(tmp_path):
+    det = str(tmp_path / "detail.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--log2n", "16",
-                        "--cpu-log2n", "12", "--circuit-log2n", "17", "--circuit-depth", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-log2n", "12", "--circuit-log2n", "17", "--circuit-depth", "3", "--detail-file", det], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _check(r.stdout.strip().splitlines()[-1], 1, 6, 2)
+    d = _check(_last_line(r.stdout), 1, 6, 2)
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["unit"] == "gates/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert set(cb) == CPU_KEYS
+    assert cb["kind"] == "port" and cb["unit"] == "gates/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     # BASELINE.md section 3 in full: both CPU forms on all cores and on one thread, the host description, the cargo probe, the label
     assert cb["label"] == "CPU restatement of reference algorithm (not ark-mpc measured)"
-    fs = cb["fused_single_pass"]
-    assert fs["value"] > 0 and fs["single_thread_value"] > 0 and fs["same_words_as_nine_passes"] is True and cb["single_thread_value"] > 0
-    for k in ("cpu_model", "nproc", "compiler", "flags", "cargo_probe", "excludes"):
-        assert cb.get(k), k
-    assert "gcc" in cb["compiler"] and "-O3" in cb["flags"]
+    assert cb["fused_value"] > 0 and cb["fused_single_thread_value"] > 0 and cb["single_thread_value"] > 0
+    assert "gcc" in cb["compiler"] and "-O3" in cb["flags"] and cb["cpu_model"] and cb["nproc"] >= 1 and cb["cargo_probe"]
+    assert d["oracle_bitexact_gates"] == d["oracle_bitexact_of"] == 1 << 12
     # the top-level roofline fraction is the reproducible one; the live HIP-event figure rides beside it
     rf = d["roofline"]
-    assert rf["frac_hip_events"] > 0 and rf["achieved_hip_events"] > 0 and "frac_source" in rf
+    assert rf["frac_hip_events"] > 0 and rf["avg_launch_ms"] > 0
+    # the N = 1 line leads with the figures a reader needs beside `value`: one scalar or two per leg, and whether each leg's check held
+    for k in ("aos_pipeline_frac_of_hbm_peak", "aos_gates_per_s", "end_to_end_party_gates_per_s", "circuit_party_gates_per_s", "circuit_frac_of_link_floor",
+              "config5_end_to_end_ms", "config4_ms"):
+        assert d[k] > 0, k
+    assert d["legs"] == {k: "ok" for k in ("end_to_end", "circuit", "aos", "config4", "config5")}
+    assert 0 < d["circuit_frac_of_link_floor"] <= 1.05
+    # ---- the detail file: every leg's full record ----
+    assert d["detail_file"]
+    D = json.load(open(det))
+    assert D["headline"]["value"] == d["value"]
+    fs = D["cpu_baseline"]["fused_single_pass"]
+    assert fs["same_words_as_nine_passes"] is True and fs["value"] == cb["fused_value"]
+    for k in ("cpu_model", "nproc", "compiler", "flags", "cargo_probe", "excludes"):
+        assert D["cpu_baseline"].get(k), k
+    assert "frac_source" in D["roofline"] and D["roofline"]["achieved_hip_events"] > 0
     # the circuit leg: resident operands, random triples from host memory, bit-exact, priced against the 192 B / party-gate link floor
-    c = d["circuit"]
-    assert c["results_check"].endswith("ok") and 0 < c["frac_of_link_floor"] <= 1.05 and c["party_gates_per_s"] > 0
+    c = D["circuit"]
+    assert c["results_check"].endswith("ok") and c["party_gates_per_s"] == d["circuit_party_gates_per_s"]
     assert set(c["modes"]) >= {"prefetched_async", "round4_blocking", "pageable_async", "sessions_resident_operands"}
-    assert d["circuit_party_gates_per_s"] == c["party_gates_per_s"]
-    # the N = 1 line leads with the figures a reader needs beside `value`: the arkworks-layout fraction, the host-to-host rate, config 5's wall time
-    for k in ("aos_pipeline_frac_of_hbm_peak", "end_to_end_party_gates_per_s", "config5_end_to_end_ms", "end_to_end"):
-        assert k in d, k
-    e2e = d["end_to_end"]
+    e2e = D["end_to_end"]
     for k in ("party_gates_per_s", "two_party_gates_per_s", "h2d_GBps", "d2h_GBps", "frac_of_measured_pcie"):
         assert k in e2e and e2e[k] is not None and e2e[k] > 0, k
-    assert e2e["results_check"].endswith("ok")
+    assert e2e["results_check"].endswith("ok") and e2e["party_gates_per_s"] == d["end_to_end_party_gates_per_s"]
     assert e2e["one_party"]["registered"]["path"] == {"phase1": "zero-copy kernel on the caller's vectors", "phase2": "zero-copy kernel on the caller's vectors"}
     assert e2e["one_party"]["pageable"]["path"] == {"phase1": "copy pipeline", "phase2": "copy pipeline"}
     assert e2e["wire_form"]["ms"] > 0 and e2e["wire_form"]["check"].endswith("ok")
-    c4 = d["config4"]
-    assert c4["host_vectors"]["check"].endswith("ok") and c4["host_vectors"]["pageable_ms"] > c4["ms"]
+    c4 = D["config4"]
+    assert c4["host_vectors"]["check"].endswith("ok") and c4["host_vectors"]["pageable_ms"] > c4["ms"] and c4["ms"] == d["config4_ms"]
     assert 0 < c4["frac_of_nominal_valu_rate"] < c4["frac_of_int_alu_peak"] < 1
+    assert D["config5"]["results_check"].endswith("ok") and D["aos"]["results_check"] == "ok"
 
 
 def test_torchrun_two_ranks():
@@ -84,9 +123,7 @@ def test_torchrun_two_ranks():
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
                         "--log2n", "16", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1                       # rank 0 only
-    d = _check(lines[0], 2, 4, 1)
+    d = _check(_last_line(r.stdout), 2, 4, 1)        # rank 0 only
     assert "cpu_baseline" not in d               # N = 1 only
     assert d["per_rank_oracle_check"]["ranks_all_exact"] is True and d["per_rank_oracle_check"]["gates_checked_per_rank"] == 4096
     assert d["distinct_devices"] == 1            # both ranks of this test sit on the box's one GPU, and the line says so
@@ -98,8 +135,7 @@ def test_torchrun_two_ranks_strong_scaling():
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
                         "--scaling", "strong", "--total-log2n", "17", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    d = _check(lines[0], 2, 4, 1, scaling="strong")
+    d = _check(_last_line(r.stdout), 2, 4, 1, scaling="strong")
     assert d["config"]["gates_per_gpu"] == 1 << 16 and d["config"]["gates_per_step_all_gpus"] == 1 << 17
 
 
@@ -139,7 +175,7 @@ def test_bench_two_ranks_on_two_distinct_devices():
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _check([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0], 2, 10, 2)
+    d = _check(_last_line(r.stdout), 2, 10, 2)
     assert d["distinct_devices"] == 2 and d["per_rank_oracle_check"]["ranks_all_exact"] is True
 
 
@@ -160,10 +196,10 @@ def test_config5_driver_two_ranks_equals_single_slice():
 
 def test_steps_above_2p20_gates_run_in_ranges():
     """--log2n 21 with the default --chunks 0: two 2^20-gate ranges per step (8 launches), results still verified."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--log2n", "21", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--log2n", "21", "--no-cpu-baseline", "--no-extras"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    d = json.loads(_last_line(r.stdout))
     assert d["config"]["launches_per_step"] == 8 and d["roofline"]["gates_per_launch"] == 1 << 20
     assert d["results_check"].endswith("ok") and d["value"] > 0
 
