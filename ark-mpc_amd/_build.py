@@ -73,6 +73,31 @@ def build_engine(force=False, verbose=False):
     return so
 
 
+def build_hazard(force=False, verbose=False):
+    """lib/libarkmpc_hip_hazard.so: the same engine compiled with -DARKMPC_HAZARD_SWITCHES, which brings back the two environment switches of the
+    round-5 hazard hunt -- ARKMPC_ZC_ON_OWN_PINS=1 (kernels address vectors the library registered itself: the known-bad combination) and
+    ARKMPC_PIN_DRAIN -- that the product library does not contain.  Built on demand only (tools/crash_hunt.sh, probes/); ARKMPC_LIBRARY selects it."""
+    obj_dir = os.path.join(LIB, "obj_hazard")
+    os.makedirs(obj_dir, exist_ok=True)
+    deps = [os.path.join(CSRC, d) for d in ENGINE_DEPS]
+    objs, jobs = [], []
+    for src in ENGINE_SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(obj_dir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + deps):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-DARKMPC_HAZARD_SWITCHES", "-c", s, "-o", o])
+    objs += [os.path.join(OBJ, src.replace(".cpp", ".o")) for src in HOST_CPP_SOURCES]       # (host objects: shared with the product build)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for out in ex.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    so = os.path.join(LIB, "libarkmpc_hip_hazard.so")
+    if force or jobs or _newer(so, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs)
+    return so
+
+
 def build_host(force=False, verbose=False):
     """C++ host-side mirror of the reference's fabric API (host/fabric.hpp, header-only) + its two-party driver."""
     src = os.path.join(HOST, "mock_mpc_main.cpp")
@@ -95,3 +120,5 @@ def build_all(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--hazard" in sys.argv:
+        print(build_hazard(force="--force" in sys.argv, verbose=True))

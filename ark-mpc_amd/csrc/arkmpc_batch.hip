@@ -71,6 +71,28 @@ static int batch_check(arkmpc_ctx* ctx, const arkmpc_batch* b) {
     if (b->field_id != ctx->field_id || b->device != ctx->device) return ark_bad(ctx, "batch belongs to a different field / device");
     return ARKMPC_OK;
 }
+// The host side of an asynchronous import, given back: blocks until the upload has read the caller's records (the `ready` event needs no
+// context), drops the pins, frees the staging block.  `o` is the OWNER of the storage; ctx is any context of its device.  The event returns to
+// the context's free list only after a successful wait -- one that could not be waited for is destroyed, not recycled.
+static int batch_release_host_side(arkmpc_ctx* ctx, arkmpc_batch* o) {
+    int rc = ARKMPC_OK;
+    if (o->ready) {
+        if (hipEventSynchronize(o->ready) == hipSuccess) {
+            CtxGuard guard(ctx);
+            // consumers that did not call arkmpc_batch_acquire are still ordered from here on: the import is complete
+            ctx->link_ev.push_back(o->ready);
+        } else {
+            (void)hipGetLastError();
+            ark_set_err(ctx, "hipEventSynchronize(import) failed");
+            rc = ARKMPC_ERR_HIP;
+            (void)hipEventDestroy(o->ready);
+        }
+        o->ready = nullptr;
+    }
+    if (o->pins) { delete o->pins; o->pins = nullptr; }
+    if (o->staging) { const int r = arkmpc_free(ctx, o->staging); if (r && !rc) rc = r; o->staging = nullptr; }
+    return rc;
+}
 
 extern "C" {
 
@@ -111,10 +133,14 @@ int arkmpc_batch_retain(arkmpc_batch* b) {
 // last handle (the batch itself and every slice of it) is gone.
 int arkmpc_batch_destroy(arkmpc_ctx* ctx, arkmpc_batch* b) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
+    if (b && b->device != ctx->device) return ark_bad(ctx, "batch lives on another device: destroy it through a context of its own device (nothing was released)");
     int rc = ARKMPC_OK;
     while (b && b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         arkmpc_batch* parent = b->parent;
-        if (b->ready || b->pins || b->staging) { int r = arkmpc_batch_host_release(ctx, b); if (r) rc = r; }      // an import nobody released: wait for it, drop the pin
+        // an import nobody released: wait for it, drop the pin, free the staging block -- unconditionally (round-5 advisor finding: the public
+        // arkmpc_batch_host_release returns early for a context of another field, and the storage below must not go back to the pool while the
+        // upload stream may still be writing it)
+        if (b->ready || b->pins || b->staging) { int r = batch_release_host_side(ctx, b); if (r) rc = r; }
         if (b->base) { int r = arkmpc_free(ctx, b->base); if (r) rc = r; }
         delete b;
         b = parent;
@@ -272,17 +298,7 @@ int arkmpc_batch_host_release(arkmpc_ctx* ctx, arkmpc_batch* batch) {
     if (!ctx) return ARKMPC_ERR_BAD_ARG;
     int rc = batch_check(ctx, batch);
     if (rc) return rc;
-    arkmpc_batch* o = owner_of(batch);
-    if (o->ready) {
-        if (hipEventSynchronize(o->ready) != hipSuccess) { ark_set_err(ctx, "hipEventSynchronize(import) failed"); rc = ARKMPC_ERR_HIP; }
-        CtxGuard guard(ctx);
-        // consumers that did not call arkmpc_batch_acquire are still ordered from here on: the import is complete
-        ctx->link_ev.push_back(o->ready);
-        o->ready = nullptr;
-    }
-    if (o->pins) { delete o->pins; o->pins = nullptr; }
-    if (o->staging) { const int r = arkmpc_free(ctx, o->staging); if (r && !rc) rc = r; o->staging = nullptr; }
-    return rc;
+    return batch_release_host_side(ctx, owner_of(batch));
 }
 
 // the batch as the arkworks Vec<T> the awaiting caller expects (always AoS records); blocks until the data has landed

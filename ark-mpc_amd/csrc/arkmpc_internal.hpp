@@ -121,7 +121,10 @@ static inline int arena_reserve(arkmpc_ctx* ctx, size_t bytes) {
 // the upload direction busy and hide the kernels and the downloads under it: three streams per context -- `up` (H2D DMA), the compute
 // stream, `down` (D2H DMA) -- ordered by events only, and the caller's buffers pinned in place so that the copies are true DMA.
 // ---------------------------------------------------------------------------------------------------------------------------------
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <iterator>
 #include <map>
 static inline int link_ensure(arkmpc_ctx* ctx) {
     if (ctx->up) return ARKMPC_OK;
@@ -130,11 +133,11 @@ static inline int link_ensure(arkmpc_ctx* ctx) {
     return ARKMPC_OK;
 }
 
-// Process-wide registry of the ranges THIS library pinned (hipHostRegister), reference-counted: two sessions may name the same buffer (a
-// party's out_de is its in-process peer's peer_de; batch_mul(&a, &a) passes one vector twice), and the pinning must outlive the last DMA of
-// either.  ROCm accepts a second hipHostRegister of a registered range and the first hipHostUnregister then drops it for both, so ranges
-// pinned by somebody else (the caller's arkmpc_host_register / arkmpc_host_alloc, torch's pinned tensors) are detected up front
-// (hipPointerGetAttributes) and left alone.
+// Process-wide registry of the host ranges pinned THROUGH THIS LIBRARY (hipHostRegister): by a session / import for the duration of a call
+// (library references) and by the caller's arkmpc_host_register (caller references).  Reference-counted: two sessions may name the same buffer
+// (a party's out_de is its in-process peer's peer_de; batch_mul(&a, &a) passes one vector twice), and the pinning must outlive the last DMA
+// of either.  ROCm accepts a second hipHostRegister of a registered range and the first hipHostUnregister then drops it for both, so ranges
+// pinned by somebody else (arkmpc_host_alloc, torch's pinned tensors) are detected up front (hipPointerGetAttributes) and left alone.
 // true if the HIP runtime already tracks the address (pinned / registered host memory, device memory); plain malloc memory is reported
 // either as an error (older runtimes) or as hipMemoryTypeUnregistered
 static inline bool runtime_knows(const void* p) {
@@ -147,14 +150,26 @@ static inline bool runtime_knows(const void* p) {
 static inline bool runtime_knows_range(const void* p, size_t bytes) {
     return bytes && runtime_knows(p) && runtime_knows((const char*)p + bytes - 1);
 }
+// Does [p, p + bytes) lie inside ONE allocation / registration the runtime tracks?  (Round-5 advisor finding: a vector that starts in one
+// registration and ends in another, with a gap between them, passed the end-point check, and a kernel reading it through the first range's
+// device alias would fault -- XNACK is off on this platform.)  A runtime that cannot name the range falls back to the end-point check.
+static inline bool one_runtime_range(const void* p, size_t bytes) {
+    void* start = nullptr;
+    size_t size = 0;
+    if (hipPointerGetAttribute(&start, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)p) == hipSuccess &&
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)p) == hipSuccess && start && size)
+        return (uintptr_t)p >= (uintptr_t)start && (uintptr_t)p + bytes <= (uintptr_t)start + size;
+    (void)hipGetLastError();
+    return runtime_knows((const char*)p + bytes - 1);
+}
 // Devices this process has (had) a context on: what drain_after_registration() below waits for.
 inline std::atomic<unsigned>& devices_in_use() { static std::atomic<unsigned> m{0}; return m; }
-// WAIT AFTER REGISTRATION (round 5; opt-in, ARKMPC_PIN_DRAIN=1, =2 adds a map + unmap of a page of our own).  Chasing a flaky soak showed that a
-// KERNEL which addresses in place a caller's vector that this library registered itself can read stale memory in a few of the vector's pages when
-// the vector's address had an earlier registered life (freed, handed out again by malloc with other physical pages) -- DESIGN section 4,
-// probes/group_pageable_race_probe.py.  Waiting for the device after every registration shrank that window (0 failures in 80 stress repetitions,
-// then 9 in 30 on another box) without closing it; what closed it is not letting kernels address such vectors at all (Place::zc below: they
-// travel by DMA, 0 failures in 30 repetitions with the registrations still made).  The wait is kept as a switch for the probe.
+#ifdef ARKMPC_HAZARD_SWITCHES
+// WAIT AFTER REGISTRATION (round 5; only in the hazard build, tools/crash_hunt.sh: ARKMPC_PIN_DRAIN=1, =2 adds a map + unmap of a page of our
+// own).  Chasing a flaky soak showed that a KERNEL which addresses in place a caller's vector that this library registered itself can read stale
+// memory in a few of the vector's pages when the vector's address had an earlier registered life (freed, handed out again by malloc with other
+// physical pages) -- profiles/r05_hazard/README.md.  Waiting for the device after every registration shrank that window without closing it; what
+// closed it is not letting kernels address such vectors at all (Place::zc below).  The wait is kept as a switch for the probe.
 static inline void drain_after_registration() {
     static const int mode = getenv("ARKMPC_PIN_DRAIN") ? atoi(getenv("ARKMPC_PIN_DRAIN")) : 0;
     if (!mode) return;
@@ -175,54 +190,129 @@ static inline void drain_after_registration() {
     }
     (void)hipGetLastError();
 }
+#else
+static inline void drain_after_registration() {}
+#endif
 struct PinRegistry {
     std::mutex mu;
-    struct Ent { size_t bytes; int refs; };
+    std::condition_variable cv;
+    // busy: a hipHostRegister / hipHostUnregister of this range is in flight OUTSIDE the lock (0.2-0.7 ms per 64 MiB: two in-process parties,
+    // or group members in threads, pin their vectors side by side; a second asker of the SAME range waits on cv for the outcome).
+    // caller_refs: references held through arkmpc_host_register -- while there is one the range is the caller's pinned memory, not a per-call
+    // registration of the library.  reused: the range overlaps addresses that already had a registered life which ended (see `retired`).
+    struct Ent { size_t bytes; int refs; int caller_refs; bool reused; bool busy; };
     std::map<uintptr_t, Ent> ents;
-    // returns the base of the entry that now holds a reference for [p, p + bytes), or 0 if the range is not ours to pin / could not be pinned
-    uintptr_t acquire(const void* p, size_t bytes) {
-        const uintptr_t a = (uintptr_t)p;
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = ents.upper_bound(a);
-        if (it != ents.begin()) {
-            --it;
-            if (a >= it->first && a + bytes <= it->first + it->second.bytes) { it->second.refs++; return it->first; }
+    using It = std::map<uintptr_t, Ent>::iterator;
+    // Addresses whose registration (through this library) has ENDED, as merged page-granular intervals [lo, hi).  A later registration that
+    // overlaps one is marked `reused`, and no kernel addresses such a vector in place (Place::zc): the stale-read hazard of DESIGN section 4
+    // needs a kernel reading through a mapping made at an address that had an earlier registered life.  Whatever a caller does -- register and
+    // unregister per gate on fresh Vecs that malloc hands out again -- zero-copy kernels only ever see addresses in their FIRST registered life.
+    std::map<uintptr_t, uintptr_t> retired;
+    static constexpr size_t kMaxRetired = 4096;
+    static constexpr uintptr_t kPage = 4096;
+
+    It containing(uintptr_t a, size_t bytes) {             // (mu held)
+        It it = ents.upper_bound(a);
+        if (it == ents.begin()) return ents.end();
+        --it;
+        return (a >= it->first && a + bytes <= it->first + it->second.bytes) ? it : ents.end();
+    }
+    bool overlaps_entry(uintptr_t a, size_t bytes) {       // (mu held) any entry that shares a byte with [a, a + bytes)
+        It it = ents.lower_bound(a + bytes);
+        if (it == ents.begin()) return false;
+        --it;
+        return it->first + it->second.bytes > a;
+    }
+    It settled(std::unique_lock<std::mutex>& lk, uintptr_t a, size_t bytes) {    // the containing entry once no runtime call is in flight for it
+        for (;;) {
+            It it = containing(a, bytes);
+            if (it == ents.end() || !it->second.busy) return it;
+            cv.wait(lk);
         }
-        if (runtime_knows_range(p, bytes)) return 0;                           // pinned by the caller already (or not host memory)
-        if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        ents[a] = Ent{bytes, 1};
-        drain_after_registration();
+    }
+    void retire(uintptr_t lo, size_t bytes) {              // (mu held)
+        uintptr_t hi = (lo + bytes + kPage - 1) & ~(kPage - 1);
+        lo &= ~(kPage - 1);
+        auto it = retired.upper_bound(lo);
+        if (it != retired.begin()) {
+            auto pr = std::prev(it);
+            if (pr->second >= lo) { lo = pr->first; hi = std::max(hi, pr->second); it = retired.erase(pr); }
+        }
+        while (it != retired.end() && it->first <= hi) { hi = std::max(hi, it->second); it = retired.erase(it); }
+        retired[lo] = hi;
+        while (retired.size() > kMaxRetired) {             // bounded: close the smallest gap (the set only ever grows, which errs on the safe side)
+            auto best = retired.begin();
+            uintptr_t gap = ~(uintptr_t)0;
+            for (auto a = retired.begin(), b = std::next(a); b != retired.end(); ++a, ++b)
+                if (b->first - a->second < gap) { gap = b->first - a->second; best = a; }
+            auto nx = std::next(best);
+            best->second = nx->second;
+            retired.erase(nx);
+        }
+    }
+    bool retired_overlaps(uintptr_t a, size_t bytes) {     // (mu held)
+        auto it = retired.upper_bound(a);
+        if (it != retired.begin() && std::prev(it)->second > a) return true;
+        return it != retired.end() && it->first < a + bytes;
+    }
+    // A reference for [p, p + bytes): on the entry that contains it, or on a new registration.  Returns the entry's base, or 0 if the range is
+    // not ours to pin (pinned by somebody else, not host memory, straddles an entry) or could not be pinned.  *performed = a hipHostRegister ran.
+    uintptr_t acquire(const void* p, size_t bytes, bool caller = false, bool* performed = nullptr) {
+        const uintptr_t a = (uintptr_t)p;
+        if (performed) *performed = false;
+        std::unique_lock<std::mutex> lk(mu);
+        It it = settled(lk, a, bytes);
+        if (it != ents.end()) { it->second.refs++; if (caller) it->second.caller_refs++; return it->first; }
+        if (overlaps_entry(a, bytes)) return 0;                                    // begins or ends inside one of our registrations: leave it to the pageable path
+        ents[a] = Ent{bytes, 1, caller ? 1 : 0, false, true};                      // reserved; the runtime is asked without the lock
+        lk.unlock();
+        bool ok = !runtime_knows_range(p, bytes);                                  // pinned by the caller already (or not host memory)
+        if (ok && hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        if (ok) drain_after_registration();
+        lk.lock();
+        it = ents.find(a);
+        if (!ok) { ents.erase(it); cv.notify_all(); return 0; }
+        it->second.busy = false;
+        it->second.reused = retired_overlaps(a, bytes);
+        cv.notify_all();
+        if (performed) *performed = true;
         return a;
     }
     // the same for a range already known to be pinned (by the caller, or by an entry of this registry): a reference if it is ours, no runtime calls
     uintptr_t acquire_if_ours(const void* p, size_t bytes) {
-        const uintptr_t a = (uintptr_t)p;
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = ents.upper_bound(a);
-        if (it == ents.begin()) return 0;
-        --it;
-        if (a >= it->first && a + bytes <= it->first + it->second.bytes) { it->second.refs++; return it->first; }
-        return 0;
+        std::unique_lock<std::mutex> lk(mu);
+        It it = settled(lk, (uintptr_t)p, bytes);
+        if (it == ents.end()) return 0;
+        it->second.refs++;
+        return it->first;
     }
-    // is [p, p + bytes) inside a range THIS LIBRARY registered (no reference taken)?
-    bool covers(const void* p, size_t bytes) {
-        const uintptr_t a = (uintptr_t)p;
+    // is [p, p + bytes) inside ONE range registered through this library (no reference taken)?  *ours: held by the library's own per-call
+    // registrations only (no arkmpc_host_register on it); *reused: its addresses had an earlier registered life.
+    bool lookup(const void* p, size_t bytes, bool* ours, bool* reused) {
         std::lock_guard<std::mutex> lk(mu);
-        auto it = ents.upper_bound(a);
-        if (it == ents.begin()) return false;
-        --it;
-        return a >= it->first && a + bytes <= it->first + it->second.bytes;
+        It it = containing((uintptr_t)p, bytes);
+        if (it == ents.end()) return false;
+        *ours = it->second.caller_refs == 0;
+        *reused = it->second.reused;
+        return true;
     }
-    void release(uintptr_t base) {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = ents.find(base);
+    void release(uintptr_t base, bool caller = false) {
+        std::unique_lock<std::mutex> lk(mu);
+        It it = ents.find(base);
         if (it == ents.end()) return;
-        if (--it->second.refs == 0) {
-            (void)hipHostUnregister((void*)base);
-            (void)hipGetLastError();
-            ents.erase(it);
-        }
+        if (caller && it->second.caller_refs > 0) it->second.caller_refs--;
+        if (--it->second.refs > 0) return;
+        it->second.busy = true;                            // nobody takes a reference while the runtime drops the mapping
+        const size_t bytes = it->second.bytes;
+        lk.unlock();
+        (void)hipHostUnregister((void*)base);
+        (void)hipGetLastError();
+        lk.lock();
+        ents.erase(base);
+        retire(base, bytes);
+        cv.notify_all();
     }
+    size_t retired_intervals() { std::lock_guard<std::mutex> lk(mu); return retired.size(); }
 };
 // one registry per process (the engine is one shared object; inline + function-local static = one instance across its translation units)
 inline PinRegistry& pin_registry() { static PinRegistry r; return r; }
@@ -262,14 +352,19 @@ struct Place {
     Mem kind = Mem::Pageable;
     void* dev = nullptr;                                   // what a kernel dereferences: the pointer itself (Device), its mapped alias (Pinned)
     bool ours = false;                                     // pinned because THIS LIBRARY registered it in place (per call), not because the caller holds it in pinned memory
-    // may a kernel address the vector where it lies?  Not a vector this library registered itself: kernels that read or write such a vector in
-    // place are what the stale-memory hazard of DESIGN section 4 needs (30 stress repetitions with them: up to 27 wrong vectors; the same
-    // registrations used by DMA only: none) -- those vectors travel by DMA, as they did in round 4.  ARKMPC_ZC_ON_OWN_PINS=1 lifts the rule.
-    static bool zc_on_own_pins() { static const bool on = getenv("ARKMPC_ZC_ON_OWN_PINS") && getenv("ARKMPC_ZC_ON_OWN_PINS")[0] == '1'; return on; }
-    bool zc() const { return dev && !((uintptr_t)dev & 15) && (kind == Mem::Device || (kind == Mem::Pinned && (!ours || zc_on_own_pins()))); }    // (the zero-copy kernels move 16-byte quarters; a Rust Vec only promises 8)
+    bool reused = false;                                   // registered (through this library) at addresses that had an earlier registered life
+    // may a kernel address the vector where it lies?  Not a vector this library registered itself, and not one registered at a retired address:
+    // kernels that read or write such a vector in place are what the stale-memory hazard of DESIGN section 4 needs (30 stress repetitions with
+    // them: up to 27 wrong vectors; the same registrations used by DMA only: none) -- those vectors travel by DMA.
+#ifdef ARKMPC_HAZARD_SWITCHES
+    static bool zc_on_own_pins() { static const bool on = getenv("ARKMPC_ZC_ON_OWN_PINS") && getenv("ARKMPC_ZC_ON_OWN_PINS")[0] == '1'; return on; }   // (hazard build only: tools/crash_hunt.sh)
+#else
+    static constexpr bool zc_on_own_pins() { return false; }
+#endif
+    bool zc() const { return dev && !((uintptr_t)dev & 15) && (kind == Mem::Device || (kind == Mem::Pinned && ((!ours && !reused) || zc_on_own_pins()))); }    // (the zero-copy kernels move 16-byte quarters; a Rust Vec only promises 8)
     bool device() const { return kind == Mem::Device; }
 };
-static inline Place classify(const arkmpc_ctx* ctx, const void* p, size_t bytes) {
+static inline Place classify(arkmpc_ctx* ctx, const void* p, size_t bytes) {
     Place pl;
     if (!p || !bytes) return pl;
     hipPointerAttribute_t attr;
@@ -280,17 +375,20 @@ static inline Place classify(const arkmpc_ctx* ctx, const void* p, size_t bytes)
         return pl;
     }
     if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return pl;                               // hipMemoryTypeUnregistered, managed
-    if (!runtime_knows((const char*)p + bytes - 1)) return pl;                                          // a range that only begins inside somebody's registration
+    bool ours = false, reused = false;
+    if (!pin_registry().lookup(p, bytes, &ours, &reused) && !one_runtime_range(p, bytes)) return pl;    // begins in one registration and ends outside it: not pinned memory
     pl.kind = Mem::Pinned;
     pl.dev = attr.devicePointer;
-    pl.ours = pin_registry().covers(p, bytes);
+    pl.ours = ours;
+    pl.reused = reused;
+    if (reused && !ours && !((uintptr_t)pl.dev & 15)) ctx->stats.zc_refused_reused_address++;           // a caller-held vector that would otherwise be addressed in place
     return pl;
 }
 // The same for a vector a kernel is going to address in place: the registry reference is taken FIRST (HostPins::keep), the pointer is looked
 // at afterwards.  The other order left a window -- round-4 advisor finding: a vector that is pinned only because ANOTHER session of this library
 // registered it (an in-process peer's out_de passed as this party's peer_de) could be unregistered by that session between the look and the
 // reference, and the kernel would then fault on an unmapped address.  If the look says "not pinned after all" the reference is dropped again.
-static inline Place classify_and_hold(const arkmpc_ctx* ctx, HostPins& pins, const void* p, size_t bytes) {
+static inline Place classify_and_hold(arkmpc_ctx* ctx, HostPins& pins, const void* p, size_t bytes) {
     const size_t before = pins.held.size();
     pins.keep(p, bytes);
     const Place pl = classify(ctx, p, bytes);

@@ -76,17 +76,18 @@ typedef void (*absorb_fn)(uint64_t*, const unsigned char*, size_t);
 void absorb136_portable(uint64_t* st, const unsigned char* data, size_t nblocks) {
     for (size_t i = 0; i < nblocks; ++i) absorb136(st, data + 136 * i);
 }
-absorb_fn pick_absorb() {
+struct Picked { const char* name; absorb_fn fn; };
+Picked pick_absorb() {
     struct Cand { const char* name; absorb_fn fn; bool ok; };
     const Cand cands[] = {{"portable", absorb136_portable, true}, {"scalar", arkmpc_keccak_absorb136_scalar, sizeof(void*) == 8},
                           {"bmi", arkmpc_keccak_absorb136_bmi, arkmpc_cpu_has_bmi() != 0}, {"avx512", arkmpc_keccak_absorb136_avx512, arkmpc_cpu_has_avx512() != 0},
                           {"lanes", arkmpc_keccak_absorb136_lanes, arkmpc_cpu_has_avx512() != 0},
                           {"rows", arkmpc_keccak_absorb136_rows, arkmpc_cpu_has_avx512() != 0}};
     if (const char* force = getenv("ARKMPC_KECCAK"))
-        for (const Cand& c : cands) if (c.ok && !strcmp(force, c.name)) return c.fn;
+        for (const Cand& c : cands) if (c.ok && !strcmp(force, c.name)) return Picked{c.name, c.fn};
     static unsigned char probe[512 * 136];                // (64 blocks x 3 runs picked a slower loop now and then on a busy host: config 5 end to end 1.22 vs 1.40 s)
     for (size_t i = 0; i < sizeof(probe); ++i) probe[i] = (unsigned char)(i * 131u + 7u);
-    absorb_fn best = absorb136_portable;
+    Picked best{"portable", absorb136_portable};
     double best_t = 1e300;
     for (const Cand& c : cands) {
         if (!c.ok) continue;
@@ -98,14 +99,15 @@ absorb_fn pick_absorb() {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (dt < t) t = dt;
         }
-        if (t < best_t) { best_t = t; best = c.fn; }
+        if (t < best_t) { best_t = t; best = Picked{c.name, c.fn}; }
     }
     return best;
 }
-absorb_fn absorb_blocks() {
-    static const absorb_fn fn = pick_absorb();
-    return fn;
+const Picked& picked_absorb() {
+    static const Picked p = pick_absorb();
+    return p;
 }
+absorb_fn absorb_blocks() { return picked_absorb().fn; }
 
 template <int F> void to_be_t(const uint64_t m[4], unsigned char out[32]) {
     Fe c = fe_to_canonical<F>(fe_from_host(m));
@@ -124,6 +126,8 @@ template <int F> void from_be_t(const unsigned char be[32], uint64_t out[4]) {
 }
 
 }  // namespace
+
+extern "C" const char* arkmpc_sha3_loop(void) { return picked_absorb().name; }
 
 void sha3_256_init(Sha3State* s) { memset(s, 0, sizeof(*s)); }
 

@@ -23,7 +23,8 @@ class ArkMpcError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libarkmpc_hip.so")
+    """the in-tree engine; ARKMPC_LIBRARY names another BUILD of the same engine (tools/crash_hunt.sh: the hazard build, lib/libarkmpc_hip_hazard.so)"""
+    return os.environ.get("ARKMPC_LIBRARY") or os.path.join(_HERE, "lib", "libarkmpc_hip.so")
 
 
 def load_library():
@@ -259,11 +260,11 @@ class Engine:
     def hostmul_end(self, s): self._ck(self.lib.arkmpc_hostmul_end(s))
     def stats(self):
         """arkmpc_ctx_get_stats as a dict"""
-        st = (ctypes.c_uint64 * 8)()
+        st = (ctypes.c_uint64 * 9)()
         self._ck(self.lib.arkmpc_ctx_get_stats(self.h, st))
         return {"hostmul_zero_copy_phases": (int(st[0]), int(st[1])), "hostmul_copy_phases": (int(st[2]), int(st[3])),
                 "hostmul_device_bytes_last": int(st[4]), "hostmul_device_bytes_peak": int(st[5]),
-                "batch_async_imports": int(st[6]), "batch_blocking_imports": int(st[7])}
+                "batch_async_imports": int(st[6]), "batch_blocking_imports": int(st[7]), "zc_refused_reused_address": int(st[8])}
     # ---- device-batch handles (arkmpc_batch_*): the subset the asynchronous import needs
     SCALAR, SCALAR_SHARE = 0, 1
     AOS, SPLIT = 0, 1
@@ -525,10 +526,10 @@ class Group:
         self._ck(self.lib.arkmpc_group_hostmul_abort(s))
 
     def member_stats(self, member):
-        st = (ctypes.c_uint64 * 8)()
+        st = (ctypes.c_uint64 * 9)()
         self.lib.arkmpc_ctx_get_stats(self.member_ctx(member), st)
         return {"hostmul_zero_copy_phases": (int(st[0]), int(st[1])), "hostmul_copy_phases": (int(st[2]), int(st[3])),
-                "hostmul_device_bytes_last": int(st[4]), "hostmul_device_bytes_peak": int(st[5])}
+                "hostmul_device_bytes_last": int(st[4]), "hostmul_device_bytes_peak": int(st[5]), "zc_refused_reused_address": int(st[8])}
 
     def prepare_beaver(self, layout, n, party, key, x, y, a, b, c, my_de, peer_de, out):
         """Pre-marshalled K1 and K2+K3 group calls (replayed in timing loops)."""

@@ -209,6 +209,10 @@ class MockNetwork : public MpcNetwork {
 // ---------------------------------------------------------------------------------------------------------------
 // Preprocessing: offline_prep.rs:12-82
 // ---------------------------------------------------------------------------------------------------------------
+// thrown by a source that cannot serve a request (LowGearPrep asserts, offline-phase/src/structs.rs:189); sources throw it BEFORE consuming anything
+struct PreprocessingExhausted : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
 class PreprocessingPhase {
   public:
     virtual ~PreprocessingPhase() = default;
@@ -227,6 +231,9 @@ class PreprocessingPhase {
     // and unmodified until the next call on this source.  The fabric then imports them straight from there (asynchronously, in place over
     // the link when the storage is pinned) -- no intermediate Vec, no pin / unpin per gate.  Consumes the triples like next_triplet_batch.
     virtual bool borrow_triplet_batch(size_t /*n*/, const ScalarShare** /*a*/, const ScalarShare** /*b*/, const ScalarShare** /*c*/) { return false; }
+    // Optional: how many triples the source can still hand out (SIZE_MAX = it does not say).  The fabric reads triples AHEAD of need only when the
+    // source can serve them: a read-ahead that would exhaust the source is not attempted, so nothing is consumed for a gate that may never come.
+    virtual size_t triples_remaining() const { return SIZE_MAX; }
     virtual bool constant_input_masks(Scalar& /*local value*/, ScalarShare& /*local share*/, ScalarShare& /*counterparty share*/) { return false; }
 };
 // offline_prep.rs:88-170: a = 2, b = 3, c = 6 statically split; MAC key share = party id
@@ -381,12 +388,13 @@ class VectorBeaverSource : public PreprocessingPhase {
         a.assign(pa, pa + n); b.assign(pb, pb + n); c.assign(pc, pc + n);
     }
     bool borrow_triplet_batch(size_t n, const ScalarShare** a, const ScalarShare** b, const ScalarShare** c) override {
-        if (n > cap_ - used_) throw std::runtime_error("preprocessing exhausted: " + std::to_string(cap_ - used_) + " triples left, " + std::to_string(n) + " requested");
+        if (n > cap_ - used_) throw PreprocessingExhausted("preprocessing exhausted: " + std::to_string(cap_ - used_) + " triples left, " + std::to_string(n) + " requested");
         *a = store_[0] + used_; *b = store_[1] + used_; *c = store_[2] + used_;
         used_ += n;
         return true;
     }
     size_t remaining() const { return cap_ - used_; }
+    size_t triples_remaining() const override { return cap_ - used_; }
 
   private:
     std::unique_ptr<PreprocessingPhase> inner_;
@@ -720,9 +728,13 @@ class MpcFabric : public std::enable_shared_from_this<MpcFabric> {
     // with prefetch on the triples of the NEXT gate are requested from the source and started on their way as soon as this gate's K1 is enqueued,
     // i.e. under this gate's network round and K2+K3.  The source is a FIFO of triples, so reading ahead changes nothing a party can observe,
     // as long as both parties do it (they run the same program); a request of another size is served from what was read ahead, in order.
-    // ARKMPC_TRIPLE_PREFETCH=0 turns it off (execute_mock_mpc).  prefetch_triples is called by batch_mul; a source that throws when asked ahead
-    // of need (exhausted) is asked again when the triples are really requested.
-    void set_triple_prefetch(bool on) { if (!on && pending_) throw std::logic_error("triples have been read ahead already"); prefetch_ = on; }
+    // ARKMPC_TRIPLE_PREFETCH=0 turns it off (execute_mock_mpc).  prefetch_triples is called by batch_mul.  What is read ahead is CONSUMED from
+    // the source, so (round-5 advisor finding): a source that says it cannot serve the request (triples_remaining) is not asked ahead; only the
+    // source's own PreprocessingExhausted is tolerated, and asked again when the triples are really requested; triples that were consumed stay
+    // with the fabric whatever happens to their upload (a failed asynchronous import is retried as a blocking one when the triples are needed,
+    // and reported there).  A caller that knows its LAST multiplication calls set_triple_prefetch(false) before it: nothing is then read ahead
+    // for a gate that never comes; triples already read ahead stay queued and are served first.
+    void set_triple_prefetch(bool on) { prefetch_ = on; }
     bool triple_prefetch() const { return prefetch_; }
     void prefetch_triples(size_t n);
     AuthenticatedScalarBatch random_shared_scalars(size_t n);                                    // fabric.rs:917-928
@@ -1250,6 +1262,7 @@ struct MpcFabric::TripleFetch {
     size_t n = 0;
     std::vector<ScalarShare> h[3];                           // the source's Vecs, alive until the import has read them (empty: lent in place)
     AuthenticatedScalarBatch t[3];
+    bool up[3] = {false, false, false};                      // t[k]'s import was started; false = the records wait in h[k] for land() to import them
     bool landed = false;
 };
 inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, AuthenticatedScalarBatch& b, AuthenticatedScalarBatch& c, bool broadcast_ok) {
@@ -1275,9 +1288,9 @@ inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, 
     AuthenticatedScalarBatch* out[3] = {&a, &b, &c};
     if (pending_ && pending_->n != n) {
         // a request of another size than what was read ahead: the source is a FIFO, so serve from the read-ahead triples first, in order
+        land(*pending_);
         std::shared_ptr<TripleFetch> p = std::move(pending_);
         pending_.reset();
-        land(*p);
         if (n < p->n) {
             auto rest = std::make_shared<TripleFetch>();
             rest->n = p->n - n;
@@ -1304,13 +1317,17 @@ inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, 
         next_id_ += 3 * n;
         return;
     }
+    if (pending_) land(*pending_);                           // (in place: if this throws, the consumed triples are still the fabric's)
     std::shared_ptr<TripleFetch> t = pending_ ? std::move(pending_) : fetch_triples(n);
     pending_.reset();
     land(*t);
     next_id_ += 3 * n;
     for (int k = 0; k < 3; ++k) *out[k] = std::move(t->t[k]);
 }
-// n triples from the source, started on their way to the GPU; returns at once for vectors that can go up asynchronously
+// n triples from the source, started on their way to the GPU; returns at once for vectors that can go up asynchronously.  Throws only what the
+// SOURCE throws (nothing consumed).  Once the source has handed the triples over they are consumed -- this party's FIFO has advanced, as its
+// peer's will -- so from then on nothing is dropped: an import that could not be started leaves its records in the fetch (a lent range is copied
+// out: it is only good until the next call on the source) and land() imports them, or reports why it cannot, when the triples are needed.
 inline std::shared_ptr<MpcFabric::TripleFetch> MpcFabric::fetch_triples(size_t n) {
     auto f = std::make_shared<TripleFetch>();
     f->n = n;
@@ -1318,22 +1335,33 @@ inline std::shared_ptr<MpcFabric::TripleFetch> MpcFabric::fetch_triples(size_t n
     if (!prep_->borrow_triplet_batch(n, &p[0], &p[1], &p[2])) {
         prep_->next_triplet_batch(n, f->h[0], f->h[1], f->h[2]);
         for (int k = 0; k < 3; ++k) {
-            if (f->h[k].size() != n) throw std::runtime_error("preprocessing exhausted");   // structs.rs:189 asserts
+            if (f->h[k].size() != n) throw PreprocessingExhausted("preprocessing exhausted");   // structs.rs:189 asserts
             p[k] = f->h[k].data();
         }
     }
     for (int k = 0; k < 3; ++k) {
-        arkmpc_batch* b = nullptr;
-        check(ctx(), arkmpc_batch_from_host_async(ctx(), ARKMPC_KIND_SCALAR_SHARE, share_layout_, n, p[k], &b), "batch_from_host_async");
         f->t[k].n = n;
-        f->t[k].buf = DeviceBuf::adopt(eng_, b);             // (no fabric pointer while the fetch may be parked in pending_: no cycle fabric -> batch -> fabric)
+        arkmpc_batch* b = nullptr;
+        if (arkmpc_batch_from_host_async(ctx(), ARKMPC_KIND_SCALAR_SHARE, share_layout_, n, p[k], &b) == ARKMPC_OK) {
+            f->t[k].buf = DeviceBuf::adopt(eng_, b);         // (no fabric pointer while the fetch may be parked in pending_: no cycle fabric -> batch -> fabric)
+            f->up[k] = true;
+        } else if (f->h[k].empty()) f->h[k].assign(p[k], p[k] + n);
     }
     return f;
 }
 // the compute stream waits for the imports; the source's memory is released (blocks until the uploads have read it -- long done for triples
-// that were read ahead a gate ago)
+// that were read ahead a gate ago).  Records whose asynchronous import could not be started go up now, blocking; a failure here throws with the
+// records still in the fetch.
 inline void MpcFabric::land(TripleFetch& t) {
     if (t.landed) return;
+    for (int k = 0; k < 3; ++k) {
+        if (!t.up[k]) {
+            arkmpc_batch* b = nullptr;
+            check(ctx(), arkmpc_batch_from_host(ctx(), ARKMPC_KIND_SCALAR_SHARE, share_layout_, t.n, t.h[k].data(), &b), "batch_from_host (triples whose asynchronous import failed)");
+            t.t[k].buf = DeviceBuf::adopt(eng_, b);
+            t.up[k] = true;
+        }
+    }
     for (int k = 0; k < 3; ++k) {
         check(ctx(), arkmpc_batch_acquire(ctx(), t.t[k].buf.handle()), "batch_acquire");
         check(ctx(), arkmpc_batch_host_release(ctx(), t.t[k].buf.handle()), "batch_host_release");
@@ -1346,7 +1374,8 @@ inline void MpcFabric::prefetch_triples(size_t n) {
     if (!prefetch_ || pending_ || !n) return;
     ScalarShare ca, cb, cc;
     if (prep_->constant_triplet(ca, cb, cc)) return;         // constant sources are one record on the GPU already
-    try { pending_ = fetch_triples(n); } catch (const std::exception&) { pending_.reset(); }
+    if (prep_->triples_remaining() < n) return;              // the source cannot serve a gate of this size any more: nothing is consumed for one that may never come
+    try { pending_ = fetch_triples(n); } catch (const PreprocessingExhausted&) { pending_.reset(); }      // (thrown before anything was consumed; asked again at need)
 }
 inline void MpcFabric::random_inverse_pairs(size_t n, AuthenticatedScalarBatch& l, AuthenticatedScalarBatch& r) {
     std::vector<ScalarShare> hl, hr;

@@ -100,12 +100,15 @@ def leg_end_to_end(pkg, eng, dev, log2n=20, reps_min=6):
                 "party_gates_per_s_isolated_call": n / float(np.median(iso)), "h2d_GBps": n * E2E_UP_BYTES / t / 1e9,
                 "d2h_GBps": n * E2E_DOWN_BYTES / t / 1e9, "frac_of_measured_pcie": (n * E2E_UP_BYTES / t / 1e9) / cal["h2d_GBps"]}
 
-    pageable = timed_one("pageable, NEW vectors for every session (numpy / Vec memory); pinned in place inside each call and moved by DMA (no kernel addresses a vector the library registered itself, DESIGN section 4)", True)
+    # registered FIRST: a kernel addresses a caller-registered vector in place only in the FIRST registered life of its addresses (the library retires
+    # the addresses of every registration that ended, its own per-call ones included: csrc/arkmpc_internal.hpp PinRegistry), so these vectors are
+    # registered before any pageable session has pinned and released them
     regs = [a for p in (0, 1) for a in list(H[p].values())] + de + out + want_de
     for a in regs:
         lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))
     registered = timed_one("registered once by the caller (arkmpc_host_register), as a caller that keeps its vectors across gates would: both phases run as kernels that read and write "
                            "the pinned vectors in place, no copy commands (ARKMPC_HOSTMUL_ZEROCOPY=0 puts them back on the copy pipeline: 8.0-8.1 ms at 2^20)", False)
+    pageable = timed_one("pageable, NEW vectors for every session (numpy / Vec memory); pinned in place inside each call and moved by DMA (no kernel addresses a vector the library registered itself, DESIGN section 4)", True)
     # two parties on this one GPU, a context and a host thread each, payloads handed over in host memory (network/mock.rs moves host payloads)
     es = [pkg.Engine(FID, device=dev) for _ in (0, 1)]
     bar = threading.Barrier(2)

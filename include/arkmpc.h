@@ -77,6 +77,8 @@ typedef struct {
     uint64_t hostmul_device_bytes_peak;
     uint64_t batch_async_imports;           /* arkmpc_batch_from_host_async calls that went up asynchronously (in-place kernel or DMA) */
     uint64_t batch_blocking_imports;        /* ... that fell back to the blocking copy (small or unpinnable vectors) */
+    uint64_t zc_refused_reused_address;     /* caller-pinned vectors a kernel could have addressed in place but did NOT, because the vector was registered
+                                             * (arkmpc_host_register) at addresses that already had a registered life which ended: they travelled by DMA */
 } arkmpc_ctx_stats;
 int arkmpc_ctx_get_stats(arkmpc_ctx* ctx, arkmpc_ctx_stats* out_stats);
 /* Kernel timer: arm slot s (0..63) and the NEXT K1 / K2+K3 / K5 launch on this context gets HIP events bound to
@@ -364,6 +366,9 @@ int arkmpc_commit_sha3(arkmpc_ctx* ctx, size_t n, const uint64_t* values, const 
                        uint64_t out_commitment[4]);
 /* plain SHA3-256 of a host buffer (the `sha3` crate's Sha3_256) */
 int arkmpc_sha3_256(const uint8_t* msg, size_t len, uint8_t out32[32]);
+/* which Keccak-f[1600] absorb loop this process uses for the sponge: "portable" | "scalar" | "bmi" | "avx512" | "lanes" | "rows" -- the one
+ * ARKMPC_KECCAK names if this CPU supports it, else the fastest of a timed trial at first use (csrc/sha3_host.hip).  Static string. */
+const char* arkmpc_sha3_loop(void);
 
 /* ---- BN254 G1 points (context field must be ARKMPC_BN254_FR) -------------------------------- */
 int arkmpc_g1_add(arkmpc_ctx* ctx, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* out);  /* curve.rs:203-209 */

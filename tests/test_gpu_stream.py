@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import pyref
-from helpers import mont_array, from_mont_array, mixed_values, rand_values, authenticated_shares
+from helpers import FreshVA, mont_array, from_mont_array, mixed_values, rand_values, authenticated_shares
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -614,7 +614,7 @@ def test_hostmul_zero_copy_sees_what_the_cpu_wrote_between_sessions(pkg, engs, o
     def pinned(nwords):
         if how == "host_alloc":
             return arena.zeros(nwords)
-        a = np.zeros(nwords, dtype=np.uint64)
+        a = FreshVA.zeros(nwords)             # (addresses in their first registered life: a recycled numpy address would travel by DMA, tests/test_gpu_pinning.py)
         assert lib.arkmpc_host_register(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes)) == 0
         regs.append(a)
         return a
@@ -650,7 +650,7 @@ def test_hostmul_zero_copy_on_slices_of_one_registered_region(pkg, engs, oracle)
     e = engs[fid]
     lib = pkg.load_library()
     _, keys, sh = _inputs(fid, n, seed=8600, tile_from=1500)
-    slab = np.zeros(2 * 8 * (8 * n + 8) + 64, dtype=np.uint64)
+    slab = FreshVA.zeros(2 * 8 * (8 * n + 8) + 64)               # (an address in its first registered life)
     off0 = (-(slab.ctypes.data // 8)) % 2                        # first word on a 16-byte boundary
     assert lib.arkmpc_host_register(ctypes.c_void_p(slab.ctypes.data), ctypes.c_size_t(slab.nbytes)) == 0
     cur = [off0 + 2]                                             # (not the region's first byte)

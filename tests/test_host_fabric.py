@@ -16,22 +16,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "ark-mpc_amd", "lib", "arkmpc_mock_mpc")
 
 
-@pytest.fixture(params=["host", "device", "wire"], autouse=True)
-def link_mode(request):
-    """Every scenario runs three times: payloads handed over as host vectors (network/mock.rs), as device buffers (the same
-    in-memory move for HBM-resident batches), and as the serde_json frames QuicTwoPartyNet carries
-    (network/quic.rs:303-306), produced and parsed by the engine's wire codec on the GPU."""
-    os.environ["ARKMPC_MOCK_LINK"] = request.param
+# Every scenario runs over every link mode and in both HBM layouts of the mirror's AuthenticatedScalarBatch -- as a covering set of three
+# (link, layout) pairs by default; ARKMPC_SOAK=full runs the whole 3 x 2 product (each case is its own process: ~2 s of runtime start-up).
+_PAIRS = [("host", "split"), ("device", "aos"), ("wire", "split")]
+if os.environ.get("ARKMPC_SOAK") == "full":
+    _PAIRS = [(l, y) for l in ("host", "device", "wire") for y in ("split", "aos")]
+
+
+@pytest.fixture(params=_PAIRS, ids=["%s-%s" % p for p in _PAIRS], autouse=True)
+def link_and_layout(request):
+    """link: payloads handed over as host vectors (network/mock.rs), as device buffers (the same in-memory move for HBM-resident batches), or as
+    the serde_json frames QuicTwoPartyNet carries (network/quic.rs:303-306), produced and parsed by the engine's wire codec on the GPU.
+    layout: the engine-native split columns (the default: K1 reads no dead MAC bytes, the opening payload is the share column itself) or
+    arkworks' AoS records."""
+    os.environ["ARKMPC_MOCK_LINK"], os.environ["ARKMPC_SHARE_LAYOUT"] = request.param
     yield request.param
     os.environ.pop("ARKMPC_MOCK_LINK", None)
-
-
-@pytest.fixture(params=["split", "aos"], autouse=True)
-def share_layout(request):
-    """... and in both HBM layouts of the mirror's AuthenticatedScalarBatch: the engine-native split columns (the default: K1 reads no dead
-    MAC bytes, the opening payload is the share column itself) and arkworks' AoS records."""
-    os.environ["ARKMPC_SHARE_LAYOUT"] = request.param
-    yield request.param
     os.environ.pop("ARKMPC_SHARE_LAYOUT", None)
 
 
