@@ -1294,7 +1294,7 @@ inline void MpcFabric::next_triple_batch(size_t n, AuthenticatedScalarBatch& a, 
         if (n < p->n) {
             auto rest = std::make_shared<TripleFetch>();
             rest->n = p->n - n;
-            for (int k = 0; k < 3; ++k) { *out[k] = p->t[k].slice(0, n); rest->t[k] = p->t[k].slice(n, p->n - n); rest->t[k].fabric.reset(); }
+            for (int k = 0; k < 3; ++k) { *out[k] = p->t[k].slice(0, n); rest->t[k] = p->t[k].slice(n, p->n - n); rest->t[k].fabric.reset(); rest->up[k] = true; }
             pending_ = std::move(rest);
         } else {
             std::shared_ptr<TripleFetch> more = fetch_triples(n - p->n);

@@ -129,6 +129,19 @@ def test_torchrun_two_ranks():
     assert d["distinct_devices"] == 1            # both ranks of this test sit on the box's one GPU, and the line says so
 
 
+def test_torchrun_one_rank_over_rccl():
+    """the driver's launcher with the backend it uses -- torch.distributed.run + nccl (= RCCL) -- with ONE rank on the box's one GPU: the process
+    group is built on the device, and the barriers, the max / sum reductions, the object and tensor gathers of the headline all cross RCCL
+    (world size 1; two ranks cannot share a GPU under RCCL, so the 2-rank tests above use gloo)"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                        "--log2n", "16", "--no-extras", "--cpu-log2n", "12"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _check(_last_line(r.stdout), 1, 4, 1)
+    assert d["per_rank_oracle_check"]["ranks_all_exact"] is True and d["cpu_baseline"]["value"] > 0 and d["oracle_bitexact_gates"] == 1 << 12
+
+
 def test_torchrun_two_ranks_strong_scaling():
     """--scaling strong: a fixed total (here 2^17 gates per step) cut into one contiguous range per rank"""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): the rocprofv3 passes behind the bench line of the current round.  ROUND=r04 tools/profile.sh
+# Runs ON THE GPU BOX (via gpurun): the rocprofv3 passes behind the bench line of the current round.  ROUND=r06 tools/profile.sh
 # Outputs under gpurun_out/prof_$ROUND/ (scratch); `tools/profile.sh collect` (run locally afterwards) copies the summaries into profiles/$ROUND*.
-#   bench_default_run.json / bench_driver_shape_run.json     the default `python bench.py` and the driver's shape (--steps 20 --warmup 5)
+#   bench_default_run.json / bench_driver_shape_run.json     the default `python bench.py` and the driver's shape (--steps 20 --warmup 5): the compact line;
+#   bench_default_detail.json / bench_driver_shape_detail.json   every leg's full record of the same runs
 #   trace_default/       --kernel-trace --stats of the default bench command
 #   trace_split/ pmc_{fetch,write}_split/   the split-layout loop alone: kernel stats, FETCH_SIZE / WRITE_SIZE per launch (separate passes)
 #   trace_aos/   pmc_{fetch,write}_aos/     the same for the arkworks AoS layout
@@ -12,7 +13,7 @@
 #   bench_group_e2e.jsonl                       `bench.py --single-process --only-e2e` with 1, 2, 4, 8 members sharing device 0 (2^20 gates in total)
 # Summary: tools/summarize_prof.py
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
 if [ "${1:-}" = "collect" ]; then
@@ -20,6 +21,7 @@ if [ "${1:-}" = "collect" ]; then
   S=$OUT
   mkdir -p profiles/$ROUND profiles/${ROUND}_host profiles/${ROUND}_ec profiles/${ROUND}_e2e
   cp $S/summary.txt $S/bench_default_run.json $S/bench_driver_shape_run.json $S/bench_default_under_rocprof.json $S/clock_effect.json profiles/$ROUND/
+  cp $S/bench_default_detail.json $S/bench_driver_shape_detail.json profiles/$ROUND/
   [ -f $S/bench_single_process.jsonl ] && cp $S/bench_single_process.jsonl profiles/$ROUND/
   for f in bench_circuit_run.json bench_group_e2e.jsonl; do [ -f $S/$f ] && cp $S/$f profiles/${ROUND}_e2e/; done
   [ -f $S/circuit_trace/circuit_kernel_stats.csv ] && cp $S/circuit_trace/circuit_kernel_stats.csv $S/circuit_trace/circuit_memory_copy_stats.csv profiles/${ROUND}_e2e/ 2>/dev/null
@@ -60,8 +62,9 @@ export TMPDIR=/tmp
 cd /tmp
 B="python $REPO/bench.py"
 A="--steps 100 --warmup 10 --no-cpu-baseline --no-extras --no-cold"
-$B > $OUT/bench_default_run.json 2> $OUT/bench_default_run.log
-$B --steps 20 --warmup 5 > $OUT/bench_driver_shape_run.json 2> $OUT/bench_driver_shape_run.log
+# (bench.py ends stdout with ONE compact line; every leg's full record goes to --detail-file)
+$B --detail-file $OUT/bench_default_detail.json > $OUT/bench_default_run.json 2> $OUT/bench_default_run.log
+$B --steps 20 --warmup 5 --detail-file $OUT/bench_driver_shape_detail.json > $OUT/bench_driver_shape_run.json 2> $OUT/bench_driver_shape_run.log
 $B --only-e2e > $OUT/bench_e2e_run.json 2> $OUT/bench_e2e_run.log
 $B --only-circuit > $OUT/bench_circuit_run.json 2> $OUT/bench_circuit_run.log
 for d in "0" "0,0" "0,0,0,0" "0,0,0,0,0,0,0,0"; do
@@ -70,7 +73,7 @@ for d in "0" "0,0" "0,0,0,0" "0,0,0,0,0,0,0,0"; do
 done
 mkdir -p $OUT/circuit_trace
 rocprofv3 --kernel-trace --memory-copy-trace --stats -f csv -d $OUT/circuit_trace -o circuit -- $B --only-circuit --circuit-depth 4 > $OUT/circuit_trace/bench_circuit_under_rocprof.json 2> $OUT/circuit_trace/rocprof.log
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_default -o trace -- $B > $OUT/bench_default_under_rocprof.json 2> $OUT/trace_default.log
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_default -o trace -- $B --detail-file $OUT/bench_default_under_rocprof_detail.json > $OUT/bench_default_under_rocprof.json 2> $OUT/trace_default.log
 for L in split aos; do
   rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_$L -o trace -- $B --layout $L $A > $OUT/bench_trace_$L.json 2> $OUT/trace_$L.log
   rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch_$L -o fetch -- $B --layout $L $A > $OUT/bench_fetch_$L.json 2> $OUT/fetch_$L.log
