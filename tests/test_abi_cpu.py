@@ -139,3 +139,15 @@ def test_hostmul_sessions_from_c_on_gpu(tmp_path):
     import subprocess
     r = subprocess.run([_build_c_smoke(tmp_path, "hostmul_session")], capture_output=True, text=True)
     assert r.returncode == 0 and "hostmul sessions ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pin_registry_bookkeeping_unit(tmp_path):
+    """tests/cpp/pin_registry_unit.hip: the retired-interval set and the entry lookups of PinRegistry (csrc/arkmpc_internal.hpp) against a page
+    bitmap -- the bookkeeping behind "zero-copy kernels only see addresses in their first registered life".  Host-only: no HIP call is made."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pin_registry_unit")
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O1", "-std=c++17", "-w", "-o", exe,
+                           os.path.join(root, "tests", "cpp", "pin_registry_unit.hip")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "pin registry unit ok" in r.stdout, r.stdout + r.stderr
