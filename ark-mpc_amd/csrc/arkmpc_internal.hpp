@@ -381,7 +381,8 @@ static inline Place classify(arkmpc_ctx* ctx, const void* p, size_t bytes) {
     pl.dev = attr.devicePointer;
     pl.ours = ours;
     pl.reused = reused;
-    if (reused && !ours && !((uintptr_t)pl.dev & 15)) ctx->stats.zc_refused_reused_address++;           // a caller-held vector that would otherwise be addressed in place
+    // a caller-held vector that would otherwise be addressed in place (atomic: group members classify through member 0's context from their own threads)
+    if (reused && !ours && !((uintptr_t)pl.dev & 15)) __atomic_fetch_add(&ctx->stats.zc_refused_reused_address, 1, __ATOMIC_RELAXED);
     return pl;
 }
 // The same for a vector a kernel is going to address in place: the registry reference is taken FIRST (HostPins::keep), the pointer is looked

@@ -283,9 +283,14 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
  * the library registered itself: on this platform such a kernel can read stale memory when the vector's address had an earlier registered life
  * (freed, handed out again by malloc with other physical pages) -- DESIGN section 4.  Kernels address in place only what the CALLER holds in
  * pinned memory: arkmpc_host_alloc, or arkmpc_host_register ONCE for a vector it keeps (register once, not per gate).  ARKMPC_PIN_IN_PLACE=0
- * never registers (the runtime's pageable copies, about half the rate), ARKMPC_ZC_ON_OWN_PINS=1 lifts the rule. */
+ * never registers (the runtime's pageable copies, about half the rate). */
 int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK */
-int arkmpc_host_unregister(void* ptr);
+int arkmpc_host_unregister(void* ptr);                  /* drops what arkmpc_host_register took; memory pinned by somebody else is left alone */
+/* FIRST-LIFE RULE (round 6): every registration made through this library -- the per-call pins of pageable vectors and arkmpc_host_register --
+ * is tracked process-wide; when it ends its pages are RETIRED, and a vector registered later over retired addresses (a fresh Vec per gate gets
+ * recycled addresses from the allocator) is never addressed by a kernel: it takes the DMA pipeline, same words, and is counted in
+ * arkmpc_ctx_stats.zc_refused_reused_address.  So: register long-lived memory ONCE (or use arkmpc_host_alloc, whose blocks are recycled without
+ * ever being unregistered), and arkmpc_host_unregister BEFORE freeing -- freeing registered memory is undefined for the HIP runtime too. */
 int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc), RECYCLED: a freed block comes back from a free list by size */
 int arkmpc_host_free(void* ptr);                        /* class in microseconds (the runtime's own alloc + free of 64 MiB cost 16 ms); contents are not cleared */
 int arkmpc_host_trim(void);                             /* returns the free list (at most ARKMPC_HOST_POOL_MB, default 4096 MiB) to the runtime */
