@@ -290,7 +290,9 @@ int arkmpc_host_unregister(void* ptr);                  /* drops what arkmpc_hos
  * is tracked process-wide; when it ends its pages are RETIRED, and a vector registered later over retired addresses (a fresh Vec per gate gets
  * recycled addresses from the allocator) is never addressed by a kernel: it takes the DMA pipeline, same words, and is counted in
  * arkmpc_ctx_stats.zc_refused_reused_address.  So: register long-lived memory ONCE (or use arkmpc_host_alloc, whose blocks are recycled without
- * ever being unregistered), and arkmpc_host_unregister BEFORE freeing -- freeing registered memory is undefined for the HIP runtime too. */
+ * ever being unregistered), and arkmpc_host_unregister BEFORE freeing -- freeing registered memory is undefined for the HIP runtime too.
+ * Memory the caller pins with the runtime directly (hipHostRegister, hipHostMalloc, torch's pinned tensors) is outside this bookkeeping: it is
+ * addressed in place, and a caller that re-registers recycled addresses that way owns the rule itself. */
 int arkmpc_host_alloc(size_t bytes, void** out_ptr);    /* pinned allocation (hipHostMalloc), RECYCLED: a freed block comes back from a free list by size */
 int arkmpc_host_free(void* ptr);                        /* class in microseconds (the runtime's own alloc + free of 64 MiB cost 16 ms); contents are not cleared */
 int arkmpc_host_trim(void);                             /* returns the free list (at most ARKMPC_HOST_POOL_MB, default 4096 MiB) to the runtime */
