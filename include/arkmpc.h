@@ -284,7 +284,7 @@ int arkmpc_beaver_finish_fused_from(arkmpc_ctx* ctx, size_t n, int party_id, con
  * (freed, handed out again by malloc with other physical pages) -- DESIGN section 4.  Kernels address in place only what the CALLER holds in
  * pinned memory: arkmpc_host_alloc, or arkmpc_host_register ONCE for a vector it keeps (register once, not per gate).  ARKMPC_PIN_IN_PLACE=0
  * never registers (the runtime's pageable copies, about half the rate). */
-int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK */
+int arkmpc_host_register(void* ptr, size_t bytes);      /* already registered = ARKMPC_OK (ARKMPC_ERR_BAD_ARG if the same pointer is registered again with a LARGER size: unregister first) */
 int arkmpc_host_unregister(void* ptr);                  /* drops what arkmpc_host_register took; memory pinned by somebody else is left alone */
 /* FIRST-LIFE RULE (round 6): every registration made through this library -- the per-call pins of pageable vectors and arkmpc_host_register --
  * is tracked process-wide; when it ends its pages are RETIRED, and a vector registered later over retired addresses (a fresh Vec per gate gets

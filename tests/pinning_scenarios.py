@@ -74,6 +74,12 @@ def main():
     res["second_life_same_pages"] = session(eng, v)
     assert all(unreg(a) == 0 for a in v.values())
 
+    # registering the same pointer again is harmless -- unless the second call asks for more than the first one pinned
+    grow = FreshVA.zeros(1 << 18)
+    assert reg(grow[: 1 << 17]) == 0 and reg(grow[: 1 << 17]) == 0 and reg(grow[: 1 << 16]) == 0
+    assert reg(grow) != 0
+    assert unreg(grow[: 1 << 17]) == 0 and reg(grow) == 0 and unreg(grow) == 0
+
     # C: register -> session -> unregister -> free -> the same addresses handed out again with NEW pages -> register -> session
     v = vectors()
     assert all(reg(a) == 0 for a in v.values())
