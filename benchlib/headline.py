@@ -22,7 +22,8 @@ class Ranks:
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():          # (always, where bench.py runs; the class itself is also exercised on CPU with gloo: tests/test_sharding_gloo.py)
+            torch.cuda.synchronize()
 
     def reduce(self, v, op):
         if self.dist is None:

@@ -136,3 +136,35 @@ def test_sharded_msm_equals_unsharded(oracle):
     for pr in procs: pr.join(timeout=60)
     assert all(pr.exitcode == 0 for pr in procs)
     assert same and m0 in (18, 19)
+
+
+def _ranks_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from benchlib.headline import Ranks, short_device
+    r = Ranks(dist, world, rank, rank, "gloo")
+    r.barrier()
+    got = {"max": r.reduce(10.0 + rank, "MAX"), "min": r.reduce(10.0 + rank, "MIN"), "sum": r.reduce(1.0, "SUM"),
+           "floats": r.gather_floats(0.5 * (rank + 1)),
+           "objs": [short_device(o) for o in r.gather_objects({"local_device": rank, "pci_bus_id": 160 + rank, "pid": 1})]}
+    r.barrier()
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_rank_plumbing_over_gloo():
+    """bench.py's process-group plumbing (benchlib/headline.py Ranks: the barrier, MAX / MIN / SUM over ranks, the per-rank float and object
+    gathers behind `ms_per_step`, `ranks_seen`, `rank_devices`) with two real processes over gloo: every rank must see the same, whole picture"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ranks_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs: p.join(timeout=60)
+    for rank in range(world):
+        g = res[rank]
+        assert g["max"] == 11.0 and g["min"] == 10.0 and g["sum"] == 2.0
+        assert g["floats"] == [0.5, 1.0] and g["objs"] == ["0@pci160", "1@pci161"]
