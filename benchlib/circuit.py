@@ -187,7 +187,8 @@ def leg_circuit(pkg, eng, dev, log2n=20, depth=8):
     for q in hold:
         lib.arkmpc_host_free(q)
     best = modes["prefetched_async"]
-    summary = {"circuit_party_gates_per_s": best["party_gates_per_s"], "circuit_frac_of_link_floor": best["frac_of_link_floor"]}
+    summary = {"circuit_party_gates_per_s": best["party_gates_per_s"], "circuit_two_party_gates_per_s": best["party_gates_per_s"] / 2,
+               "circuit_frac_of_link_floor": best["frac_of_link_floor"]}
     return summary, {"what": "depth-%d chain z <- z * y of batch_mul gates at 2^%d, operands resident (split columns), both parties on this ONE GPU and its one host link, d||e handed "
                     "over in HBM, every gate on fresh random triples from host memory (192 B per party-gate over the link); wall clock from the first import to the last "
                     "kernel, the first gate's triples NOT read ahead" % (depth, log2n),

@@ -37,7 +37,7 @@ def _full_line(world=8):
                                  "cpu_model": "AMD EPYC 9575F 64-Core Processor", "compiler": "gcc (Ubuntu 11.4.0-1ubuntu1~22.04.2) 11.4.0", "flags": "-O3 -march=native -fPIC -pthread",
                                  "cargo_probe": "absent"})
     for k in ("aos_pipeline_frac_of_hbm_peak", "aos_gates_per_s", "end_to_end_party_gates_per_s", "end_to_end_two_party_gates_per_s", "end_to_end_frac_of_measured_pcie",
-              "circuit_party_gates_per_s", "circuit_frac_of_link_floor", "config4_ms", "config4_scalar_muls_per_s", "config4_frac_of_int_alu_peak", "config5_end_to_end_ms",
+              "circuit_party_gates_per_s", "circuit_two_party_gates_per_s", "circuit_frac_of_link_floor", "config4_ms", "config4_scalar_muls_per_s", "config4_frac_of_int_alu_peak", "config5_end_to_end_ms",
               "config5_device_ms", "config5_host_sha3_share_of_end_to_end", "config5_device_frac_of_hbm_peak", "config5_split_device_frac_of_hbm_peak"):
         line[k] = f
     return line
