@@ -34,6 +34,6 @@ for v in "${VALS[@]}"; do
     env $VAR=$v python "$R/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-extras --no-cold "$@" 2>/dev/null | python3 -c "
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$VAR=$v', 'value %.4e' % d['value'], 'ms_per_step %.5f' % d['ms_per_step'], 'k1 %.5f' % d['pipeline']['k1_avg_launch_ms'], 'k3 %.5f' % d['roofline']['avg_launch_ms'], 'frac %.4f' % d['roofline']['frac'], d['results_check'][-2:])"
+print('$VAR=$v', 'value %.4e' % d['value'], 'ms_per_step %.5f' % d['ms_per_step'], 'k1 %.5f' % d['k1_avg_launch_ms'], 'k3 %.5f' % d['roofline']['avg_launch_ms'], 'frac %.4f' % d['roofline']['frac'], d['results_check'][-2:])"
   fi
 done
