@@ -62,6 +62,48 @@ template <int V> static void run(const char* name, const unsigned char* buf, siz
            nrec * 64.0 / (ms * 1e-3) / 1e9);
 }
 
+// K1's own pattern on split columns: one 32-byte element per lane from each of four columns (two 16-byte loads 16 B apart, lanes 32 B apart),
+// two 32-byte elements written.  LD: 0 plain, 1 non-temporal, 2 buffer loads with sc0 sc1 nt; ST: 0 plain, 1 non-temporal
+template <int LD, int ST> __global__ void __launch_bounds__(256) k_k1like(size_t n, const unsigned char* x, const unsigned char* y, const unsigned char* a, const unsigned char* b,
+                                                                         unsigned char* d, unsigned char* e) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32x4 v[8];
+    const unsigned char* src[4] = {x, a, y, b};
+    for (int k = 0; k < 4; ++k) {
+        if (LD == 2) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src[k], 0, 0x7fffffff, 0x00027000);
+            v[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(32 * i), 0, 7);
+            v[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(32 * i + 16), 0, 7);
+        } else {
+            const u32x4* p = (const u32x4*)(src[k] + 32 * i);
+            v[2 * k] = LD == 1 ? __builtin_nontemporal_load(p) : p[0];
+            v[2 * k + 1] = LD == 1 ? __builtin_nontemporal_load(p + 1) : p[1];
+        }
+    }
+    const u32x4 d0 = v[0] - v[2], d1 = v[1] - v[3], e0 = v[4] - v[6], e1 = v[5] - v[7];
+    u32x4* pd = (u32x4*)(d + 32 * i); u32x4* pe = (u32x4*)(e + 32 * i);
+    if (ST == 1) { __builtin_nontemporal_store(d0, pd); __builtin_nontemporal_store(d1, pd + 1); __builtin_nontemporal_store(e0, pe); __builtin_nontemporal_store(e1, pe + 1); }
+    else { pd[0] = d0; pd[1] = d1; pe[0] = e0; pe[1] = e1; }
+}
+#define K1_SETS 6
+template <int LD, int ST> static void run_k1(const char* name, unsigned char* buf, size_t n) {
+    // SETS rotating sets of (x, y, a, b, d, e), 32 n bytes each (inputs alone: 128 MiB per set), so that nothing of a launch is still in the
+    // 256 MiB Infinity Cache when its set comes round again -- with two sets and non-temporal stores it is: 28.6 us, an artefact
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto launch = [&](int set) {
+        unsigned char* base = buf + (size_t)set * 6 * 32 * n;
+        hipLaunchKernelGGL((k_k1like<LD, ST>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, base, base + 32 * n, base + 64 * n, base + 96 * n, base + 128 * n, base + 160 * n);
+    };
+    for (int w = 0; w < K1_SETS; ++w) launch(w);
+    CK(hipEventRecord(e0));
+    const int reps = 48;
+    for (int r = 0; r < reps; ++r) launch(r % K1_SETS);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    printf("{\"variant\": \"k1like_%s\", \"gates\": %zu, \"us\": %.2f, \"GBps_on_192B_per_gate\": %.1f}\n", name, n, ms * 1e3, n * 192.0 / (ms * 1e-3) / 1e9);
+}
+
 int main() {
     const size_t nrec = (size_t)1 << 23;          // 2^23 records x 64 B = 512 MiB
     unsigned char* buf; uint32_t* sink;
@@ -74,5 +116,14 @@ int main() {
     run<5>("half2_buffer_slc", buf, nrec, sink, 32);
     run<6>("half2_buffer_glc_slc_dlc", buf, nrec, sink, 32);
     run<7>("half8", buf, nrec, sink, 32);
+    CK(hipFree(buf));
+    const size_t n = (size_t)1 << 20;             // K1 at the headline's batch: K1_SETS sets x 6 columns x 32 MiB
+    unsigned char* cols; CK(hipMalloc(&cols, (size_t)K1_SETS * 6 * 32 * n)); CK(hipMemset(cols, 3, (size_t)K1_SETS * 6 * 32 * n));
+    run_k1<0, 0>("plain_plain", cols, n);
+    run_k1<1, 0>("nt_plain", cols, n);
+    run_k1<1, 1>("nt_nt", cols, n);
+    run_k1<2, 0>("buffer_sc0sc1nt_plain", cols, n);
+    run_k1<2, 1>("buffer_sc0sc1nt_nt", cols, n);
+    run_k1<0, 1>("plain_nt", cols, n);
     return 0;
 }
